@@ -1,0 +1,78 @@
+// Shared device/host helpers for the Foley HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef uint16_t bf16_t;  // storage type for bf16 in global/LDS memory
+
+// ---- dtype codes shared with include/foley_hip.h -------------------------------------------
+enum { FOLEY_F32 = 0, FOLEY_BF16 = 1, FOLEY_I32 = 2 };
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even, NaN preserved (matches torch .to(bfloat16))
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Cvt;
+template <> struct Cvt<float> {
+  static __device__ __forceinline__ float to(float v) { return v; }
+  static __device__ __forceinline__ float from(float v) { return v; }
+};
+template <> struct Cvt<bf16_t> {
+  static __device__ __forceinline__ bf16_t to(float v) { return f32_to_bf16(v); }
+  static __device__ __forceinline__ float from(bf16_t v) { return bf16_to_f32(v); }
+};
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+// torch GELU(approximate="tanh")
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float inner = k0 * (x + k1 * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(inner));
+}
+// DAC snake: x + (alpha + 1e-9)^-1 * sin(alpha x)^2
+__device__ __forceinline__ float snake_f(float x, float alpha, float inv_alpha) {
+  float s = sinf(alpha * x);
+  return x + inv_alpha * (s * s);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Row-broadcast operand addressing shared by the row kernels and GEMM epilogues.
+//   mode 0: one vector for every row            (index 0)
+//   mode 1: rows ordered [cfg][clip][l]; operand indexed [cfg][l]
+struct RowBcast {
+  const float* p;       // base (may be null => operand absent)
+  long ld;              // elements between operand rows
+  int mode;             // see above
+  int rows_per_cfg;     // clips * L
+  int L;                // tokens per clip
+  const int* step_ptr;  // optional device-resident iteration counter
+  long step_stride;     // elements added per iteration
+};
+
+__device__ __forceinline__ const float* rb_row(const RowBcast& b, int r) {
+  const float* p = b.p;
+  if (b.step_ptr) p += (long)(*b.step_ptr) * b.step_stride;
+  if (b.mode == 1) p += ((long)(r / b.rows_per_cfg) * b.L + (r % b.L)) * b.ld;
+  return p;
+}
+
+#define FOLEY_CHECK_HIP(expr)                                         \
+  do {                                                                \
+    hipError_t _e = (expr);                                           \
+    if (_e != hipSuccess) return foley_set_err(hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+int foley_set_err(const char* msg, const char* file, int line);

@@ -1,0 +1,793 @@
+// Runtime of libfoley_hip.so: context, packed-weight registry, step-invariant precompute, the DiT
+// forward, the device-resident sampler loop and the DAC decoder - all as sequences of launches
+// of the kernels in gemm.hip / attention.hip / rowops.hip on the caller's stream.  C ABI in
+// include/foley_hip.h.  No torch types, no CPU fallback.
+#include "../../include/foley_hip.h"
+#include "kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+// --------------------------------------------------------------------------- errors
+static thread_local std::string g_err;
+int foley_set_err(const char* msg, const char* file, int line) {
+  const char* base = strrchr(file, '/');
+  g_err = std::string(msg) + " (" + (base ? base + 1 : file) + ":" + std::to_string(line) + ")";
+  return FOLEY_ERR_INVALID;
+}
+#define FAIL(code, msg) (foley_set_err(msg, __FILE__, __LINE__), (code))
+#define TRY(expr)            \
+  do {                       \
+    int _rc = (expr);        \
+    if (_rc != 0) return _rc; \
+  } while (0)
+#define HIPTRY(expr)                                                     \
+  do {                                                                   \
+    hipError_t _e = (expr);                                              \
+    if (_e != hipSuccess) {                                              \
+      foley_set_err(hipGetErrorString(_e), __FILE__, __LINE__);          \
+      return FOLEY_ERR_HIP;                                              \
+    }                                                                    \
+  } while (0)
+
+// --------------------------------------------------------------------------- context
+struct TensorRef {
+  const void* p = nullptr;
+  int dtype = 0;
+  std::vector<int64_t> shape;
+  int64_t numel() const {
+    int64_t n = 1;
+    for (auto s : shape) n *= s;
+    return n;
+  }
+};
+
+struct DevBuf {  // context-owned workspace block
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct foley_ctx {
+  int device = 0;
+  foley_config cfg{};
+  std::unordered_map<std::string, TensorRef> tensors;
+  // run state (valid after foley_prepare)
+  bool prepared = false;
+  foley_plan plan{};
+  std::vector<DevBuf> owned;        // everything hipMalloc'ed for the current plan
+  // prepared tables
+  float* vec_table = nullptr;       // [n_iter, D]
+  float* modtab = nullptr;          // [n_triple][2][n_iter][9D]
+  float* txt_k = nullptr;           // [n_triple][ncfg, H, Lt, 128]
+  float* txt_v = nullptr;
+  float* v_cond0 = nullptr;         // [ncfg, Lv, D]
+  float* add_sync = nullptr;        // [ncfg, La, D]
+  int* ident_idx = nullptr;         // 0..max(Lv,La)-1
+  // forward workspace
+  void* xin = nullptr;              // T [M, C]
+  float* audio = nullptr;           // [M, D]
+  float* vcond = nullptr;           // [Mv, D]
+  void* xn_a = nullptr;             // T [M, D]
+  void* xn_v = nullptr;             // T [Mv, D]
+  float* qkv_a = nullptr;           // [M, 3D]
+  float* qkv_v = nullptr;           // [Mv, 3D]
+  float* Q = nullptr;               // [Bc, H, S, 128]
+  float* K = nullptr;
+  float* V = nullptr;
+  void* att_a = nullptr;            // T [M, D]
+  void* att_v = nullptr;            // T [Mv, D]
+  void* hid_a = nullptr;            // T [M, max(mlp_hidden, conv_hidden)]
+  void* hid_v = nullptr;            // T [Mv, mlp_hidden]
+  void* svec = nullptr;             // T [ncfg*La, D]
+  float* smod = nullptr;            // [ncfg*La, 6D]
+  float* pred = nullptr;            // [M, C]
+  float* x_saved = nullptr;         // [clips, C, La]
+  float* d_acc = nullptr;
+  int* step_ctr = nullptr;
+  // graph
+  hipGraphExec_t graph_exec = nullptr;
+  float* graph_latents = nullptr;   // latents pointer baked into the captured iteration
+  // timing
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  // DAC workspace (grown on demand)
+  DevBuf dacP, dacQ, dacR, dacZ;
+};
+
+static size_t esize(int dtype) { return dtype == FOLEY_BF16 ? 2 : 4; }
+
+static int ctx_alloc(foley_ctx* c, size_t bytes, void** out) {
+  void* p = nullptr;
+  bytes = (bytes + 255) & ~(size_t)255;
+  hipError_t e = hipMalloc(&p, bytes ? bytes : 256);
+  if (e != hipSuccess) return FAIL(FOLEY_ERR_HIP, hipGetErrorString(e));
+  c->owned.push_back({p, bytes});
+  *out = p;
+  return 0;
+}
+
+static void ctx_free_plan(foley_ctx* c) {
+  if (c->graph_exec) {
+    hipGraphExecDestroy(c->graph_exec);
+    c->graph_exec = nullptr;
+  }
+  for (auto& b : c->owned) hipFree(b.p);
+  c->owned.clear();
+  c->prepared = false;
+}
+
+static int grow(DevBuf& b, size_t bytes) {
+  if (b.bytes >= bytes) return 0;
+  if (b.p) hipFree(b.p);
+  b.p = nullptr;
+  b.bytes = 0;
+  hipError_t e = hipMalloc(&b.p, bytes);
+  if (e != hipSuccess) return FAIL(FOLEY_ERR_HIP, hipGetErrorString(e));
+  b.bytes = bytes;
+  return 0;
+}
+
+static int get_tensor(foley_ctx* c, const std::string& name, int dtype, std::initializer_list<int64_t> shape,
+                      const void** out) {
+  auto it = c->tensors.find(name);
+  if (it == c->tensors.end()) {
+    g_err = "tensor '" + name + "' was not registered";
+    return FOLEY_ERR_MISSING;
+  }
+  const TensorRef& t = it->second;
+  bool ok = t.dtype == dtype && t.shape.size() == shape.size();
+  if (ok) {
+    size_t i = 0;
+    for (auto s : shape) ok = ok && (t.shape[i++] == s);
+  }
+  if (!ok) {
+    g_err = "tensor '" + name + "' has the wrong dtype/shape";
+    return FOLEY_ERR_INVALID;
+  }
+  *out = t.p;
+  return 0;
+}
+
+// --------------------------------------------------------------------------- launch helpers
+static RowBcast rb_none() { return RowBcast{nullptr, 0, 0, 1, 1, nullptr, 0}; }
+
+struct Lin {  // a packed linear / conv-as-GEMM layer
+  const void* w = nullptr;
+  const float* b = nullptr;
+  int N = 0, K = 0;
+};
+
+static int get_lin(foley_ctx* c, const std::string& name, int dtype, int N, int K, bool bias, Lin* out) {
+  const void* w;
+  TRY(get_tensor(c, name + ".w", dtype, {N, K}, &w));
+  out->w = w;
+  out->N = N;
+  out->K = K;
+  out->b = nullptr;
+  if (bias) {
+    const void* b;
+    TRY(get_tensor(c, name + ".b", FOLEY_F32, {N}, &b));
+    out->b = (const float*)b;
+  }
+  return 0;
+}
+
+// plain linear layer over M rows
+static GemmArgs gemm_plain(const void* A, int M, const Lin& l, void* out, long ldc) {
+  GemmArgs g{};
+  g.A = A; g.W = l.w; g.bias = l.b;
+  g.M = M; g.N = l.N; g.K = l.K; g.lda = l.K;
+  g.segV = M > 0 ? M : 1; g.segS = g.segV; g.taps = 1; g.tapC = l.K; g.dil = 1; g.tap0 = 0;
+  g.out0 = out; g.out1 = nullptr;
+  g.osegV = g.segV; g.out_seg = 0; g.out_row = ldc; g.out_shift = 0; g.out_check = 0;
+  g.rb = rb_none(); g.res = nullptr; g.alpha = nullptr; g.alphaC = 1;
+  return g;
+}
+
+// channels-last conv (k taps, dilation d, 'same' padding) over segments of `seg` rows
+static GemmArgs gemm_conv(const void* A, int M, int seg, int C, int taps, int dil, const Lin& l, void* out,
+                          long ldc) {
+  GemmArgs g = gemm_plain(A, M, l, out, ldc);
+  g.lda = C;
+  g.segV = seg; g.segS = seg; g.taps = taps; g.tapC = C; g.dil = dil; g.tap0 = -((taps - 1) / 2) * dil;
+  return g;
+}
+
+// --------------------------------------------------------------------------- C ABI: context
+extern "C" uint32_t foley_abi_version(void) { return FOLEY_ABI_VERSION; }
+extern "C" const char* foley_last_error(void) { return g_err.c_str(); }
+
+extern "C" int foley_ctx_create(int device, const foley_config* cfg, foley_ctx** out) {
+  if (!cfg || !out) return FAIL(FOLEY_ERR_INVALID, "null argument");
+  if (cfg->hidden % cfg->heads || cfg->hidden / cfg->heads != 128)
+    return FAIL(FOLEY_ERR_INVALID, "head_dim must be 128");
+  if (cfg->compute_dtype != FOLEY_DT_F32 && cfg->compute_dtype != FOLEY_DT_BF16)
+    return FAIL(FOLEY_ERR_INVALID, "compute_dtype must be f32 or bf16");
+  if (cfg->dac_n_rates < 1 || cfg->dac_n_rates > 8) return FAIL(FOLEY_ERR_INVALID, "bad dac_n_rates");
+  int ndev = 0;
+  HIPTRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return FAIL(FOLEY_ERR_INVALID, "no such HIP device");
+  HIPTRY(hipSetDevice(device));
+  foley_ctx* c = new foley_ctx();
+  c->device = device;
+  c->cfg = *cfg;
+  hipEventCreate(&c->ev0);
+  hipEventCreate(&c->ev1);
+  *out = c;
+  return 0;
+}
+
+extern "C" void foley_ctx_destroy(foley_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  ctx_free_plan(c);
+  for (DevBuf* b : {&c->dacP, &c->dacQ, &c->dacR, &c->dacZ})
+    if (b->p) hipFree(b->p);
+  if (c->ev0) hipEventDestroy(c->ev0);
+  if (c->ev1) hipEventDestroy(c->ev1);
+  delete c;
+}
+
+extern "C" int foley_set_tensor(foley_ctx* c, const char* name, const void* p, int dtype, int ndim,
+                                const int64_t* shape) {
+  if (!c || !name || !p || ndim < 0 || ndim > 8) return FAIL(FOLEY_ERR_INVALID, "bad tensor registration");
+  if (((uintptr_t)p) & 15) return FAIL(FOLEY_ERR_INVALID, "tensor pointers must be 16-byte aligned");
+  TensorRef t;
+  t.p = p;
+  t.dtype = dtype;
+  t.shape.assign(shape, shape + ndim);
+  c->tensors[name] = t;
+  c->prepared = false;  // cached tables depend on the weights
+  return 0;
+}
+
+extern "C" int foley_last_elapsed_ms(foley_ctx* c, float* ms) {
+  if (!c || !ms || !c->timed) return FAIL(FOLEY_ERR_STATE, "nothing timed yet");
+  HIPTRY(hipEventSynchronize(c->ev1));
+  HIPTRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return 0;
+}
+
+// --------------------------------------------------------------------------- prepare
+// Everything that does not depend on the latents: time embedding for every loop
+// iteration, the triple blocks' AdaLN tables, text K/V per block, cond/visual/sync embedders.
+extern "C" int foley_prepare(foley_ctx* c, const foley_plan* pl, void* stream_v) {
+  if (!c || !pl) return FAIL(FOLEY_ERR_INVALID, "null argument");
+  hipStream_t st = (hipStream_t)stream_v;
+  HIPTRY(hipSetDevice(c->device));
+  const foley_config& f = c->cfg;
+  if (pl->ncfg < 1 || pl->ncfg > 2 || pl->clips < 1 || pl->La < 1 || pl->Lv < 1 || pl->Ls < 8 || pl->Ls % 8 ||
+      pl->Lt < 1 || pl->n_iter < 1)
+    return FAIL(FOLEY_ERR_INVALID, "bad plan dimensions");
+  if (pl->rope_len < 2 * pl->La) return FAIL(FOLEY_ERR_INVALID, "rope table shorter than 2*La");
+  HIPTRY(hipStreamSynchronize(st));
+  ctx_free_plan(c);
+  c->plan = *pl;
+
+  const int D = f.hidden, H = f.heads, C = f.latent_dim, T = f.compute_dtype;
+  const size_t es = esize(T);
+  const int ncfg = pl->ncfg, clips = pl->clips, La = pl->La, Lv = pl->Lv, Ls = pl->Ls, Lt = pl->Lt;
+  const int Bc = ncfg * clips, M = Bc * La, Mv = Bc * Lv, S = La + Lv, NI = pl->n_iter;
+  const int hidmax = f.mlp_hidden > f.conv_hidden ? f.mlp_hidden : f.conv_hidden;
+
+#define ALLOC(ptr, bytes) TRY(ctx_alloc(c, (bytes), (void**)&(ptr)))
+  ALLOC(c->vec_table, (size_t)NI * D * 4);
+  ALLOC(c->modtab, (size_t)f.depth_triple * 2 * NI * 9 * D * 4);
+  ALLOC(c->txt_k, (size_t)f.depth_triple * ncfg * H * Lt * 128 * 4);
+  ALLOC(c->txt_v, (size_t)f.depth_triple * ncfg * H * Lt * 128 * 4);
+  ALLOC(c->v_cond0, (size_t)ncfg * Lv * D * 4);
+  ALLOC(c->add_sync, (size_t)ncfg * La * D * 4);
+  ALLOC(c->xin, (size_t)M * C * es);
+  ALLOC(c->audio, (size_t)M * D * 4);
+  ALLOC(c->vcond, (size_t)Mv * D * 4);
+  ALLOC(c->xn_a, (size_t)M * D * es);
+  ALLOC(c->xn_v, (size_t)Mv * D * es);
+  ALLOC(c->qkv_a, (size_t)M * 3 * D * 4);
+  ALLOC(c->qkv_v, (size_t)Mv * 3 * D * 4);
+  ALLOC(c->Q, (size_t)Bc * H * S * 128 * 4);
+  ALLOC(c->K, (size_t)Bc * H * S * 128 * 4);
+  ALLOC(c->V, (size_t)Bc * H * S * 128 * 4);
+  ALLOC(c->att_a, (size_t)M * D * es);
+  ALLOC(c->att_v, (size_t)Mv * D * es);
+  ALLOC(c->hid_a, (size_t)M * hidmax * es);
+  ALLOC(c->hid_v, (size_t)Mv * f.mlp_hidden * es);
+  ALLOC(c->svec, (size_t)ncfg * La * D * es);
+  ALLOC(c->smod, (size_t)ncfg * La * 6 * D * 4);
+  ALLOC(c->pred, (size_t)M * C * 4);
+  ALLOC(c->x_saved, (size_t)clips * C * La * 4);
+  ALLOC(c->d_acc, (size_t)clips * C * La * 4);
+  ALLOC(c->step_ctr, 256);
+  HIPTRY(hipMemsetAsync(c->step_ctr, 0, 256, st));
+
+  // scratch for the precompute (freed with the plan; small)
+  const int rmax = std::max(std::max(NI, ncfg * Lt), std::max(ncfg * Lv, ncfg * Ls));
+  void *tA, *tB;
+  float* tF;
+  ALLOC(tA, (size_t)rmax * std::max(std::max(D, f.sync_hidden), 768) * es);
+  ALLOC(tB, (size_t)rmax * std::max(std::max(D, f.sync_hidden), 768) * es);
+  ALLOC(tF, (size_t)rmax * 2 * D * 4);
+
+  // 1. time embedding table: t_feat -> Linear -> SiLU -> Linear   (embed_layers.py:104-136)
+  Lin time0, time2;
+  TRY(get_lin(c, "time0", T, D, f.time_freq_dim, true, &time0));
+  TRY(get_lin(c, "time2", T, D, D, true, &time2));
+  TRY(launch_cast(pl->t_feat, FOLEY_F32, tA, T, (long)NI * f.time_freq_dim, st));
+  TRY(launch_gemm(gemm_plain(tA, NI, time0, tB, D), T, EPI_SILU_T, 0, st));
+  TRY(launch_gemm(gemm_plain(tB, NI, time2, c->vec_table, D), T, EPI_STORE_F32, 0, st));
+
+  // 2. AdaLN tables of the triple blocks: Linear(SiLU(vec)) for every iteration (modulate_layers.py:15-16)
+  TRY(launch_rows_add_act(c->vec_table, rb_none(), NI, D, 1, tA, T, st));
+  for (int b = 0; b < f.depth_triple; ++b)
+    for (int s = 0; s < 2; ++s) {
+      Lin m;
+      TRY(get_lin(c, "t" + std::to_string(b) + (s ? ".v_mod" : ".a_mod"), T, 9 * D, D, true, &m));
+      float* dst = c->modtab + ((size_t)(b * 2 + s) * NI) * 9 * D;
+      TRY(launch_gemm(gemm_plain(tA, NI, m, dst, 9 * D), T, EPI_STORE_F32, 0, st));
+    }
+
+  // 3. text: cond_in, then per block text_cross_kv -> k RMSNorm + RoPE (hifi_foley.py:289-308, 765)
+  {
+    Lin c1, c2;
+    TRY(get_lin(c, "cond1", T, D, f.cond_dim, true, &c1));
+    TRY(get_lin(c, "cond2", T, D, D, true, &c2));
+    TRY(launch_cast(pl->text, FOLEY_F32, tA, T, (long)ncfg * Lt * f.cond_dim, st));
+    TRY(launch_gemm(gemm_plain(tA, ncfg * Lt, c1, tB, D), T, EPI_SILU_T, 0, st));
+    TRY(launch_gemm(gemm_plain(tB, ncfg * Lt, c2, tA, D), T, EPI_STORE_T, 0, st));  // tA = cond embedding
+    for (int b = 0; b < f.depth_triple; ++b) {
+      Lin kv;
+      const void* kn;
+      TRY(get_lin(c, "t" + std::to_string(b) + ".t_kv", T, 2 * D, D, true, &kv));
+      TRY(get_tensor(c, "t" + std::to_string(b) + ".t_kn", FOLEY_F32, {128}, &kn));
+      TRY(launch_gemm(gemm_plain(tA, ncfg * Lt, kv, tF, 2 * D), T, EPI_STORE_F32, 0, st));
+      QkvSplitArgs q{};
+      q.qkv = tF; q.M = ncfg * Lt; q.L = Lt; q.H = H; q.nK = 2;
+      q.gain[0] = (const float*)kn; q.pos[0] = pl->pos_linear;
+      q.dst[0] = c->txt_k + (size_t)b * ncfg * H * Lt * 128;
+      q.dst[1] = c->txt_v + (size_t)b * ncfg * H * Lt * 128;
+      q.S_tot = Lt; q.tok_off = 0; q.eps = 1e-6f; q.cos_tab = pl->rope_cos; q.sin_tab = pl->rope_sin;
+      TRY(launch_qkv_split(q, st));
+    }
+  }
+
+  // 4. visual stream input: SwiGLU projection (activation_layers.py:43-44, hifi_foley.py:770)
+  {
+    Lin w13, w2;
+    TRY(get_lin(c, "vis.w13", T, 2 * D, f.clip_dim, false, &w13));
+    TRY(get_lin(c, "vis.w2", T, D, D, false, &w2));
+    TRY(launch_cast(pl->clip, FOLEY_F32, tA, T, (long)ncfg * Lv * f.clip_dim, st));
+    TRY(launch_gemm(gemm_plain(tA, ncfg * Lv, w13, tB, D), T, EPI_SILUGATE_T, 0, st));
+    TRY(launch_gemm(gemm_plain(tB, ncfg * Lv, w2, c->v_cond0, D), T, EPI_STORE_F32, 0, st));
+  }
+
+  // 5. sync features: + pos emb, Linear, SiLU, ConvMLP(k=1), nearest-exact up-sampling (hifi_foley.py:755-762)
+  {
+    Lin s0, w13, w2;
+    const void* pos;
+    TRY(get_lin(c, "sync0", T, D, f.sync_dim, true, &s0));
+    TRY(get_lin(c, "sync.w13", T, 2 * f.sync_hidden, D, false, &w13));
+    TRY(get_lin(c, "sync.w2", T, D, f.sync_hidden, false, &w2));
+    TRY(get_tensor(c, "sync_pos", FOLEY_F32, {8, f.sync_dim}, &pos));
+    TRY(launch_add_periodic(pl->sync, (const float*)pos, ncfg * Ls, f.sync_dim, 8, tA, T, st));
+    TRY(launch_gemm(gemm_plain(tA, ncfg * Ls, s0, tB, D), T, EPI_SILU_T, 0, st));
+    TRY(launch_gemm(gemm_plain(tB, ncfg * Ls, w13, tA, f.sync_hidden), T, EPI_SILUGATE_T, 0, st));
+    TRY(launch_gemm(gemm_plain(tA, ncfg * Ls, w2, tF, D), T, EPI_STORE_F32, 0, st));
+    TRY(launch_gather_rows(tF, pl->sync_gather, La, ncfg, Ls, D, c->add_sync, st));
+  }
+  HIPTRY(hipStreamSynchronize(st));
+  c->prepared = true;
+  return 0;
+}
+
+// --------------------------------------------------------------------------- DiT forward
+static RowBcast rb_vec(const float* base, long step_stride, const int* step_ptr) {
+  return RowBcast{base, 0, 0, 1, 1, step_ptr, step_stride};
+}
+static RowBcast rb_tok(const float* base, long ld, int rows_per_cfg, int L) {
+  return RowBcast{base, ld, 1, rows_per_cfg, L, nullptr, 0};
+}
+
+static int run_forward(foley_ctx* c, hipStream_t st) {
+  const foley_config& f = c->cfg;
+  const foley_plan& pl = c->plan;
+  const int D = f.hidden, H = f.heads, C = f.latent_dim, T = f.compute_dtype;
+  const int ncfg = pl.ncfg, clips = pl.clips, La = pl.La, Lv = pl.Lv, Lt = pl.Lt, NI = pl.n_iter;
+  const int Bc = ncfg * clips, M = Bc * La, Mv = Bc * Lv, S = La + Lv;
+  const int* sp = c->step_ctr;
+
+  // audio_embedder (conv k=1 == linear over the transposed latents) + add_sync (hifi_foley.py:768, 838-839)
+  {
+    Lin ain;
+    TRY(get_lin(c, "audio_in", T, D, C, true, &ain));
+    GemmArgs g = gemm_plain(c->xin, M, ain, c->audio, D);
+    g.rb = rb_tok(c->add_sync, D, clips * La, La);
+    TRY(launch_gemm(g, T, EPI_STORE_F32, 0, st));
+  }
+  // visual stream starts from the step-invariant projection, replicated per clip
+  for (int g = 0; g < ncfg; ++g)
+    for (int b = 0; b < clips; ++b)
+      HIPTRY(hipMemcpyAsync(c->vcond + ((size_t)(g * clips + b) * Lv) * D, c->v_cond0 + (size_t)g * Lv * D,
+                            (size_t)Lv * D * 4, hipMemcpyDeviceToDevice, st));
+
+  for (int blk = 0; blk < f.depth_triple; ++blk) {
+    const std::string p = "t" + std::to_string(blk) + ".";
+    auto tb = [&](int s, int chunk) {
+      return rb_vec(c->modtab + ((size_t)(blk * 2 + s) * NI) * 9 * D + (size_t)chunk * D, 9L * D, sp);
+    };
+    struct Stream { const char* pre; float* x; void* xn; float* qkv; void* att; void* hid; int rows, L, tok_off; const int* pos; };
+    Stream ss[2] = {{"a_", c->audio, c->xn_a, c->qkv_a, c->att_a, c->hid_a, M, La, Lv, pl.pos_audio_self},
+                    {"v_", c->vcond, c->xn_v, c->qkv_v, c->att_v, c->hid_v, Mv, Lv, 0, pl.pos_visual_self}};
+    // 1. joint self attention (hifi_foley.py:215-269)
+    for (int s = 0; s < 2; ++s) {
+      Stream& z = ss[s];
+      Lin qkv;
+      const void *qn, *kn;
+      TRY(get_lin(c, p + z.pre + "qkv", T, 3 * D, D, true, &qkv));
+      TRY(get_tensor(c, p + z.pre + "qn", FOLEY_F32, {128}, &qn));
+      TRY(get_tensor(c, p + z.pre + "kn", FOLEY_F32, {128}, &kn));
+      TRY(launch_ln_mod(z.x, z.rows, D, 1e-6f, tb(s, 0), tb(s, 1), z.xn, T, st));
+      TRY(launch_gemm(gemm_plain(z.xn, z.rows, qkv, z.qkv, 3 * D), T, EPI_STORE_F32, 0, st));
+      QkvSplitArgs q{};
+      q.qkv = z.qkv; q.M = z.rows; q.L = z.L; q.H = H; q.nK = 3;
+      q.gain[0] = (const float*)qn; q.gain[1] = (const float*)kn;
+      q.pos[0] = z.pos; q.pos[1] = z.pos;
+      q.dst[0] = c->Q; q.dst[1] = c->K; q.dst[2] = c->V;
+      q.S_tot = S; q.tok_off = z.tok_off; q.eps = 1e-6f; q.cos_tab = pl.rope_cos; q.sin_tab = pl.rope_sin;
+      TRY(launch_qkv_split(q, st));
+    }
+    {
+      AttnArgs a{c->Q, c->K, c->V, Bc, H, S, S, 1, c->att_v, c->att_a, Lv};
+      TRY(launch_attention(a, T, st));
+    }
+    for (int s = 0; s < 2; ++s) {
+      Stream& z = ss[s];
+      Lin proj;
+      TRY(get_lin(c, p + z.pre + "proj", T, D, D, true, &proj));
+      GemmArgs g = gemm_plain(z.att, z.rows, proj, z.x, D);
+      g.rb = tb(s, 2);
+      TRY(launch_gemm(g, T, EPI_GATE_RES, 0, st));
+    }
+    // 2. cross attention to the (cached) text keys/values (hifi_foley.py:271-319)
+    for (int s = 0; s < 2; ++s) {
+      Stream& z = ss[s];
+      Lin cq;
+      const void* qn;
+      TRY(get_lin(c, p + z.pre + "cq", T, D, D, true, &cq));
+      TRY(get_tensor(c, p + z.pre + "cqn", FOLEY_F32, {128}, &qn));
+      TRY(launch_ln_mod(z.x, z.rows, D, 1e-6f, tb(s, 3), tb(s, 4), z.xn, T, st));
+      TRY(launch_gemm(gemm_plain(z.xn, z.rows, cq, z.qkv, D), T, EPI_STORE_F32, 0, st));
+      QkvSplitArgs q{};
+      q.qkv = z.qkv; q.M = z.rows; q.L = z.L; q.H = H; q.nK = 1;
+      q.gain[0] = (const float*)qn; q.pos[0] = pl.pos_linear; q.dst[0] = c->Q;
+      q.S_tot = S; q.tok_off = z.tok_off; q.eps = 1e-6f; q.cos_tab = pl.rope_cos; q.sin_tab = pl.rope_sin;
+      TRY(launch_qkv_split(q, st));
+    }
+    {
+      const size_t off = (size_t)blk * ncfg * H * Lt * 128;
+      AttnArgs a{c->Q, c->txt_k + off, c->txt_v + off, Bc, H, S, Lt, clips, c->att_v, c->att_a, Lv};
+      TRY(launch_attention(a, T, st));
+    }
+    for (int s = 0; s < 2; ++s) {
+      Stream& z = ss[s];
+      Lin proj;
+      TRY(get_lin(c, p + z.pre + "cproj", T, D, D, true, &proj));
+      GemmArgs g = gemm_plain(z.att, z.rows, proj, z.x, D);
+      g.rb = tb(s, 5);
+      TRY(launch_gemm(g, T, EPI_GATE_RES, 0, st));
+    }
+    // 3. GELU-tanh MLPs (hifi_foley.py:321-331)
+    for (int s = 0; s < 2; ++s) {
+      Stream& z = ss[s];
+      Lin fc1, fc2;
+      TRY(get_lin(c, p + z.pre + "fc1", T, f.mlp_hidden, D, true, &fc1));
+      TRY(get_lin(c, p + z.pre + "fc2", T, D, f.mlp_hidden, true, &fc2));
+      TRY(launch_ln_mod(z.x, z.rows, D, 1e-6f, tb(s, 6), tb(s, 7), z.xn, T, st));
+      TRY(launch_gemm(gemm_plain(z.xn, z.rows, fc1, z.hid, f.mlp_hidden), T, EPI_GELU_T, 0, st));
+      GemmArgs g = gemm_plain(z.hid, z.rows, fc2, z.x, D);
+      g.rb = tb(s, 8);
+      TRY(launch_gemm(g, T, EPI_GATE_RES, 0, st));
+    }
+  }
+
+  // per-token conditioning of the single-stream blocks: SiLU(add_sync + vec) (hifi_foley.py:866-867, modulate_layers.py:15-16)
+  TRY(launch_rows_add_act(c->add_sync, rb_vec(c->vec_table, D, sp), ncfg * La, D, 1, c->svec, T, st));
+  const int Hc = f.conv_hidden;
+  for (int blk = 0; blk < f.depth_single; ++blk) {
+    const std::string p = "s" + std::to_string(blk) + ".";
+    Lin mod, qkv, lin1, w13, w2;
+    const void *qn, *kn;
+    TRY(get_lin(c, p + "mod", T, 6 * D, D, true, &mod));
+    TRY(get_lin(c, p + "qkv", T, 3 * D, D, true, &qkv));
+    TRY(get_lin(c, p + "lin1", T, D, 3 * D, true, &lin1));
+    TRY(get_lin(c, p + "w13", T, 2 * Hc, 3 * D, false, &w13));
+    TRY(get_lin(c, p + "w2", T, D, 3 * Hc, false, &w2));
+    TRY(get_tensor(c, p + "qn", FOLEY_F32, {128}, &qn));
+    TRY(get_tensor(c, p + "kn", FOLEY_F32, {128}, &kn));
+    auto sm = [&](int chunk) { return rb_tok(c->smod + (size_t)chunk * D, 6L * D, clips * La, La); };
+    // modulation is identical for every clip of a CFG half => M = ncfg*La rows only
+    TRY(launch_gemm(gemm_plain(c->svec, ncfg * La, mod, c->smod, 6 * D), T, EPI_STORE_F32, 0, st));
+    TRY(launch_ln_mod(c->audio, M, D, 1e-5f, sm(0), sm(1), c->xn_a, T, st));
+    TRY(launch_gemm(gemm_plain(c->xn_a, M, qkv, c->qkv_a, 3 * D), T, EPI_STORE_F32, 0, st));
+    QkvSplitArgs q{};
+    q.qkv = c->qkv_a; q.M = M; q.L = La; q.H = H; q.nK = 3;
+    q.gain[0] = (const float*)qn; q.gain[1] = (const float*)kn;
+    q.pos[0] = pl.pos_linear; q.pos[1] = pl.pos_linear;
+    q.dst[0] = c->Q; q.dst[1] = c->K; q.dst[2] = c->V;
+    q.S_tot = La; q.tok_off = 0; q.eps = 1.1920928955078125e-07f;  // nn.RMSNorm(eps=None) -> finfo(fp32).eps
+    q.cos_tab = pl.rope_cos; q.sin_tab = pl.rope_sin;
+    TRY(launch_qkv_split(q, st));
+    {
+      AttnArgs a{c->Q, c->K, c->V, Bc, H, La, La, 1, c->att_a, c->att_a, 0};
+      TRY(launch_attention(a, T, st));
+    }
+    {
+      GemmArgs g = gemm_conv(c->att_a, M, La, D, 3, 1, lin1, c->audio, D);
+      g.rb = sm(2);
+      TRY(launch_gemm(g, T, EPI_GATE_RES, 0, st));
+    }
+    TRY(launch_ln_mod(c->audio, M, D, 1e-5f, sm(3), sm(4), c->xn_a, T, st));
+    TRY(launch_gemm(gemm_conv(c->xn_a, M, La, D, 3, 1, w13, c->hid_a, Hc), T, EPI_SILUGATE_T, 0, st));
+    {
+      GemmArgs g = gemm_conv(c->hid_a, M, La, Hc, 3, 1, w2, c->audio, D);
+      g.rb = sm(5);
+      TRY(launch_gemm(g, T, EPI_GATE_RES, 0, st));
+    }
+  }
+
+  // FinalLayer1D: adaLN is a no-op with 3-D conditioning => linear(LayerNorm(x))
+  {
+    Lin fin;
+    TRY(get_lin(c, "final", T, C, D, true, &fin));
+    TRY(launch_ln_mod(c->audio, M, D, 1e-6f, rb_none(), rb_none(), c->xn_a, T, st));
+    TRY(launch_gemm(gemm_plain(c->xn_a, M, fin, c->pred, C), T, EPI_STORE_F32, 0, st));
+  }
+  return 0;
+}
+
+extern "C" int foley_dit_forward(foley_ctx* c, const float* latents, int iter, float* out_rows, void* stream_v) {
+  if (!c || !latents || !out_rows) return FAIL(FOLEY_ERR_INVALID, "null argument");
+  if (!c->prepared) return FAIL(FOLEY_ERR_STATE, "foley_prepare has not been called");
+  if (iter < 0 || iter >= c->plan.n_iter) return FAIL(FOLEY_ERR_INVALID, "iteration out of range");
+  hipStream_t st = (hipStream_t)stream_v;
+  HIPTRY(hipSetDevice(c->device));
+  const foley_plan& pl = c->plan;
+  const int C = c->cfg.latent_dim;
+  HIPTRY(hipMemcpyAsync(c->step_ctr, &iter, sizeof(int), hipMemcpyHostToDevice, st));
+  HIPTRY(hipStreamSynchronize(st));  // `iter` lives on the caller's stack
+  TRY(launch_latent_rows(latents, pl.clips, C, pl.La, pl.ncfg, c->xin, c->cfg.compute_dtype, st));
+  TRY(run_forward(c, st));
+  HIPTRY(hipMemcpyAsync(out_rows, c->pred, (size_t)pl.ncfg * pl.clips * pl.La * C * 4, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+// --------------------------------------------------------------------------- sampler loop
+static int run_iteration(foley_ctx* c, float* latents, hipStream_t st) {
+  const foley_plan& pl = c->plan;
+  TRY(run_forward(c, st));
+  StepArgs s{};
+  s.pred = c->pred; s.x = latents; s.x_saved = c->x_saved; s.d_acc = c->d_acc;
+  s.clips = pl.clips; s.C = c->cfg.latent_dim; s.L = pl.La; s.ncfg = pl.ncfg;
+  s.guidance = pl.guidance; s.coef = pl.solver_coef; s.step_ptr = c->step_ctr;
+  s.rows_out = c->xin; s.rows_dtype = c->cfg.compute_dtype;
+  return launch_solver_step(s, st);
+}
+
+extern "C" int foley_sample(foley_ctx* c, float* latents, int use_graph, foley_progress_cb cb, void* user,
+                            void* stream_v) {
+  if (!c || !latents) return FAIL(FOLEY_ERR_INVALID, "null argument");
+  if (!c->prepared) return FAIL(FOLEY_ERR_STATE, "foley_prepare has not been called");
+  hipStream_t st = (hipStream_t)stream_v;
+  HIPTRY(hipSetDevice(c->device));
+  const foley_plan& pl = c->plan;
+  HIPTRY(hipEventRecord(c->ev0, st));
+  HIPTRY(hipMemsetAsync(c->step_ctr, 0, sizeof(int), st));
+  TRY(launch_latent_rows(latents, pl.clips, c->cfg.latent_dim, pl.La, pl.ncfg, c->xin, c->cfg.compute_dtype, st));
+  if (use_graph) {
+    if (c->graph_exec && c->graph_latents != latents) {
+      hipGraphExecDestroy(c->graph_exec);
+      c->graph_exec = nullptr;
+    }
+    if (!c->graph_exec) {
+      c->graph_latents = latents;
+      // every per-iteration value is read from device memory (step counter), so one captured
+      // iteration replays for the whole loop
+      hipStream_t cs;
+      HIPTRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+      hipGraph_t graph = nullptr;
+      HIPTRY(hipStreamSynchronize(st));
+      hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+      int rc = 0;
+      if (e == hipSuccess) {
+        rc = run_iteration(c, latents, cs);
+        e = hipStreamEndCapture(cs, &graph);
+      }
+      if (e == hipSuccess && rc == 0) e = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
+      if (graph) hipGraphDestroy(graph);
+      hipStreamDestroy(cs);
+      if (rc != 0) return rc;
+      if (e != hipSuccess) return FAIL(FOLEY_ERR_HIP, hipGetErrorString(e));
+    }
+    for (int it = 0; it < pl.n_iter; ++it) {
+      HIPTRY(hipGraphLaunch(c->graph_exec, st));
+      if (cb) {
+        HIPTRY(hipStreamSynchronize(st));
+        cb(it + 1, pl.n_iter, user);
+      }
+    }
+  } else {
+    for (int it = 0; it < pl.n_iter; ++it) {
+      TRY(run_iteration(c, latents, st));
+      if (cb) {
+        HIPTRY(hipStreamSynchronize(st));
+        cb(it + 1, pl.n_iter, user);
+      }
+    }
+  }
+  HIPTRY(hipEventRecord(c->ev1, st));
+  c->timed = true;
+  return 0;
+}
+
+// --------------------------------------------------------------------------- DAC decoder
+// Activations are kept time-major [clip, T, C] so that every conv is a GEMM over contiguous
+// channel vectors; weight-norm is folded at pack time; each snake is evaluated once, in the
+// epilogue of the op that produces its input.  (dac.py:28-44, 98-149, 280-303)
+extern "C" int foley_dac_decode(foley_ctx* c, const float* latents, int clips, int T, float* wave, void* stream_v) {
+  if (!c || !latents || !wave || clips < 1 || T < 1) return FAIL(FOLEY_ERR_INVALID, "bad argument");
+  hipStream_t st = (hipStream_t)stream_v;
+  HIPTRY(hipSetDevice(c->device));
+  const foley_config& f = c->cfg;
+  const int L = f.latent_dim, NR = f.dac_n_rates;
+  // largest activation
+  size_t maxel = (size_t)T * f.dac_dim;
+  {
+    long t = T;
+    int ch = f.dac_dim;
+    for (int i = 0; i < NR; ++i) {
+      t *= f.dac_rates[i];
+      ch /= 2;
+      maxel = std::max(maxel, (size_t)t * ch);
+    }
+  }
+  HIPTRY(hipStreamSynchronize(st));
+  TRY(grow(c->dacP, maxel * clips * 4));
+  TRY(grow(c->dacQ, maxel * clips * 4));
+  TRY(grow(c->dacR, maxel * clips * 4));
+  TRY(grow(c->dacZ, (size_t)clips * T * L * 4 * 2));
+  float *P = (float*)c->dacP.p, *Q = (float*)c->dacQ.p, *R = (float*)c->dacR.p;
+  float* Z0 = (float*)c->dacZ.p;
+  float* Z1 = Z0 + (size_t)clips * T * L;
+  HIPTRY(hipEventRecord(c->ev0, st));
+
+  TRY(launch_latent_rows(latents, clips, L, T, 1, Z0, FOLEY_F32, st));
+  Lin pq, cin;
+  TRY(get_lin(c, "dac.pq", FOLEY_F32, L, L, true, &pq));
+  TRY(get_lin(c, "dac.in", FOLEY_F32, f.dac_dim, 7 * L, true, &cin));
+  TRY(launch_gemm(gemm_plain(Z0, clips * T, pq, Z1, L), FOLEY_F32, EPI_STORE_F32, 0, st));
+  const void* al;
+  TRY(get_tensor(c, "dac.0.alpha0", FOLEY_F32, {f.dac_dim}, &al));
+  {
+    GemmArgs g = gemm_conv(Z1, clips * T, T, L, 7, 1, cin, nullptr, f.dac_dim);
+    g.out1 = P; g.alpha = (const float*)al; g.alphaC = f.dac_dim;
+    TRY(launch_gemm(g, FOLEY_F32, EPI_DAC, 0, st));
+  }
+  float* S_in = P;   // snake-activated input of the next op
+  float* X = Q;      // residual trunk
+  float* S_alt = R;  // the other snake buffer
+  int Tin = T, Cin = f.dac_dim;
+  for (int i = 0; i < NR; ++i) {
+    const int s = f.dac_rates[i], Cout = Cin / 2, Tout = Tin * s, pad = (s + 1) / 2;
+    const std::string p = "dac." + std::to_string(i) + ".";
+    Lin up;
+    TRY(get_lin(c, p + "up", FOLEY_F32, s * Cout, 2 * Cin, true, &up));
+    const void* a1;
+    TRY(get_tensor(c, p + "0.a1", FOLEY_F32, {Cout}, &a1));
+    {
+      // transposed conv: virtual row q of segment (Tin+1) = [x[q-1] ; x[q]], N axis = (phase, Cout),
+      // output sample t = q*s + phase - pad  (dac.py:102-109)
+      GemmArgs g = gemm_plain(S_in, clips * (Tin + 1), up, X, (long)s * Cout);
+      g.lda = Cin; g.segV = Tin + 1; g.segS = Tin; g.taps = 2; g.tapC = Cin; g.dil = 1; g.tap0 = -1;
+      g.osegV = Tin + 1; g.out_seg = (long)Tout * Cout; g.out_row = (long)s * Cout; g.out_shift = -(long)pad * Cout;
+      g.out_check = 1;
+      g.out1 = S_alt; g.alpha = (const float*)a1; g.alphaC = Cout;
+      TRY(launch_gemm(g, FOLEY_F32, EPI_DAC, 0, st));
+    }
+    std::swap(S_in, S_alt);  // S_in now holds snake(x) for unit 0
+    for (int j = 0; j < 3; ++j) {
+      const int d = f.dac_dilations[j];
+      const std::string u = p + std::to_string(j) + ".";
+      Lin c7, c1;
+      const void *a2, *an;
+      TRY(get_lin(c, u + "c7", FOLEY_F32, Cout, 7 * Cout, true, &c7));
+      TRY(get_lin(c, u + "c1", FOLEY_F32, Cout, Cout, true, &c1));
+      TRY(get_tensor(c, u + "a2", FOLEY_F32, {Cout}, &a2));
+      // alpha of whatever consumes this unit's output next
+      std::string nxt = (j < 2) ? p + std::to_string(j + 1) + ".a1"
+                                : (i + 1 < NR ? "dac." + std::to_string(i + 1) + ".alpha0" : std::string("dac.out.alpha"));
+      TRY(get_tensor(c, nxt, FOLEY_F32, {Cout}, &an));
+      {
+        GemmArgs g = gemm_conv(S_in, clips * Tout, Tout, Cout, 7, d, c7, nullptr, Cout);
+        g.out1 = S_alt; g.alpha = (const float*)a2; g.alphaC = Cout;
+        TRY(launch_gemm(g, FOLEY_F32, EPI_DAC, 0, st));
+      }
+      {
+        GemmArgs g = gemm_plain(S_alt, clips * Tout, c1, X, Cout);
+        g.res = X; g.out1 = S_in; g.alpha = (const float*)an; g.alphaC = Cout;
+        TRY(launch_gemm(g, FOLEY_F32, EPI_DAC, 0, st));
+      }
+    }
+    Tin = Tout;
+    Cin = Cout;
+  }
+  const void *ow, *ob;
+  TRY(get_tensor(c, "dac.out.w", FOLEY_F32, {7 * Cin}, &ow));
+  TRY(get_tensor(c, "dac.out.b", FOLEY_F32, {1}, &ob));
+  TRY(launch_dac_out(S_in, (const float*)ow, (const float*)ob, clips, Tin, Cin, wave, st));
+  HIPTRY(hipEventRecord(c->ev1, st));
+  c->timed = true;
+  return 0;
+}
+
+// --------------------------------------------------------------------------- op-level entry points
+static RowBcast to_rb(const foley_rowbcast* r) {
+  if (!r || !r->p) return rb_none();
+  return RowBcast{r->p, (long)r->ld, r->mode, r->rows_per_cfg > 0 ? r->rows_per_cfg : 1, r->L > 0 ? r->L : 1, nullptr, 0};
+}
+
+extern "C" int foley_op_gemm(const foley_gemm_desc* d, void* stream) {
+  if (!d) return FAIL(FOLEY_ERR_INVALID, "null descriptor");
+  GemmArgs g{};
+  g.A = d->A; g.W = d->W; g.bias = d->bias; g.M = d->M; g.N = d->N; g.K = d->K; g.lda = d->lda;
+  g.segV = d->segV; g.segS = d->segS; g.taps = d->taps; g.tapC = d->tapC; g.dil = d->dil; g.tap0 = d->tap0;
+  g.out0 = d->out0; g.out1 = d->out1; g.osegV = d->osegV; g.out_seg = d->out_seg; g.out_row = d->out_row;
+  g.out_shift = d->out_shift; g.out_check = d->out_check; g.rb = to_rb(&d->rb); g.res = d->res;
+  g.alpha = d->alpha; g.alphaC = d->alphaC > 0 ? d->alphaC : 1;
+  if (g.segV < 1 || g.segS < 1 || g.osegV < 1 || g.taps < 1) return FAIL(FOLEY_ERR_INVALID, "bad GEMM descriptor");
+  return launch_gemm(g, d->dtype, d->epilogue, d->tile, (hipStream_t)stream);
+}
+
+extern "C" int foley_op_attention(const float* q, const float* k, const float* v, int Bq, int H, int Sq, int Skv,
+                                  int kv_bdiv, void* outA, void* outB, int split, int out_dtype, void* stream) {
+  AttnArgs a{q, k, v, Bq, H, Sq, Skv, kv_bdiv > 0 ? kv_bdiv : 1, outA, outB, split};
+  return launch_attention(a, out_dtype, (hipStream_t)stream);
+}
+
+extern "C" int foley_op_ln_mod(const float* x, int M, int D, float eps, const foley_rowbcast* shift,
+                               const foley_rowbcast* scale, void* out, int out_dtype, void* stream) {
+  return launch_ln_mod(x, M, D, eps, to_rb(shift), to_rb(scale), out, out_dtype, (hipStream_t)stream);
+}
+
+extern "C" int foley_op_qkv_split(const float* qkv, int M, int L, int H, int nK, const float* const* gain,
+                                  const int32_t* const* pos, float* const* dst, int S_tot, int tok_off, float eps,
+                                  const float* cos_tab, const float* sin_tab, void* stream) {
+  if (nK < 1 || nK > 3) return FAIL(FOLEY_ERR_INVALID, "nK must be 1..3");
+  QkvSplitArgs a{};
+  a.qkv = qkv; a.M = M; a.L = L; a.H = H; a.nK = nK;
+  for (int i = 0; i < nK; ++i) {
+    a.gain[i] = gain ? gain[i] : nullptr;
+    a.pos[i] = pos ? pos[i] : nullptr;
+    a.dst[i] = dst[i];
+  }
+  a.S_tot = S_tot; a.tok_off = tok_off; a.eps = eps; a.cos_tab = cos_tab; a.sin_tab = sin_tab;
+  return launch_qkv_split(a, (hipStream_t)stream);
+}
+
+extern "C" int foley_op_solver_step(const float* pred, float* x, float* x_saved, float* d_acc, int clips, int C,
+                                    int L, int ncfg, float guidance, const float* coef, int32_t* step_ptr,
+                                    void* rows_out, int rows_dtype, void* stream) {
+  StepArgs s{pred, x, x_saved, d_acc, clips, C, L, ncfg, guidance, coef, step_ptr, rows_out, rows_dtype};
+  return launch_solver_step(s, (hipStream_t)stream);
+}
+
+extern "C" int foley_op_latent_rows(const float* x, int clips, int C, int L, int ncfg, void* out, int out_dtype,
+                                    void* stream) {
+  return launch_latent_rows(x, clips, C, L, ncfg, out, out_dtype, (hipStream_t)stream);
+}
+
+extern "C" int foley_op_dac_out(const float* s, const float* w, const float* bias, int B, int T, int C, float* out,
+                                void* stream) {
+  return launch_dac_out(s, w, bias, B, T, C, out, (hipStream_t)stream);
+}

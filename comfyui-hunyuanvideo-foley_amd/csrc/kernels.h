@@ -1,0 +1,120 @@
+// Internal launch interface between the kernel files and the runtime (not part of the C ABI).
+#pragma once
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// GEMM / conv-as-GEMM engine:  D[r, n] = sum_k A'[r, k] * W[n, k]  (+ fused epilogue)
+//
+// A' is a *virtual* row matrix over a channels-last activation [rows, C]: virtual row r belongs to
+// segment b = r / segV at position q = r % segV, and its K axis is `taps` blocks of `tapC`
+// channels, block j being source row (q + tap0 + j*dil) of segment b (zero when that row falls
+// outside [0, segS)).  taps=1 is a plain linear layer; taps=3,dil=1,tap0=-1 is the DiT's
+// channels-last conv k=3 pad=1; taps=7 is the DAC dilated conv; taps=2,tap0=-1 over segV=T+1
+// virtual rows is a stride-s transposed conv whose s output phases are the N axis.
+// ---------------------------------------------------------------------------------------------
+enum GemmEpi {
+  EPI_STORE_F32 = 0,  // out0(f32) = acc + bias (+ rb addend)
+  EPI_STORE_T = 1,    // out0(T)   = acc + bias
+  EPI_SILU_T = 2,     // out0(T)   = silu(acc + bias)
+  EPI_GELU_T = 3,     // out0(T)   = gelu_tanh(acc + bias)
+  EPI_SILUGATE_T = 4, // out0(T)[.., N/2] = silu(a) * b, (a, b) = alternating 32-column groups
+  EPI_GATE_RES = 5,   // out0(f32) += rb gate * (acc + bias)
+  EPI_DAC = 6,        // v = acc + bias (+ res); out0(f32) = v; out1(f32) = snake(v)
+  EPI_COUNT
+};
+
+struct GemmArgs {
+  const void* A;
+  const void* W;      // [N, K] row-major, K contiguous
+  const float* bias;  // [N] or null
+  int M, N, K;
+  long lda;           // elements between source rows of A
+  int segV, segS;     // virtual / source rows per segment
+  int taps, tapC, dil, tap0;
+  // output mapping: element (r, n) -> b*out_seg + q*out_row + n + out_shift with (b, q) taken
+  // over osegV rows; skipped when out_check and the in-segment offset leaves [0, out_seg)
+  void* out0;
+  void* out1;
+  int osegV;
+  long out_seg, out_row, out_shift;
+  int out_check;
+  RowBcast rb;        // gate (EPI_GATE_RES) or addend (EPI_STORE_F32)
+  const float* res;   // EPI_DAC residual (same mapping as out0) or null
+  const float* alpha; // EPI_DAC snake alpha, indexed n % alphaC
+  int alphaC;
+};
+
+// dtype: FOLEY_F32 or FOLEY_BF16 operands (accumulation is always fp32). tile: 0 = auto.
+int launch_gemm(const GemmArgs& g, int dtype, int epi, int tile, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// Attention: O = softmax(Q K^T / sqrt(128)) V, no mask.  Q [Bq, H, Sq, 128], K/V [Bkv, H, Skv, 128]
+// fp32.  Query batch b reads K/V batch b / kv_bdiv.  Output rows are token-major [.., H*128] in
+// dtype `out_dtype`; tokens [0, split) go to outA (clip-major rows of `split` tokens), the rest
+// to outB.
+// ---------------------------------------------------------------------------------------------
+struct AttnArgs {
+  const float* q;
+  const float* k;
+  const float* v;
+  int Bq, H, Sq, Skv, kv_bdiv;
+  void* outA;
+  void* outB;
+  int split;
+};
+int launch_attention(const AttnArgs& a, int out_dtype, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// Row kernels
+// ---------------------------------------------------------------------------------------------
+// out(T)[r, :] = LayerNorm(x[r, :]; eps) * (1 + scale) + shift   (scale/shift optional)
+int launch_ln_mod(const float* x, int M, int D, float eps, const RowBcast& shift, const RowBcast& scale,
+                  void* out, int out_dtype, hipStream_t st);
+
+struct QkvSplitArgs {
+  const float* qkv;  // [M, nK * H * 128]
+  int M, L, H, nK;   // rows ordered [clip][l], L tokens per clip
+  const float* gain[3];  // RMSNorm gain per operand, null => copy only
+  const int* pos[3];     // RoPE position per token l, null => no rotation
+  float* dst[3];         // [clips, H, S_tot, 128]
+  int S_tot, tok_off;
+  float eps;
+  const float* cos_tab;  // [P, 64]
+  const float* sin_tab;
+};
+int launch_qkv_split(const QkvSplitArgs& a, hipStream_t st);
+
+// out(T)[r, :] = act(a[r, :] + v[:]) ; a optional [R, D]; v optional broadcast row (step-indexed)
+int launch_rows_add_act(const float* a, const RowBcast& v, int R, int D, int act_silu, void* out,
+                        int out_dtype, hipStream_t st);
+// out(T)[r, :] = x[r, :] + pos[r % period, :]
+int launch_add_periodic(const float* x, const float* pos, int R, int D, int period, void* out,
+                        int out_dtype, hipStream_t st);
+// out[r, :] = src[idx[r % n_idx] + (r / n_idx) * src_rows, :]  (fp32 row gather)
+int launch_gather_rows(const float* src, const int* idx, int n_idx, int groups, int src_rows, int D,
+                       float* out, hipStream_t st);
+// generic dtype cast of a contiguous buffer
+int launch_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long n, hipStream_t st);
+
+// latents x [clips, C, L] fp32 -> rows(T) [(cfg*clips + b)*L + l, C] for cfg in [0, ncfg)
+int launch_latent_rows(const float* x, int clips, int C, int L, int ncfg, void* out, int out_dtype,
+                       hipStream_t st);
+
+// Solver update (CFG combine + flow-match step) and re-staging of the model input rows.
+struct StepArgs {
+  const float* pred;   // [ncfg*clips*L, C] model output rows
+  float* x;            // [clips, C, L] current sample (updated in place)
+  float* x_saved;      // stage-0 sample for multi-stage solvers (or null)
+  float* d_acc;        // running derivative combination (or null)
+  int clips, C, L, ncfg;
+  float guidance;
+  const float* coef;   // per-iteration [n_iter][4]: {w_new, w_acc, dt, flags}
+  int* step_ptr;       // device iteration counter (incremented by the kernel)
+  void* rows_out;      // next model input rows (T), cfg-duplicated
+  int rows_dtype;
+};
+int launch_solver_step(const StepArgs& a, hipStream_t st);
+
+// DAC tail: out[b, t] = tanh(bias + sum_{j<7, c<C} w[j*C + c] * s[b, t + j - 3, c])
+int launch_dac_out(const float* s, const float* w, const float* bias, int B, int T, int C, float* out,
+                   hipStream_t st);

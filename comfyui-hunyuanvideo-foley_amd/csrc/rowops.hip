@@ -1,0 +1,367 @@
+// HBM-bound row kernels of the Foley path: LayerNorm+modulate, RMSNorm+RoPE head split, small
+// elementwise helpers, the solver update and the DAC output convolution.  All arithmetic fp32;
+// one wavefront per row with 16-byte vector accesses and wave-level (DPP) reductions.
+#include "kernels.h"
+
+namespace {
+
+#define FOLEY_LAUNCH_CHECK()                                                             \
+  do {                                                                                   \
+    hipError_t _e = hipGetLastError();                                                   \
+    if (_e != hipSuccess) return foley_set_err(hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+// ------------------------------------------------------------------ LayerNorm (+ AdaLN modulate)
+// reference: nn.LayerNorm(elementwise_affine=False) + modulate() (modulate_layers.py:19-30) and
+// SingleStreamBlock's norm*(1+scale)+shift (hifi_foley.py:368,387)
+template <typename OutT, int MAXV>
+__global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x, int M, int D, float eps,
+                                                     RowBcast shift, RowBcast scale, OutT* __restrict__ out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const int nv = D >> 2;  // float4 per row
+  const f32x4* xr = (const f32x4*)(x + (long)row * D);
+  f32x4 v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      v[i] = xr[c];
+      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float d = v[i][u] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  const float* sh = shift.p ? rb_row(shift, row) : nullptr;
+  const float* sc = scale.p ? rb_row(scale, row) : nullptr;
+  OutT* orow = out + (long)row * D;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float y = (v[i][u] - mean) * rstd;
+        if (sc) y = y * (1.0f + sc[c * 4 + u]);
+        if (sh) y = y + sh[c * 4 + u];
+        orow[c * 4 + u] = Cvt<OutT>::to(y);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ q/k RMSNorm + RoPE + head split
+// reference: rearrange "(K H D)", RMSNorm (norm_layers.py:36-52 / nn.RMSNorm), apply_rotary_emb
+// (attn_layers.py:112-146).  One wave per (row, head, operand); lane owns the rotation pair
+// (2*lane, 2*lane+1).
+__global__ __launch_bounds__(256) void qkv_split_kernel(const QkvSplitArgs a) {
+  const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const long total = (long)a.M * a.H * a.nK;
+  if (wid >= total) return;
+  const int w = (int)(wid % a.nK);
+  const int h = (int)((wid / a.nK) % a.H);
+  const int r = (int)(wid / ((long)a.nK * a.H));
+  const int b = r / a.L, l = r - b * a.L;
+  const float* src = a.qkv + (long)r * (a.nK * a.H * 128) + (long)w * a.H * 128 + h * 128 + 2 * lane;
+  float x0 = src[0], x1 = src[1];
+  if (a.gain[w]) {
+    const float ss = wave_sum(x0 * x0 + x1 * x1);
+    const float rinv = rsqrtf(ss * (1.0f / 128.0f) + a.eps);
+    x0 = x0 * rinv * a.gain[w][2 * lane];
+    x1 = x1 * rinv * a.gain[w][2 * lane + 1];
+  }
+  if (a.pos[w]) {
+    const int p = a.pos[w][l];
+    const float c = a.cos_tab[(long)p * 64 + lane], s = a.sin_tab[(long)p * 64 + lane];
+    const float y0 = x0 * c - x1 * s;
+    const float y1 = x1 * c + x0 * s;
+    x0 = y0;
+    x1 = y1;
+  }
+  float* dst = a.dst[w] + (((long)b * a.H + h) * a.S_tot + a.tok_off + l) * 128 + 2 * lane;
+  dst[0] = x0;
+  dst[1] = x1;
+}
+
+// ------------------------------------------------------------------ small elementwise helpers
+template <typename OutT>
+__global__ void rows_add_act_kernel(const float* __restrict__ a, RowBcast v, int R, int D, int act_silu,
+                                    OutT* __restrict__ out) {
+  const long n = (long)R * D;
+  const float* vr = v.p ? rb_row(v, 0) : nullptr;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float y = a ? a[i] : 0.f;
+    if (vr) y += vr[i % D];
+    if (act_silu) y = silu_f(y);
+    out[i] = Cvt<OutT>::to(y);
+  }
+}
+
+template <typename OutT>
+__global__ void add_periodic_kernel(const float* __restrict__ x, const float* __restrict__ pos, int R, int D,
+                                    int period, OutT* __restrict__ out) {
+  const long n = (long)R * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / D), c = (int)(i - (long)r * D);
+    out[i] = Cvt<OutT>::to(x[i] + pos[(long)(r % period) * D + c]);
+  }
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, int n_idx,
+                                   int groups, int src_rows, int D, float* __restrict__ out) {
+  const long n = (long)groups * n_idx * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / D;
+    const int c = (int)(i - r * D);
+    const int g = (int)(r / n_idx), l = (int)(r - (long)g * n_idx);
+    out[i] = src[((long)g * src_rows + idx[l]) * D + c];
+  }
+}
+
+template <typename S, typename Dst>
+__global__ void cast_kernel(const S* __restrict__ s, Dst* __restrict__ d, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    d[i] = Cvt<Dst>::to(Cvt<S>::from(s[i]));
+}
+
+// latents [clips, C, L] -> token rows [(cfg*clips + b)*L + l, C]  (PatchEmbed1D's transpose,
+// embed_layers.py:43-52, and the CFG duplication of utils.py:205)
+template <typename OutT>
+__global__ __launch_bounds__(256) void latent_rows_kernel(const float* __restrict__ x, int clips, int C, int L,
+                                                          int ncfg, OutT* __restrict__ out) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int l0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, l = l0 + tx;
+    tile[i][tx] = (c < C && l < L) ? x[((long)b * C + c) * L + l] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int l = l0 + i, c = c0 + tx;
+    if (l < L && c < C) {
+      const OutT v = Cvt<OutT>::to(tile[tx][i]);
+      for (int g = 0; g < ncfg; ++g) out[(((long)g * clips + b) * L + l) * C + c] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ solver update
+// CFG combine (utils.py:241-243) + FlowMatchDiscreteScheduler.step (scheduling_flow_match_
+// discrete.py:262-297 and the multi-stage bookkeeping :299-373) driven by a per-iteration
+// coefficient row {w_new, w_acc, dt, w_store, flags}; then re-stages the next model input rows.
+constexpr int STEP_SAVE_X = 1, STEP_USE_SAVED = 2, STEP_ACC_RESET = 4;
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void solver_step_kernel(const StepArgs a) {
+  __shared__ float tile[32][33];
+  const int it = *a.step_ptr;
+  const float* cf = a.coef + (long)it * 8;
+  const float w_new = cf[0], w_acc = cf[1], dt = cf[2], w_store = cf[3];
+  const int flags = (int)cf[4];
+  const int b = blockIdx.z;
+  const int l0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const long rows = (long)a.clips * a.L;
+  // phase 1: read pred rows [l][c] (coalesced over c) and transpose through LDS
+  for (int i = ty; i < 32; i += 8) {
+    const int l = l0 + i, c = c0 + tx;
+    float v = 0.f;
+    if (l < a.L && c < a.C) {
+      const long r = (long)b * a.L + l;
+      if (a.ncfg == 2) {
+        const float u = a.pred[r * a.C + c], cnd = a.pred[(rows + r) * a.C + c];
+        v = u + a.guidance * (cnd - u);
+      } else {
+        v = a.pred[r * a.C + c];
+      }
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  // phase 2: update x [b][c][l] (coalesced over l)
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, l = l0 + tx;
+    float xn = 0.f;
+    if (c < a.C && l < a.L) {
+      const long xi = ((long)b * a.C + c) * a.L + l;
+      const float v = tile[tx][i];
+      const float xc = a.x[xi];
+      float acc = 0.f;
+      if (a.d_acc) acc = (flags & STEP_ACC_RESET) ? 0.f : a.d_acc[xi];
+      const float deriv = (w_acc != 0.f) ? (w_new * v + w_acc * acc) : (w_new * v);
+      const float base = (flags & STEP_USE_SAVED) ? a.x_saved[xi] : xc;
+      if (flags & STEP_SAVE_X) a.x_saved[xi] = xc;
+      xn = base + deriv * dt;
+      a.x[xi] = xn;
+      if (a.d_acc) a.d_acc[xi] = acc + w_store * v;
+    }
+    tile[tx][i] = xn;
+  }
+  __syncthreads();
+  // phase 3: next model input rows (cfg-duplicated), coalesced over c
+  if (a.rows_out) {
+    for (int i = ty; i < 32; i += 8) {
+      const int l = l0 + i, c = c0 + tx;
+      if (l < a.L && c < a.C) {
+        const OutT v = Cvt<OutT>::to(tile[i][tx]);
+        for (int g = 0; g < a.ncfg; ++g)
+          ((OutT*)a.rows_out)[(((long)g * a.clips + b) * a.L + l) * a.C + c] = v;
+      }
+    }
+  }
+}
+
+__global__ void step_increment_kernel(int* p) { *p = *p + 1; }
+
+// ------------------------------------------------------------------ DAC output conv (64 -> 1, k=7) + tanh
+// reference: decoder.model[-2:] = WNConv1d(C, 1, 7, padding=3), nn.Tanh() (dac.py:141-146).
+// A block handles 64 consecutive samples; the (64+6) x C snake-activated rows are staged in LDS.
+__global__ __launch_bounds__(256) void dac_out_kernel(const float* __restrict__ s, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, int T, int C,
+                                                      float* __restrict__ out) {
+  extern __shared__ float sm[];  // (70 rows) * (C + 1) + 7 * C weights
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * 64;
+  const int pitch = C + 1;
+  float* rows = sm;
+  float* wl = sm + 70 * pitch;
+  for (int i = threadIdx.x; i < 7 * C; i += 256) wl[i] = w[i];
+  for (int i = threadIdx.x; i < 70 * C; i += 256) {
+    const int rr = i / C, c = i - rr * C;
+    const int t = t0 + rr - 3;
+    rows[rr * pitch + c] = (t >= 0 && t < T) ? s[((long)b * T + t) * C + c] : 0.f;
+  }
+  __syncthreads();
+  // 4 lanes per output sample, each covering a quarter of the channels
+  const int ti = threadIdx.x >> 2, part = threadIdx.x & 3;
+  const int cq = C >> 2;
+  float acc = 0.f;
+  for (int j = 0; j < 7; ++j) {
+    const float* rp = rows + (ti + j) * pitch + part * cq;
+    const float* wp = wl + j * C + part * cq;
+    for (int c = 0; c < cq; ++c) acc += rp[c] * wp[c];
+  }
+  acc += __shfl_xor(acc, 1, 64);
+  acc += __shfl_xor(acc, 2, 64);
+  const int t = t0 + ti;
+  if (part == 0 && t < T) out[(long)b * T + t] = tanhf(acc + bias[0]);
+}
+
+inline int grid1d(long n, int block) {
+  long g = (n + block - 1) / block;
+  return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+int launch_ln_mod(const float* x, int M, int D, float eps, const RowBcast& shift, const RowBcast& scale,
+                  void* out, int out_dtype, hipStream_t st) {
+  if (D % 4 || D > 8 * 256) return foley_set_err("ln_mod: D must be a multiple of 4 and <= 2048", __FILE__, __LINE__);
+  dim3 grid((M + 3) / 4), block(256);
+  if (out_dtype == FOLEY_F32)
+    hipLaunchKernelGGL((ln_mod_kernel<float, 8>), grid, block, 0, st, x, M, D, eps, shift, scale, (float*)out);
+  else if (out_dtype == FOLEY_BF16)
+    hipLaunchKernelGGL((ln_mod_kernel<bf16_t, 8>), grid, block, 0, st, x, M, D, eps, shift, scale, (bf16_t*)out);
+  else return foley_set_err("ln_mod: bad dtype", __FILE__, __LINE__);
+  FOLEY_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_qkv_split(const QkvSplitArgs& a, hipStream_t st) {
+  const long waves = (long)a.M * a.H * a.nK;
+  hipLaunchKernelGGL(qkv_split_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
+  FOLEY_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_rows_add_act(const float* a, const RowBcast& v, int R, int D, int act_silu, void* out, int out_dtype,
+                        hipStream_t st) {
+  const long n = (long)R * D;
+  if (out_dtype == FOLEY_F32)
+    hipLaunchKernelGGL(rows_add_act_kernel<float>, dim3(grid1d(n, 256)), dim3(256), 0, st, a, v, R, D, act_silu, (float*)out);
+  else if (out_dtype == FOLEY_BF16)
+    hipLaunchKernelGGL(rows_add_act_kernel<bf16_t>, dim3(grid1d(n, 256)), dim3(256), 0, st, a, v, R, D, act_silu, (bf16_t*)out);
+  else return foley_set_err("rows_add_act: bad dtype", __FILE__, __LINE__);
+  FOLEY_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_add_periodic(const float* x, const float* pos, int R, int D, int period, void* out, int out_dtype,
+                        hipStream_t st) {
+  const long n = (long)R * D;
+  if (out_dtype == FOLEY_F32)
+    hipLaunchKernelGGL(add_periodic_kernel<float>, dim3(grid1d(n, 256)), dim3(256), 0, st, x, pos, R, D, period, (float*)out);
+  else if (out_dtype == FOLEY_BF16)
+    hipLaunchKernelGGL(add_periodic_kernel<bf16_t>, dim3(grid1d(n, 256)), dim3(256), 0, st, x, pos, R, D, period, (bf16_t*)out);
+  else return foley_set_err("add_periodic: bad dtype", __FILE__, __LINE__);
+  FOLEY_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_gather_rows(const float* src, const int* idx, int n_idx, int groups, int src_rows, int D, float* out,
+                       hipStream_t st) {
+  const long n = (long)groups * n_idx * D;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid1d(n, 256)), dim3(256), 0, st, src, idx, n_idx, groups, src_rows, D, out);
+  FOLEY_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_cast(const void* src, int sd, void* dst, int dd, long n, hipStream_t st) {
+  dim3 g(grid1d(n, 256)), b(256);
+  if (sd == FOLEY_F32 && dd == FOLEY_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, bf16_t>), g, b, 0, st, (const float*)src, (bf16_t*)dst, n);
+  else if (sd == FOLEY_BF16 && dd == FOLEY_F32)
+    hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g, b, 0, st, (const bf16_t*)src, (float*)dst, n);
+  else if (sd == FOLEY_F32 && dd == FOLEY_F32)
+    hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, st, (const float*)src, (float*)dst, n);
+  else return foley_set_err("cast: unsupported dtype pair", __FILE__, __LINE__);
+  FOLEY_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_latent_rows(const float* x, int clips, int C, int L, int ncfg, void* out, int out_dtype, hipStream_t st) {
+  dim3 grid((L + 31) / 32, (C + 31) / 32, clips), block(256);
+  if (out_dtype == FOLEY_F32)
+    hipLaunchKernelGGL(latent_rows_kernel<float>, grid, block, 0, st, x, clips, C, L, ncfg, (float*)out);
+  else if (out_dtype == FOLEY_BF16)
+    hipLaunchKernelGGL(latent_rows_kernel<bf16_t>, grid, block, 0, st, x, clips, C, L, ncfg, (bf16_t*)out);
+  else return foley_set_err("latent_rows: bad dtype", __FILE__, __LINE__);
+  FOLEY_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_solver_step(const StepArgs& a, hipStream_t st) {
+  dim3 grid((a.L + 31) / 32, (a.C + 31) / 32, a.clips), block(256);
+  if (a.rows_dtype == FOLEY_BF16) hipLaunchKernelGGL(solver_step_kernel<bf16_t>, grid, block, 0, st, a);
+  else hipLaunchKernelGGL(solver_step_kernel<float>, grid, block, 0, st, a);
+  FOLEY_LAUNCH_CHECK();
+  hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, st, a.step_ptr);
+  FOLEY_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_dac_out(const float* s, const float* w, const float* bias, int B, int T, int C, float* out,
+                   hipStream_t st) {
+  if (C % 4 || C > 256) return foley_set_err("dac_out: unsupported channel count", __FILE__, __LINE__);
+  const size_t sh = (70 * (C + 1) + 7 * C) * sizeof(float);
+  hipLaunchKernelGGL(dac_out_kernel, dim3((T + 63) / 64, B), dim3(256), sh, st, s, w, bias, T, C, out);
+  FOLEY_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,220 @@
+"""Weight packers: reference-keyed state dicts -> the packed arena libfoley_hip.so consumes.
+
+The reference loads checkpoints into nn.Modules (nodes.py:72-133, utils.py:61-87) and re-derives
+layouts on every forward (einops rearranges, conv permutes, weight-norm parametrisation).  Here
+every layout decision is taken ONCE at load time:
+
+  * Linear weights stay [N, K] (K contiguous = the MFMA-friendly "NT" GEMM operand).
+  * Single-block `linear_qkv` rows are permuted from the reference's "(H D K)" packing
+    (hifi_foley.py:362) to "(K H D)", so one head-split kernel serves both block types.
+  * Channels-last conv k=3 weights [out, in, 3] become [out, 3*in] with the tap outermost
+    (K index = tap*in + c): the conv is then a GEMM over overlapping activation rows.
+  * SwiGLU pairs (w1, w3) are fused into one [2*hidden, K] matrix whose rows alternate in
+    groups of 32 (w1 rows g*32.., then w3 rows g*32..): both halves of a gate land in the same
+    lane of adjacent 32x32 MFMA fragments and the gate is applied in registers.
+  * DAC: weight-norm folded (w = g*v/||v||, nn/layers.py:9-14; dim 0 = *input* channel for the
+    transposed convs), convs packed tap-major like above, each stride-s transposed conv packed as
+    s output phases x 2 taps: Wt[p*Cout + co, (x[q-1] | x[q])] = (w[:, co, p+s] | w[:, co, p]).
+
+All matrices are cast to the compute dtype (fp32 parity mode / bf16 throughput mode); biases,
+norm gains and snake alphas stay fp32.  Everything is laid out in ONE flat device buffer (the
+"arena") so multi-GPU runs can ship the model with a single broadcast.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, Iterable, Tuple
+
+import torch
+
+from .config import DACConfig, DiTConfig
+
+Tensor = torch.Tensor
+
+_TRIPLE_LINEARS = (  # packed name, reference module, has bias
+    ("a_mod", "audio_mod.linear"), ("v_mod", "v_cond_mod.linear"),
+    ("a_qkv", "audio_self_attn_qkv"), ("v_qkv", "v_cond_attn_qkv"),
+    ("a_proj", "audio_self_proj"), ("v_proj", "v_cond_self_proj"),
+    ("a_cq", "audio_cross_q"), ("v_cq", "v_cond_cross_q"),
+    ("t_kv", "text_cross_kv"),
+    ("a_cproj", "audio_cross_proj"), ("v_cproj", "v_cond_cross_proj"),
+    ("a_fc1", "audio_mlp.fc1"), ("a_fc2", "audio_mlp.fc2"),
+    ("v_fc1", "v_cond_mlp.fc1"), ("v_fc2", "v_cond_mlp.fc2"),
+)
+_TRIPLE_GAINS = (
+    ("a_qn", "audio_self_q_norm"), ("a_kn", "audio_self_k_norm"),
+    ("v_qn", "v_cond_attn_q_norm"), ("v_kn", "v_cond_attn_k_norm"),
+    ("a_cqn", "audio_cross_q_norm"), ("v_cqn", "v_cond_cross_q_norm"),
+    ("t_kn", "text_cross_k_norm"),
+)
+
+
+def conv_to_gemm(w: Tensor) -> Tensor:
+    """[out, in, k] -> [out, k*in], K index = tap*in + c."""
+    return w.permute(0, 2, 1).reshape(w.shape[0], -1).contiguous()
+
+
+def interleave_gate(w1: Tensor, w3: Tensor) -> Tensor:
+    """Fuse a SwiGLU pair into [2*hidden, K] with alternating 32-row groups (w1 first)."""
+    h, k = w1.shape
+    assert h % 32 == 0 and w3.shape == w1.shape
+    return torch.cat((w1.view(h // 32, 32, k), w3.view(h // 32, 32, k)), dim=1).reshape(2 * h, k).contiguous()
+
+
+def qkv_hdk_to_khd(w: Tensor, heads: int) -> Tensor:
+    """rows packed '(H D K)' (q/k/v innermost) -> '(K H D)'; works for weight [3D, K] and bias [3D]."""
+    d3 = w.shape[0]
+    hd = d3 // (3 * heads)
+    rest = w.shape[1:]
+    return w.reshape(heads, hd, 3, *rest).permute(2, 0, 1, *range(3, 3 + len(rest))).reshape(d3, *rest).contiguous()
+
+
+def _f32(t: Tensor) -> Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+def pack_dit(sd: Dict[str, Tensor], cfg: DiTConfig, dtype: torch.dtype) -> "OrderedDict[str, Tensor]":
+    """Reference DiT state dict -> packed tensors (CPU or wherever `sd` lives)."""
+    out: "OrderedDict[str, Tensor]" = OrderedDict()
+    H = cfg.heads
+
+    def mat(name: str, w: Tensor):
+        out[name + ".w"] = w.detach().to(torch.float32).to(dtype).contiguous()
+
+    def lin(name: str, ref: str, bias: bool = True):
+        mat(name, sd[ref + ".weight"])
+        if bias:
+            out[name + ".b"] = _f32(sd[ref + ".bias"])
+
+    for b in range(cfg.depth_triple):
+        p, r = f"t{b}.", f"triple_blocks.{b}."
+        for n, m in _TRIPLE_LINEARS:
+            lin(p + n, r + m)
+        for n, m in _TRIPLE_GAINS:
+            out[p + n] = _f32(sd[r + m + ".weight"])
+    for b in range(cfg.depth_single):
+        p, r = f"s{b}.", f"single_blocks.{b}."
+        lin(p + "mod", r + "modulation.linear")
+        mat(p + "qkv", qkv_hdk_to_khd(sd[r + "linear_qkv.weight"].float(), H))
+        out[p + "qkv.b"] = _f32(qkv_hdk_to_khd(sd[r + "linear_qkv.bias"].float(), H))
+        out[p + "qn"] = _f32(sd[r + "q_norm.weight"])
+        out[p + "kn"] = _f32(sd[r + "k_norm.weight"])
+        mat(p + "lin1", conv_to_gemm(sd[r + "linear1.weight"].float()))
+        out[p + "lin1.b"] = _f32(sd[r + "linear1.bias"])
+        mat(p + "w13", interleave_gate(conv_to_gemm(sd[r + "linear2.w1.weight"].float()),
+                                       conv_to_gemm(sd[r + "linear2.w3.weight"].float())))
+        mat(p + "w2", conv_to_gemm(sd[r + "linear2.w2.weight"].float()))
+    mat("audio_in", sd["audio_embedder.proj.weight"].float().squeeze(-1))
+    out["audio_in.b"] = _f32(sd["audio_embedder.proj.bias"])
+    mat("vis.w13", interleave_gate(sd["visual_proj.w1.weight"].float(), sd["visual_proj.w3.weight"].float()))
+    mat("vis.w2", sd["visual_proj.w2.weight"])
+    lin("cond1", "cond_in.linear_1")
+    lin("cond2", "cond_in.linear_2")
+    lin("time0", "time_in.mlp.0")
+    lin("time2", "time_in.mlp.2")
+    lin("sync0", "sync_in.0")
+    mat("sync.w13", interleave_gate(sd["sync_in.2.w1.weight"].float().squeeze(-1),
+                                    sd["sync_in.2.w3.weight"].float().squeeze(-1)))
+    mat("sync.w2", sd["sync_in.2.w2.weight"].float().squeeze(-1))
+    out["sync_pos"] = _f32(sd["sync_pos_emb"]).reshape(8, -1)
+    lin("final", "final_layer.linear")   # final_layer.adaLN_modulation is dead code
+    out["empty_clip"] = _f32(sd["empty_clip_feat"]).reshape(-1)
+    out["empty_sync"] = _f32(sd["empty_sync_feat"]).reshape(-1)
+    return out
+
+
+def fold_weight_norm(sd: Dict[str, Tensor], key: str) -> Tensor:
+    """Accepts parametrized (`original0/1`), legacy (`weight_g/v`) and already-folded checkpoints."""
+    if key + ".parametrizations.weight.original0" in sd:
+        g, v = sd[key + ".parametrizations.weight.original0"], sd[key + ".parametrizations.weight.original1"]
+    elif key + ".weight_g" in sd:
+        g, v = sd[key + ".weight_g"], sd[key + ".weight_v"]
+    else:
+        return sd[key + ".weight"].float()
+    g, v = g.float(), v.float()
+    n = v.flatten(1).norm(dim=1).view(-1, *([1] * (v.dim() - 1)))
+    return v * (g / n)
+
+
+def convT_to_gemm(w: Tensor, stride: int) -> Tensor:
+    """ConvTranspose1d weight [Cin, Cout, 2s] -> [s*Cout, 2*Cin]: row (phase p, co),
+    K = [x[q-1] channels | x[q] channels] <-> taps (p+s | p)."""
+    cin, cout, k = w.shape
+    assert k == 2 * stride
+    wp = w.permute(2, 1, 0)                       # [2s, Cout, Cin]
+    return torch.cat((wp[stride:], wp[:stride]), dim=-1).reshape(stride * cout, 2 * cin).contiguous()
+
+
+def pack_dac(sd: Dict[str, Tensor], cfg: DACConfig) -> "OrderedDict[str, Tensor]":
+    """Decoder half of the DAC-VAE state dict -> packed fp32 tensors (dac.py:120-149, 197)."""
+    out: "OrderedDict[str, Tensor]" = OrderedDict()
+    out["dac.pq.w"] = _f32(sd["post_quant_conv.weight"]).squeeze(-1).contiguous()
+    out["dac.pq.b"] = _f32(sd["post_quant_conv.bias"])
+    out["dac.in.w"] = conv_to_gemm(fold_weight_norm(sd, "decoder.model.0"))
+    out["dac.in.b"] = _f32(sd["decoder.model.0.bias"])
+    n = len(cfg.rates)
+    for i, s in enumerate(cfg.rates):
+        r, p = f"decoder.model.{i + 1}.block.", f"dac.{i}."
+        out[p + "alpha0"] = _f32(sd[r + "0.alpha"]).reshape(-1)
+        out[p + "up.w"] = convT_to_gemm(fold_weight_norm(sd, r + "1"), s)
+        out[p + "up.b"] = _f32(sd[r + "1.bias"]).repeat(s)
+        for j in range(3):
+            q, u = r + f"{j + 2}.block.", p + f"{j}."
+            out[u + "a1"] = _f32(sd[q + "0.alpha"]).reshape(-1)
+            out[u + "c7.w"] = conv_to_gemm(fold_weight_norm(sd, q + "1"))
+            out[u + "c7.b"] = _f32(sd[q + "1.bias"])
+            out[u + "a2"] = _f32(sd[q + "2.alpha"]).reshape(-1)
+            out[u + "c1.w"] = fold_weight_norm(sd, q + "3").squeeze(-1).contiguous()
+            out[u + "c1.b"] = _f32(sd[q + "3.bias"])
+    out["dac.out.alpha"] = _f32(sd[f"decoder.model.{n + 1}.alpha"]).reshape(-1)
+    wo = fold_weight_norm(sd, f"decoder.model.{n + 2}")     # [1, C, 7]
+    out["dac.out.w"] = wo[0].permute(1, 0).reshape(-1).contiguous()
+    out["dac.out.b"] = _f32(sd[f"decoder.model.{n + 2}.bias"]).reshape(1)
+    return out
+
+
+# ----------------------------------------------------------------------------- arena
+_ALIGN = 256
+
+
+def arena_layout(packed: Dict[str, Tensor]) -> Tuple[int, "OrderedDict[str, Tuple[int, torch.dtype, Tuple[int, ...]]]"]:
+    """name -> (byte offset, dtype, shape); returns (total bytes, table)."""
+    table: "OrderedDict[str, Tuple[int, torch.dtype, Tuple[int, ...]]]" = OrderedDict()
+    off = 0
+    for k, t in packed.items():
+        table[k] = (off, t.dtype, tuple(t.shape))
+        off += (t.numel() * t.element_size() + _ALIGN - 1) // _ALIGN * _ALIGN
+    return off, table
+
+
+class Arena:
+    """One flat device buffer holding every packed tensor (single-broadcast friendly)."""
+
+    def __init__(self, total_bytes: int, table, device):
+        self.table = table
+        self.buffer = torch.empty(max(total_bytes, _ALIGN), dtype=torch.uint8, device=device)
+
+    @classmethod
+    def from_packed(cls, packed: Dict[str, Tensor], device) -> "Arena":
+        total, table = arena_layout(packed)
+        a = cls(total, table, device)
+        for k, t in packed.items():
+            a.view(k).copy_(t, non_blocking=False)
+        return a
+
+    def view(self, name: str) -> Tensor:
+        off, dt, shape = self.table[name]
+        n = 1
+        for s in shape:
+            n *= s
+        nbytes = n * torch.empty((), dtype=dt).element_size()
+        return self.buffer[off:off + nbytes].view(dt).view(shape)
+
+    def items(self) -> Iterable[Tuple[str, Tensor]]:
+        for k in self.table:
+            yield k, self.view(k)
+
+
+def torch_dtype(name: str) -> torch.dtype:
+    return {"fp32": torch.float32, "bf16": torch.bfloat16, "f32": torch.float32}[name]

@@ -1,0 +1,339 @@
+"""ctypes binding of libfoley_hip.so (include/foley_hip.h).  PyTorch is only the allocator /
+stream provider here: every call passes raw device pointers + the current HIP stream.
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, a
+`FoleyRuntimeError` is raised - the HIP path is the only implementation of the hot path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libfoley_hip.so")
+
+DT_F32, DT_BF16, DT_I32 = 0, 1, 2
+_TORCH2DT = {torch.float32: DT_F32, torch.bfloat16: DT_BF16, torch.int32: DT_I32}
+
+EPI_STORE_F32, EPI_STORE_T, EPI_SILU_T, EPI_GELU_T, EPI_SILUGATE_T, EPI_GATE_RES, EPI_DAC = range(7)
+
+
+class FoleyRuntimeError(RuntimeError):
+    pass
+
+
+class FoleyConfigC(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "depth_triple", "depth_single", "hidden", "heads", "mlp_hidden", "conv_hidden", "sync_hidden",
+        "cond_dim", "clip_dim", "sync_dim", "latent_dim", "time_freq_dim", "compute_dtype", "dac_dim",
+        "dac_n_rates")] + [("dac_rates", C.c_int32 * 8), ("dac_dilations", C.c_int32 * 3)]
+
+
+class FoleyPlanC(C.Structure):
+    _fields_ = [
+        ("ncfg", C.c_int32), ("clips", C.c_int32), ("La", C.c_int32), ("Lv", C.c_int32), ("Ls", C.c_int32),
+        ("Lt", C.c_int32), ("n_iter", C.c_int32), ("guidance", C.c_float),
+        ("text", C.c_void_p), ("clip", C.c_void_p), ("sync", C.c_void_p), ("t_feat", C.c_void_p),
+        ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("rope_len", C.c_int32),
+        ("pos_audio_self", C.c_void_p), ("pos_visual_self", C.c_void_p), ("pos_linear", C.c_void_p),
+        ("sync_gather", C.c_void_p), ("solver_coef", C.c_void_p),
+    ]
+
+
+class RowBcastC(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("ld", C.c_int64), ("mode", C.c_int32), ("rows_per_cfg", C.c_int32),
+                ("L", C.c_int32)]
+
+
+class GemmDescC(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int64),
+        ("segV", C.c_int32), ("segS", C.c_int32), ("taps", C.c_int32), ("tapC", C.c_int32),
+        ("dil", C.c_int32), ("tap0", C.c_int32),
+        ("out0", C.c_void_p), ("out1", C.c_void_p),
+        ("osegV", C.c_int32), ("out_seg", C.c_int64), ("out_row", C.c_int64), ("out_shift", C.c_int64),
+        ("out_check", C.c_int32),
+        ("rb", RowBcastC), ("res", C.c_void_p), ("alpha", C.c_void_p), ("alphaC", C.c_int32),
+        ("dtype", C.c_int32), ("epilogue", C.c_int32), ("tile", C.c_int32),
+    ]
+
+
+PROGRESS_CB = C.CFUNCTYPE(None, C.c_int32, C.c_int32, C.c_void_p)
+
+_SIGNATURES = {
+    "foley_abi_version": (C.c_uint32, []),
+    "foley_last_error": (C.c_char_p, []),
+    "foley_ctx_create": (C.c_int, [C.c_int, C.POINTER(FoleyConfigC), C.POINTER(C.c_void_p)]),
+    "foley_ctx_destroy": (None, [C.c_void_p]),
+    "foley_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "foley_prepare": (C.c_int, [C.c_void_p, C.POINTER(FoleyPlanC), C.c_void_p]),
+    "foley_dit_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "foley_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, PROGRESS_CB, C.c_void_p, C.c_void_p]),
+    "foley_dac_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "foley_last_elapsed_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "foley_op_gemm": (C.c_int, [C.POINTER(GemmDescC), C.c_void_p]),
+    "foley_op_attention": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                                                        C.c_void_p]),
+    "foley_op_ln_mod": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.POINTER(RowBcastC),
+                                  C.POINTER(RowBcastC), C.c_void_p, C.c_int, C.c_void_p]),
+    "foley_op_qkv_split": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                     C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_float,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    "foley_op_solver_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_void_p, C.c_void_p,
+                                                                          C.c_void_p, C.c_int, C.c_void_p]),
+    "foley_op_latent_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                       C.c_void_p]),
+    "foley_op_dac_out": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_void_p]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_LIB: Optional[C.CDLL] = None
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """dlopen libfoley_hip.so and type its entry points; raises if it is not built."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    p = path or os.environ.get("FOLEY_HIP_LIB", LIB_PATH)
+    if not os.path.exists(p):
+        raise FoleyRuntimeError(
+            f"{p} not found - build it with `python __graft_entry__.py build` (hipcc, gfx950). "
+            "There is no CPU / PyTorch fallback for the Foley sampling path.")
+    lib = C.CDLL(p)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError if the .so does not export the ABI
+        fn.restype = res
+        fn.argtypes = args
+    if lib.foley_abi_version() != 1:
+        raise FoleyRuntimeError("libfoley_hip.so ABI version mismatch")
+    if path is None:
+        _LIB = lib
+    return lib
+
+
+def _check(lib, rc: int, what: str):
+    if rc != 0:
+        msg = lib.foley_last_error()
+        raise FoleyRuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise FoleyRuntimeError("libfoley_hip.so needs device tensors (got a CPU tensor)")
+    if not t.is_contiguous():
+        raise FoleyRuntimeError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dt_of(t: torch.Tensor) -> int:
+    return _TORCH2DT[t.dtype]
+
+
+def make_config(dit, dac, compute_dtype: torch.dtype) -> FoleyConfigC:
+    c = FoleyConfigC()
+    c.depth_triple, c.depth_single, c.hidden, c.heads = dit.depth_triple, dit.depth_single, dit.hidden, dit.heads
+    c.mlp_hidden, c.conv_hidden, c.sync_hidden = dit.mlp_hidden, dit.conv_hidden, dit.sync_hidden
+    c.cond_dim, c.clip_dim, c.sync_dim = dit.cond_dim, dit.clip_dim, dit.sync_dim
+    c.latent_dim, c.time_freq_dim = dit.latent_dim, dit.time_freq_dim
+    c.compute_dtype = _TORCH2DT[compute_dtype]
+    c.dac_dim, c.dac_n_rates = dac.decoder_dim, len(dac.rates)
+    for i, r in enumerate(dac.rates):
+        c.dac_rates[i] = r
+    for i, d in enumerate(dac.dilations):
+        c.dac_dilations[i] = d
+    return c
+
+
+class FoleyContext:
+    """Owns one `foley_ctx` on one GPU plus references to every tensor registered with it."""
+
+    def __init__(self, dit_cfg, dac_cfg, compute_dtype: torch.dtype, device: torch.device):
+        self.lib = load_library()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise FoleyRuntimeError("FoleyContext needs a HIP device (torch device type 'cuda')")
+        self.dit_cfg, self.dac_cfg, self.compute_dtype = dit_cfg, dac_cfg, compute_dtype
+        self._cfg = make_config(dit_cfg, dac_cfg, compute_dtype)
+        h = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _check(self.lib, self.lib.foley_ctx_create(idx, C.byref(self._cfg), C.byref(h)), "foley_ctx_create")
+        self._h = h
+        self._keep: Dict[str, torch.Tensor] = {}
+        self._plan_keep = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.foley_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights
+    def set_tensor(self, name: str, t: torch.Tensor):
+        shape = (C.c_int64 * t.dim())(*t.shape)
+        _check(self.lib, self.lib.foley_set_tensor(self._h, name.encode(), _ptr(t), dt_of(t), t.dim(), shape),
+               f"foley_set_tensor({name})")
+        self._keep[name] = t
+
+    def set_tensors(self, items):
+        for k, t in items:
+            self.set_tensor(k, t)
+
+    # ---- run
+    def prepare(self, plan: dict):
+        """plan: ncfg, clips, La, Lv, Ls, Lt, n_iter, guidance + device tensors (see foley_plan)."""
+        p = FoleyPlanC()
+        for k in ("ncfg", "clips", "La", "Lv", "Ls", "Lt", "n_iter", "rope_len"):
+            setattr(p, k, int(plan[k]))
+        p.guidance = float(plan["guidance"])
+        for k in ("text", "clip", "sync", "t_feat", "rope_cos", "rope_sin", "pos_audio_self", "pos_visual_self",
+                  "pos_linear", "sync_gather", "solver_coef"):
+            setattr(p, k, _ptr(plan[k]))
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.foley_prepare(self._h, C.byref(p), _stream()), "foley_prepare")
+        self._plan_keep = plan    # the ctx borrows the plan's tables until the next prepare
+        self.plan = plan
+
+    def dit_forward(self, latents: torch.Tensor, it: int) -> torch.Tensor:
+        pl = self.plan
+        out = torch.empty(pl["ncfg"] * pl["clips"] * pl["La"], self.dit_cfg.latent_dim, dtype=torch.float32,
+                          device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.foley_dit_forward(self._h, _ptr(latents), int(it), _ptr(out), _stream()),
+                   "foley_dit_forward")
+        return out
+
+    def sample(self, latents: torch.Tensor, use_graph: bool = False, progress=None) -> torch.Tensor:
+        """In-place denoising of `latents` [clips, C, La] fp32."""
+        cb = PROGRESS_CB(lambda i, n, _u: progress(i, n)) if progress else PROGRESS_CB()
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.foley_sample(self._h, _ptr(latents), int(use_graph), cb, None, _stream()),
+                   "foley_sample")
+        return latents
+
+    def dac_decode(self, latents: torch.Tensor) -> torch.Tensor:
+        clips, _c, T = latents.shape
+        hop = self.dac_cfg.hop
+        wave = torch.empty(clips, 1, T * hop, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.foley_dac_decode(self._h, _ptr(latents), clips, T, _ptr(wave), _stream()),
+                   "foley_dac_decode")
+        return wave
+
+    def last_elapsed_ms(self) -> float:
+        ms = C.c_float()
+        _check(self.lib, self.lib.foley_last_elapsed_ms(self._h, C.byref(ms)), "foley_last_elapsed_ms")
+        return float(ms.value)
+
+
+# ----------------------------------------------------------------------------- op-level wrappers (tests, microbench)
+def rowbcast(t: Optional[torch.Tensor], mode: int = 0, rows_per_cfg: int = 1, L: int = 1,
+             ld: Optional[int] = None) -> RowBcastC:
+    r = RowBcastC()
+    if t is not None and not t.is_cuda:
+        raise FoleyRuntimeError("row-broadcast operand must live on the GPU")
+    r.p = t.data_ptr() if t is not None else None     # views allowed: rows are addressed through `ld`
+    r.ld = int(ld if ld is not None else (t.shape[-1] if t is not None else 0))
+    r.mode, r.rows_per_cfg, r.L = mode, rows_per_cfg, L
+    return r
+
+
+def op_gemm(A, W, bias=None, *, M=None, epilogue=EPI_STORE_F32, out0=None, out1=None, ldc=None, conv=None,
+            convT=None, rb: Optional[RowBcastC] = None, res=None, alpha=None, alphaC=1, tile=0):
+    """Thin wrapper over foley_op_gemm.  conv=(seg, C, taps, dil) ; convT=(Tin, Cin, stride, Cout)."""
+    lib = load_library()
+    d = GemmDescC()
+    N, K = W.shape
+    d.A, d.W, d.bias = _ptr(A), _ptr(W), _ptr(bias) if bias is not None else None
+    d.N, d.K = N, K
+    d.dtype, d.epilogue, d.tile = dt_of(W), epilogue, tile
+    if convT is not None:
+        Tin, Cin, s, Cout = convT
+        clips = A.numel() // (Tin * Cin)
+        d.M, d.lda = clips * (Tin + 1), Cin
+        d.segV, d.segS, d.taps, d.tapC, d.dil, d.tap0 = Tin + 1, Tin, 2, Cin, 1, -1
+        d.osegV, d.out_seg, d.out_row = Tin + 1, Tin * s * Cout, s * Cout
+        d.out_shift, d.out_check = -((s + 1) // 2) * Cout, 1
+    elif conv is not None:
+        seg, Cc, taps, dil = conv
+        d.M = A.numel() // Cc if M is None else M
+        d.lda = Cc
+        d.segV, d.segS, d.taps, d.tapC, d.dil, d.tap0 = seg, seg, taps, Cc, dil, -((taps - 1) // 2) * dil
+        d.osegV, d.out_seg, d.out_row, d.out_shift, d.out_check = d.M, 0, (ldc or N), 0, 0
+    else:
+        d.M = A.shape[0] if M is None else M
+        d.lda = K
+        d.segV, d.segS, d.taps, d.tapC, d.dil, d.tap0 = d.M, d.M, 1, K, 1, 0
+        d.osegV, d.out_seg, d.out_row, d.out_shift, d.out_check = d.M, 0, (ldc or N), 0, 0
+    if epilogue == EPI_SILUGATE_T and ldc is None and convT is None:
+        d.out_row = N // 2
+    d.out0, d.out1 = _ptr(out0) if out0 is not None else None, _ptr(out1) if out1 is not None else None
+    if rb is not None:
+        d.rb = rb
+    d.res = _ptr(res) if res is not None else None
+    d.alpha = _ptr(alpha) if alpha is not None else None
+    d.alphaC = alphaC
+    _check(lib, lib.foley_op_gemm(C.byref(d), _stream()), "foley_op_gemm")
+
+
+def op_attention(q, k, v, outA, outB, split: int, kv_bdiv: int = 1):
+    lib = load_library()
+    Bq, H, Sq, _ = q.shape
+    Skv = k.shape[2]
+    _check(lib, lib.foley_op_attention(_ptr(q), _ptr(k), _ptr(v), Bq, H, Sq, Skv, kv_bdiv, _ptr(outA), _ptr(outB),
+                                       split, dt_of(outB), _stream()), "foley_op_attention")
+
+
+def op_ln_mod(x, eps, shift: Optional[RowBcastC], scale: Optional[RowBcastC], out):
+    lib = load_library()
+    M, D = x.shape
+    _check(lib, lib.foley_op_ln_mod(_ptr(x), M, D, eps, C.byref(shift) if shift else None,
+                                    C.byref(scale) if scale else None, _ptr(out), dt_of(out), _stream()),
+           "foley_op_ln_mod")
+
+
+def op_qkv_split(qkv, L, H, gains: Sequence, poss: Sequence, dsts: Sequence, S_tot, tok_off, eps, cos, sin):
+    lib = load_library()
+    nK = len(dsts)
+    M = qkv.shape[0]
+    arr = lambda xs: (C.c_void_p * nK)(*[(_ptr(x) if x is not None else None) for x in xs])
+    _check(lib, lib.foley_op_qkv_split(_ptr(qkv), M, L, H, nK, arr(gains), arr(poss), arr(dsts), S_tot, tok_off,
+                                       eps, _ptr(cos), _ptr(sin), _stream()), "foley_op_qkv_split")
+
+
+def op_solver_step(pred, x, x_saved, d_acc, ncfg, guidance, coef, step_ptr, rows_out):
+    lib = load_library()
+    clips, Cc, L = x.shape
+    _check(lib, lib.foley_op_solver_step(_ptr(pred), _ptr(x), _ptr(x_saved), _ptr(d_acc), clips, Cc, L, ncfg,
+                                         float(guidance), _ptr(coef), _ptr(step_ptr), _ptr(rows_out),
+                                         dt_of(rows_out), _stream()), "foley_op_solver_step")
+
+
+def op_latent_rows(x, ncfg, out):
+    lib = load_library()
+    clips, Cc, L = x.shape
+    _check(lib, lib.foley_op_latent_rows(_ptr(x), clips, Cc, L, ncfg, _ptr(out), dt_of(out), _stream()),
+           "foley_op_latent_rows")
+
+
+def op_dac_out(s, w, bias, out):
+    lib = load_library()
+    B, T, Cc = s.shape
+    _check(lib, lib.foley_op_dac_out(_ptr(s), _ptr(w), _ptr(bias), B, T, Cc, _ptr(out), _stream()),
+           "foley_op_dac_out")

@@ -1,0 +1,158 @@
+"""Host orchestration of one sampling run - the MI355X counterpart of
+`denoise_process_with_generator` (/utils.py:125-258): draw the noise like the reference does,
+replicate / pad the conditioning, hand everything to libfoley_hip.so, decode with the DAC.
+
+PyTorch here only allocates device memory, draws the CPU-generator noise and builds tiny index
+tables; every FLOP of the hot path runs in the HIP library.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import packers, tables
+from .config import DAC48K, DACConfig, DiTConfig
+from .runtime import FoleyContext, FoleyRuntimeError
+
+
+class FoleyModel:
+    """The HUNYUAN_MODEL socket payload: packed DiT weights resident on one GPU + its context.
+
+    Mirrors what the reference sampler touches on its nn.Module: `.dtype`,
+    `get_empty_clip_sequence`, `get_empty_sync_sequence` (hifi_foley.py:620-632).
+    """
+
+    def __init__(self, cfg: DiTConfig, dit_state: Dict[str, torch.Tensor], compute_dtype: torch.dtype,
+                 device, dac_cfg: DACConfig = DAC48K, quantization: str = "none"):
+        self.cfg, self.dac_cfg = cfg, dac_cfg
+        self.dtype = compute_dtype
+        self.device = torch.device(device)
+        self.quantization = quantization
+        packed = packers.pack_dit(dit_state, cfg, compute_dtype)
+        self.arena = packers.Arena.from_packed(packed, self.device)
+        self._finish_init()
+
+    @classmethod
+    def from_arena(cls, cfg: DiTConfig, arena: "packers.Arena", compute_dtype: torch.dtype, device,
+                   dac_cfg: DACConfig = DAC48K) -> "FoleyModel":
+        """Adopt an already packed arena (e.g. one received by broadcast on a non-root rank)."""
+        self = cls.__new__(cls)
+        self.cfg, self.dac_cfg, self.dtype, self.device = cfg, dac_cfg, compute_dtype, torch.device(device)
+        self.quantization = "none"
+        self.arena = arena
+        self._finish_init()
+        return self
+
+    def _finish_init(self):
+        self.ctx = FoleyContext(self.cfg, self.dac_cfg, self.dtype, self.device)
+        self.ctx.set_tensors((k, v) for k, v in self.arena.items() if not k.startswith("empty_"))
+        self.empty_clip_feat = self.arena.view("empty_clip").view(1, -1)
+        self.empty_sync_feat = self.arena.view("empty_sync").view(1, -1)
+        self._dac_arena = None
+        self._text_len_fixed = None
+
+    def get_empty_clip_sequence(self, bs=None, len=None):
+        e = self.empty_clip_feat
+        return e.expand(len, -1) if bs is None else e.unsqueeze(0).expand(bs, len, -1)
+
+    def get_empty_sync_sequence(self, bs=None, len=None):
+        e = self.empty_sync_feat
+        return e.expand(len, -1) if bs is None else e.unsqueeze(0).expand(bs, len, -1)
+
+    def attach_dac(self, dac: "FoleyDAC"):
+        if self._dac_arena is not dac.arena:
+            self.ctx.set_tensors(dac.arena.items())
+            self._dac_arena = dac.arena
+
+    def to(self, *a, **k):   # placement is fixed at load time; kept for reference-API compatibility
+        return self
+
+
+class FoleyDAC:
+    """Packed DAC-VAE decoder (the `dac_model` entry of HUNYUAN_DEPS)."""
+
+    sample_rate = 48000
+
+    def __init__(self, dac_state: Dict[str, torch.Tensor], device, cfg: DACConfig = DAC48K):
+        self.cfg = cfg
+        self.sample_rate = cfg.sample_rate
+        self.device = torch.device(device)
+        self.arena = packers.Arena.from_packed(packers.pack_dac(dac_state, cfg), self.device)
+
+    @classmethod
+    def from_arena(cls, arena, device, cfg: DACConfig = DAC48K):
+        self = cls.__new__(cls)
+        self.cfg, self.sample_rate, self.device, self.arena = cfg, cfg.sample_rate, torch.device(device), arena
+        return self
+
+
+def pad_or_trim_text(x: torch.Tensor, t_fixed: int) -> torch.Tensor:
+    T = x.shape[1]
+    if T == t_fixed:
+        return x
+    if T > t_fixed:
+        return x[:, :t_fixed]
+    return F.pad(x, (0, 0, 0, t_fixed - T))
+
+
+def draw_noise(batch_size: int, channels: int, length: int, dtype: torch.dtype,
+               generator: Optional[torch.Generator]) -> torch.Tensor:
+    """prepare_latents_with_generator (utils.py:114-121): CPU generator, *model* dtype."""
+    return torch.randn((batch_size, channels, int(length)), generator=generator, device="cpu", dtype=dtype)
+
+
+def build_plan(model: FoleyModel, visual_feats: Dict[str, torch.Tensor], text_feats: Dict[str, torch.Tensor],
+               La: int, guidance_scale: float, steps: int, batch_size: int, sampler: str) -> dict:
+    """Conditioning replication / padding / CFG stacking of utils.py:159-199 + the run's tables."""
+    cfg, dev = model.cfg, model.device
+    f32 = lambda t: t.to(device=dev, dtype=torch.float32)
+    clip, sync = f32(visual_feats["siglip2_feat"]), f32(visual_feats["syncformer_feat"])
+    text, unc = f32(text_feats["text_feat"]), f32(text_feats["uncond_text_feat"])
+    if clip.shape[0] != 1 or sync.shape[0] != 1 or text.shape[0] != 1 or unc.shape[0] != 1:
+        raise FoleyRuntimeError("conditioning tensors must have batch 1 (they are shared by all clips)")
+    Lv, Ls = clip.shape[1], sync.shape[1]
+    # two-bucket text length policy, sticky per model (utils.py:166-188)
+    t_fixed = min(77 if text.shape[1] <= 77 else 128, cfg.text_len)
+    model._text_len_fixed = max(model._text_len_fixed or 0, t_fixed)
+    Lt = model._text_len_fixed
+    text, unc = pad_or_trim_text(text, Lt), pad_or_trim_text(unc, Lt)
+    if guidance_scale > 1.0:                      # [uncond ; cond]  (utils.py:193-195)
+        ncfg = 2
+        text_in = torch.cat([unc, text])
+        clip_in = torch.cat([model.get_empty_clip_sequence(bs=1, len=Lv).float(), clip])
+        sync_in = torch.cat([model.get_empty_sync_sequence(bs=1, len=Ls).float(), sync])
+    else:
+        ncfg, text_in, clip_in, sync_in = 1, text, clip, sync
+    tb = tables.build_tables(La, Lv, Ls, Lt, steps, sampler, cfg.flow_shift, cfg.time_freq_dim)
+    plan = {"ncfg": ncfg, "clips": batch_size, "La": La, "Lv": Lv, "Ls": Ls, "Lt": Lt, "n_iter": steps,
+            "guidance": float(guidance_scale), "rope_len": tb["rope_cos"].shape[0],
+            "text": text_in.contiguous(), "clip": clip_in.contiguous(), "sync": sync_in.contiguous()}
+    for k in ("t_feat", "rope_cos", "rope_sin", "pos_audio_self", "pos_visual_self", "pos_linear", "sync_gather",
+              "solver_coef"):
+        plan[k] = tb[k].to(dev).contiguous()
+    return plan
+
+
+def denoise_process_with_generator(visual_feats, text_feats, audio_len_in_s, model: FoleyModel, dac: FoleyDAC,
+                                   guidance_scale: float, num_inference_steps: int, batch_size: int, sampler: str,
+                                   generator: Optional[torch.Generator] = None, use_graph: bool = True,
+                                   progress: Optional[Callable[[int, int], None]] = None,
+                                   return_latents: bool = False, noise: Optional[torch.Tensor] = None):
+    """Same contract as the reference function of this name (utils.py:125-258):
+    returns (audio [bs, 1, T] fp32 on the model's device, sample_rate)."""
+    cfg = model.cfg
+    La = int(audio_len_in_s * cfg.frame_rate)
+    if noise is None:
+        noise = draw_noise(batch_size, cfg.latent_dim, La, model.dtype, generator)
+    latents = noise.to(device=model.device, dtype=torch.float32).contiguous()
+    plan = build_plan(model, visual_feats, text_feats, La, guidance_scale, num_inference_steps, batch_size, sampler)
+    model.attach_dac(dac)
+    model.ctx.prepare(plan)
+    model.ctx.sample(latents, use_graph=use_graph, progress=progress)
+    audio = model.ctx.dac_decode(latents)
+    # (the reference's "trim to exact length" slices the size-1 channel axis: a no-op)
+    if return_latents:
+        return audio, dac.sample_rate, latents
+    return audio, dac.sample_rate

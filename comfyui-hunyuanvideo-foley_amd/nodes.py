@@ -1,0 +1,389 @@
+"""ComfyUI node layer of the MI355X-native Foley path.
+
+Drop-in boundary: the six node keys, display names, socket type strings, widget
+names / order / defaults / ranges and return tuples below are those of the reference's
+`nodes.py` (node classes at :57-70, :156-168, :211-242, :433-457, :609-631, :636-663; mappings
+:668-683), so `example_workflows/HunyuanVideoFoleyExample.json` loads unchanged.  What sits
+behind them is new: the loaders pack checkpoints into a device arena for libfoley_hip.so, the
+sampler enqueues the whole denoising loop + DAC decode on the GPU.  The `TORCH_COMPILE_CFG` and
+`BLOCKSWAPARGS` sockets are accepted and ignored: there is no tracing compiler on this path and
+the 288 GB of HBM make block swapping pointless.
+
+ComfyUI modules (`folder_paths`, `comfy.*`) are imported lazily so the package also imports in
+test environments without ComfyUI.
+"""
+from __future__ import annotations
+
+import logging
+import os
+
+import torch
+
+from .host import config as _cfg
+from .host import sampler as _sampler
+
+log = logging.getLogger("HunyuanVideo-Foley[MI355X]")
+
+_SOLVERS = ["euler", "heun-2", "midpoint-2", "kutta-4"]
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+
+
+# ----------------------------------------------------------------------------- ComfyUI glue
+def _folder_paths():
+    try:
+        import folder_paths  # type: ignore
+    except Exception:
+        return None
+    foley_dir = os.path.join(folder_paths.models_dir, "foley")
+    if "foley" not in folder_paths.folder_names_and_paths:      # models/foley/ like the reference
+        folder_paths.folder_names_and_paths["foley"] = ([foley_dir], folder_paths.supported_pt_extensions)
+    return folder_paths
+
+
+def _foley_files(substr=None):
+    fp = _folder_paths()
+    names = fp.get_filename_list("foley") if fp is not None else []
+    return [f for f in names if substr is None or substr in f]
+
+
+def _torch_device():
+    try:
+        import comfy.model_management as mm  # type: ignore
+        return mm.get_torch_device()
+    except Exception:
+        return torch.device("cuda:0")
+
+
+def _load_state_dict(path):
+    try:
+        from comfy.utils import load_torch_file  # type: ignore
+        obj = load_torch_file(path, device=torch.device("cpu"))
+    except ImportError:
+        if str(path).endswith(".safetensors"):
+            from safetensors.torch import load_file
+            obj = load_file(path)
+        else:
+            obj = torch.load(path, map_location="cpu")
+    if isinstance(obj, dict) and isinstance(obj.get("state_dict"), dict):   # utils.py:49-59
+        obj = obj["state_dict"]
+    return {k: v for k, v in obj.items() if isinstance(v, torch.Tensor)}
+
+
+def detect_ckpt_fp8(state_dict):
+    """'fp8_e5m2' / 'fp8_e4m3fn' if the checkpoint stores such tensors, else None (utils.py:492-504)."""
+    for v in state_dict.values():
+        if v.dtype == torch.float8_e5m2:
+            return "fp8_e5m2"
+        if v.dtype == torch.float8_e4m3fn:
+            return "fp8_e4m3fn"
+    return None
+
+
+def detect_ckpt_major_precision(state_dict):
+    """Dominant dtype among bf16 / fp16 / fp32 by element count (utils.py:507-515)."""
+    counts = {torch.bfloat16: 0, torch.float16: 0, torch.float32: 0}
+    for v in state_dict.values():
+        if v.dtype in counts:
+            counts[v.dtype] += v.numel()
+    if not any(counts.values()):
+        return torch.bfloat16
+    return max(counts, key=counts.get)
+
+
+class AttributeDict(dict):
+    """dict with attribute access - the HUNYUAN_DEPS payload type."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+# ----------------------------------------------------------------------------- NODE 1: model loader
+class HunyuanModelLoader:
+    @classmethod
+    def INPUT_TYPES(cls):
+        return {
+            "required": {
+                "model_name": (_foley_files(),),
+                "precision": (["auto", "bf16", "fp16", "fp32"], {"default": "bf16", "tooltip": "Compute dtype of the GEMM operands (fp32 = parity mode on fp32 MFMA; auto = detect from checkpoint)"}),
+                "quantization": (["none", "fp8_e4m3fn", "fp8_e5m2", "auto"], {"default": "auto", "tooltip": "FP8 weight-only storage of the checkpoint (values are rounded through fp8 like the reference, compute stays bf16)"}),
+            },
+        }
+
+    RETURN_TYPES = ("HUNYUAN_MODEL",)
+    FUNCTION = "build_model"
+    CATEGORY = "audio/HunyuanFoley"
+
+    @staticmethod
+    def pack_state_dict(state_dict, precision="bf16", quantization="auto", device=None, cfg=None):
+        """state dict -> FoleyModel.  fp16 is served by the bf16 kernels (same MFMA rate, fp32 accumulate)."""
+        cfg = cfg or _cfg.load_yaml_config(os.path.join(_PKG_DIR, "configs", "hunyuanvideo-foley-xxl.yaml"))
+        dtype = {"bf16": torch.bfloat16, "fp16": torch.bfloat16, "fp32": torch.float32}.get(precision)
+        detected = detect_ckpt_fp8(state_dict)
+        if precision == "auto" or dtype is None:
+            major = detect_ckpt_major_precision(state_dict)
+            dtype = torch.float32 if major == torch.float32 else torch.bfloat16
+        qmode = "none"
+        if quantization != "none":
+            # gfx950 implements OCP e4m3fn/e5m2 natively => 'auto' honours the checkpoint, else e4m3fn
+            qmode = (detected or "fp8_e4m3fn") if quantization == "auto" else quantization
+            if detected is None and quantization == "auto":
+                qmode = "none"          # nothing to honour: keep full-precision weights
+        sd = {}
+        for k, v in state_dict.items():
+            if v.dtype in (torch.float8_e4m3fn, torch.float8_e5m2):
+                v = v.to(torch.float32)
+            elif qmode != "none" and v.dim() >= 2 and v.is_floating_point():
+                # weight-only fp8: plain cast, no scales (reference utils.py:408-485)
+                qd = torch.float8_e4m3fn if qmode == "fp8_e4m3fn" else torch.float8_e5m2
+                v = v.to(torch.float32).to(qd).to(torch.float32)
+            sd[k] = v
+        return _sampler.FoleyModel(cfg, sd, dtype, device or _torch_device(), quantization=qmode)
+
+    def build_model(self, model_name, precision, quantization):
+        fp = _folder_paths()
+        if fp is None:
+            raise RuntimeError("ComfyUI's folder_paths module is required to resolve model files")
+        sd = _load_state_dict(fp.get_full_path("foley", model_name))
+        model = self.pack_state_dict(sd, precision, quantization)
+        log.info("Loaded HunyuanVideoFoley main model: %s", model_name)
+        return (model,)
+
+
+# ----------------------------------------------------------------------------- NODE 2: dependencies loader
+class HunyuanDependenciesLoader:
+    @classmethod
+    def INPUT_TYPES(cls):
+        return {
+            "required": {
+                "vae_name": (_foley_files("vae"),),
+                "synchformer_name": (_foley_files("synch"),),
+            }
+        }
+
+    RETURN_TYPES = ("HUNYUAN_DEPS",)
+    FUNCTION = "load_dependencies"
+    CATEGORY = "audio/HunyuanFoley"
+
+    def load_dependencies(self, vae_name, synchformer_name):
+        fp = _folder_paths()
+        if fp is None:
+            raise RuntimeError("ComfyUI's folder_paths module is required to resolve model files")
+        device = _torch_device()
+        deps = AttributeDict()
+        deps["dac_model"] = _sampler.FoleyDAC(_load_state_dict(fp.get_full_path("foley", vae_name)), device)
+        deps["synchformer_path"] = fp.get_full_path("foley", synchformer_name)
+        # Conditioning encoders (CLAP text, SigLIP2, Synchformer) are outside the HIP hot path
+        # (SURVEY §8f N2); they stay on PyTorch-ROCm and are created on first use.
+        deps["syncformer_model"] = None
+        deps["siglip2_model"] = None
+        deps["clap_tokenizer"] = None
+        deps["clap_model"] = None
+        deps["device"] = device
+        return (deps,)
+
+
+def _ensure_text_encoder(deps):
+    if deps.get("clap_model") is None:
+        from transformers import AutoTokenizer, ClapTextModelWithProjection
+        deps["clap_tokenizer"] = AutoTokenizer.from_pretrained("laion/larger_clap_general")
+        deps["clap_model"] = ClapTextModelWithProjection.from_pretrained("laion/larger_clap_general").eval()
+    return deps
+
+
+@torch.inference_mode()
+def encode_text_feat(prompts, deps, device):
+    """CLAP last_hidden_state for [negative, positive] (feature_utils.py:133-138)."""
+    _ensure_text_encoder(deps)
+    deps["clap_model"].to(device)
+    inputs = deps["clap_tokenizer"](prompts, padding=True, return_tensors="pt").to(device)
+    out = deps["clap_model"](**inputs, output_hidden_states=True, return_dict=True)
+    return out.last_hidden_state
+
+
+def select_frames(image, duration, frame_rate):
+    """IMAGE [N,H,W,C] float 0-1 -> uint8 [T,C,H,W] frames at 8 fps and 25 fps (nodes.py:293-317)."""
+    total = image.shape[0]
+    n = int(duration * frame_rate)
+    if n > total:
+        image = torch.cat((image, image[-1:].repeat(n - total, 1, 1, 1)), dim=0)
+    else:
+        image = image[:n]
+    frames = (image * 255.0).byte().permute(0, 3, 1, 2)
+    i8 = torch.linspace(0, n - 1, int(duration * 8)).long()
+    i25 = torch.linspace(0, n - 1, int(duration * 25)).long()
+    return frames.index_select(0, i8), frames.index_select(0, i25)
+
+
+# ----------------------------------------------------------------------------- NODE 3: sampler
+class HunyuanFoleySampler:
+    SAMPLER_NAMES = _SOLVERS
+
+    @classmethod
+    def INPUT_TYPES(cls):
+        return {
+            "required": {
+                "hunyuan_model": ("HUNYUAN_MODEL",),
+                "hunyuan_deps": ("HUNYUAN_DEPS",),
+                "frame_rate": ("FLOAT", {"default": 16, "min": 1, "max": 120, "step": 0.1, "tooltip": "The framerate of the input image sequence"}),
+                "duration": ("FLOAT", {"default": 5.0, "min": 1, "max": 60.0, "step": 0.1, "tooltip": "Duration of the audio to generate in seconds"}),
+                "prompt": ("STRING", {"multiline": True, "default": "A person walks on frozen ice"}),
+                "negative_prompt": ("STRING", {"multiline": True, "default": "noisy, harsh"}),
+                "cfg_scale": ("FLOAT", {"default": 4.5, "min": 1.0, "max": 10.0, "step": 0.1, "tooltip": "Classifier-Free Guidance scale"}),
+                "steps": ("INT", {"default": 50, "min": 10, "max": 100, "step": 1, "tooltip": "Number of denoising steps"}),
+                "sampler": (cls.SAMPLER_NAMES, {"default": "euler", "tooltip": "Flow-match ODE solver"}),
+                "batch_size": ("INT", {"default": 1, "min": 1, "max": 6, "step": 1, "tooltip": "Number of audio variations to generate at once"}),
+                "seed": ("INT", {"default": 0, "min": 0, "max": 0xffffffffffffffff}),
+                "force_offload": ("BOOLEAN", {"default": True, "tooltip": "Kept for workflow compatibility; weights stay resident in HBM"}),
+            },
+            "optional": {
+                "image": ("IMAGE",),
+                "torch_compile_cfg": ("TORCH_COMPILE_CFG", {"tooltip": "Accepted for workflow compatibility and ignored (no tracing compiler on this path)."}),
+                "block_swap_args": ("BLOCKSWAPARGS", {"tooltip": "Accepted for workflow compatibility and ignored (288 GB HBM: nothing to swap)."}),
+            }
+        }
+
+    RETURN_TYPES = ("AUDIO", "AUDIO")
+    RETURN_NAMES = ("audio_first", "audio_batch")
+    FUNCTION = "generate_audio"
+    CATEGORY = "audio/HunyuanFoley"
+
+    def generate_audio(self, hunyuan_model, hunyuan_deps, frame_rate, duration, prompt, negative_prompt, cfg_scale,
+                       steps, sampler, batch_size, seed, force_offload, image=None, torch_compile_cfg=None,
+                       block_swap_args=None, features=None):
+        """`features` (not a ComfyUI socket) lets callers inject precomputed conditioning
+        {'siglip2_feat','syncformer_feat','text_feat','uncond_text_feat'} - used by tests/bench."""
+        model, deps = hunyuan_model, hunyuan_deps
+        device = model.device
+        rng = torch.Generator(device="cpu").manual_seed(seed)          # nodes.py:273
+        audio_len_in_s = duration
+        if features is not None:
+            visual = {k: features[k] for k in ("siglip2_feat", "syncformer_feat")}
+            text = {k: features[k] for k in ("text_feat", "uncond_text_feat")}
+            audio_len_in_s = features.get("audio_len_in_s", duration)
+        elif image is not None:
+            visual, text, audio_len_in_s = self._video_features(image, duration, frame_rate, prompt,
+                                                                negative_prompt, deps, device)
+        else:
+            # text-to-audio: learned "empty" visual rows (nodes.py:326-333)
+            clip_len = int(duration * 8)
+            sync_len = int(((int(duration * 25) - 16) // 8 + 1) * 8)
+            visual = {"siglip2_feat": model.get_empty_clip_sequence(bs=1, len=clip_len),
+                      "syncformer_feat": model.get_empty_sync_sequence(bs=1, len=sync_len)}
+            res = encode_text_feat([negative_prompt, prompt], deps, device)
+            text = {"text_feat": res[1:], "uncond_text_feat": res[:1]}
+        pbar = None
+        try:
+            import comfy.utils  # type: ignore
+            pbar = comfy.utils.ProgressBar(steps)
+        except Exception:
+            pass
+        audio, sr = _sampler.denoise_process_with_generator(
+            visual, text, audio_len_in_s, model, deps["dac_model"], guidance_scale=cfg_scale,
+            num_inference_steps=steps, batch_size=batch_size, sampler=sampler, generator=rng,
+            progress=(lambda i, n: pbar.update_absolute(i, n)) if pbar is not None else None)
+        waveform_batch = audio.float().cpu()
+        first = {"waveform": waveform_batch[0].unsqueeze(0), "sample_rate": sr}
+        return (first, {"waveform": waveform_batch, "sample_rate": sr})
+
+    @staticmethod
+    def _video_features(image, duration, frame_rate, prompt, negative_prompt, deps, device):
+        raise NotImplementedError(
+            "Video-to-audio conditioning needs the SigLIP2 and Synchformer encoders (SURVEY §8f N2); "
+            "pass precomputed features via `features=` or run text-to-audio.")
+
+
+# ----------------------------------------------------------------------------- compat nodes
+class HunyuanFoleyTorchCompile:
+    """Kept so existing workflows load; the resulting config is ignored by the sampler."""
+
+    @classmethod
+    def INPUT_TYPES(cls):
+        return {
+            "required": {
+                "backend": (["inductor"], {"default": "inductor"}),
+                "fullgraph": ("BOOLEAN", {"default": False}),
+                "mode": (["default", "reduce-overhead", "max-autotune"], {"default": "default"}),
+                "dynamic": (["true", "false", "None"], {"default": "false"}),
+                "dynamo_cache_limit": ("INT", {"default": 64, "min": 64, "max": 8192, "step": 64}),
+            }
+        }
+
+    RETURN_TYPES = ("TORCH_COMPILE_CFG",)
+    FUNCTION = "make_config"
+    CATEGORY = "audio/HunyuanFoley"
+
+    def make_config(self, backend, mode, dynamic, fullgraph, dynamo_cache_limit):
+        dyn = {"true": True, "false": False, "None": None}.get(str(dynamic), False)
+        return ({"backend": backend, "mode": mode, "dynamic": dyn, "fullgraph": fullgraph,
+                 "dynamo_cache_limit": int(dynamo_cache_limit)},)
+
+
+class HunyuanBlockSwap:
+    @classmethod
+    def INPUT_TYPES(cls):
+        return {
+            "required": {
+                "blocks_to_swap": ("INT", {"default": 30, "min": 0, "max": 57, "step": 1}),
+            },
+            "optional": {
+                "use_non_blocking": ("BOOLEAN", {"default": False}),
+                "prefetch_blocks": ("INT", {"default": 1, "min": 0, "max": 10, "step": 1}),
+                "block_swap_debug": ("BOOLEAN", {"default": False}),
+            },
+        }
+
+    RETURN_TYPES = ("BLOCKSWAPARGS",)
+    RETURN_NAMES = ("block_swap_args",)
+    FUNCTION = "set_args"
+    CATEGORY = "audio/HunyuanFoley"
+    DESCRIPTION = "Accepted for compatibility; the MI355X path keeps all 57 blocks resident in HBM."
+
+    def set_args(self, **kwargs):
+        return (kwargs,)
+
+
+class SelectAudioFromBatch:
+    @classmethod
+    def INPUT_TYPES(cls):
+        return {
+            "required": {
+                "audio_batch": ("AUDIO", {"tooltip": "An audio object containing a batch of waveforms."}),
+                "index": ("INT", {"default": 0, "min": 0, "max": 63, "tooltip": "The 0-based index of the audio to select from the batch."}),
+            }
+        }
+
+    RETURN_TYPES = ("AUDIO",)
+    FUNCTION = "select_audio"
+    CATEGORY = "audio/utils"
+
+    def select_audio(self, audio_batch, index):
+        wave, sr = audio_batch["waveform"], audio_batch["sample_rate"]
+        if index >= wave.shape[0]:
+            log.warning("Index %d is out of bounds for audio batch of size %d. Clamping to last item.", index,
+                        wave.shape[0])
+            index = wave.shape[0] - 1
+        return ({"waveform": wave[index].unsqueeze(0), "sample_rate": sr},)
+
+
+NODE_CLASS_MAPPINGS = {
+    "HunyuanModelLoader": HunyuanModelLoader,
+    "HunyuanDependenciesLoader": HunyuanDependenciesLoader,
+    "HunyuanFoleySampler": HunyuanFoleySampler,
+    "HunyuanFoleyTorchCompile": HunyuanFoleyTorchCompile,
+    "HunyuanBlockSwap": HunyuanBlockSwap,
+    "SelectAudioFromBatch": SelectAudioFromBatch,
+}
+NODE_DISPLAY_NAME_MAPPINGS = {
+    "HunyuanModelLoader": "Hunyuan-Foley Model Loader",
+    "HunyuanDependenciesLoader": "Hunyuan-Foley Dependencies Loader",
+    "HunyuanFoleySampler": "Hunyuan-Foley Sampler",
+    "HunyuanFoleyTorchCompile": "Hunyuan-Foley Torch Compile",
+    "HunyuanBlockSwap": "Hunyuan-Foley BlockSwap Settings",
+    "SelectAudioFromBatch": "Select Audio From Batch",
+}

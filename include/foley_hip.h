@@ -1,0 +1,156 @@
+/* libfoley_hip.so - C ABI of the MI355X (gfx950) HunyuanVideo-Foley sampling path.
+ *
+ * The reference (phazei/ComfyUI-HunyuanVideo-Foley) is pure Python and has no FFI of its own;
+ * each entry point below replaces a Python-level interface of the reference's hot path, which a
+ * maintainer would bind with ctypes (see INTEGRATION.md for the stub):
+ *
+ *   foley_ctx_create / foley_set_tensor   <- HunyuanModelLoader.load_model (nodes.py:72-133) and
+ *                                            load_dac_any (utils.py:61-87): weights -> device
+ *   foley_prepare                         <- the per-run setup of denoise_process_with_generator
+ *                                            (utils.py:144-199) + the step-invariant part of
+ *                                            HunyuanVideoFoley.forward (hifi_foley.py:744-807)
+ *   foley_dit_forward                     <- HunyuanVideoFoley.forward (hifi_foley.py:707-924)
+ *   foley_sample                          <- the denoising loop (utils.py:201-247) incl.
+ *                                            FlowMatchDiscreteScheduler.step
+ *                                            (scheduling_flow_match_discrete.py:210-297)
+ *   foley_dac_decode                      <- DAC.decode (dac_vae/model/dac.py:280-303)
+ *   foley_op_*                            <- the individual torch ops the reference calls on the
+ *                                            path (F.linear, conv1d, SDPA, layer_norm, ...), used
+ *                                            by the parity tests and micro-benchmarks
+ *
+ * Conventions: every function returns 0 on success or a negative error code and never throws;
+ * foley_last_error() gives the message of the calling thread's last failure.  All tensor
+ * arguments are raw DEVICE pointers (torch `tensor.data_ptr()`), owned by the caller and only
+ * borrowed for the duration of the call, except tensors registered with foley_set_tensor, which
+ * the caller must keep alive until the context is destroyed.  `stream` is a hipStream_t passed
+ * as void* (torch.cuda.current_stream().cuda_stream); work is enqueued, not synchronised, unless
+ * stated.  A context is used by one thread at a time.  Plain C types only - no torch types.
+ */
+#ifndef FOLEY_HIP_H
+#define FOLEY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FOLEY_ABI_VERSION 1
+
+enum foley_dtype { FOLEY_DT_F32 = 0, FOLEY_DT_BF16 = 1, FOLEY_DT_I32 = 2 };
+
+enum foley_status {
+  FOLEY_OK = 0,
+  FOLEY_ERR_INVALID = -1,   /* bad argument / shape / dtype            */
+  FOLEY_ERR_MISSING = -2,   /* a required tensor was never registered  */
+  FOLEY_ERR_HIP = -3,       /* HIP runtime failure                      */
+  FOLEY_ERR_STATE = -4      /* call order violated (e.g. no prepare)    */
+};
+
+typedef struct foley_ctx foley_ctx;
+
+/* Model dimensions (configs/hunyuanvideo-foley-xxl.yaml model_kwargs; utils.py:32-44 for DAC). */
+typedef struct foley_config {
+  int32_t depth_triple, depth_single, hidden, heads;
+  int32_t mlp_hidden;    /* triple-block MLP hidden  = hidden * mlp_ratio          */
+  int32_t conv_hidden;   /* single-block ConvMLP hidden (mlp_layers.py:141-142)     */
+  int32_t sync_hidden;   /* sync_in ConvMLP hidden                                 */
+  int32_t cond_dim, clip_dim, sync_dim, latent_dim, time_freq_dim;
+  int32_t compute_dtype; /* FOLEY_DT_F32 (parity mode) or FOLEY_DT_BF16 (throughput) for DiT GEMM operands */
+  int32_t dac_dim;       /* decoder width (2048)                                    */
+  int32_t dac_n_rates;   /* 5                                                       */
+  int32_t dac_rates[8];  /* 8,5,4,3,2                                               */
+  int32_t dac_dilations[3];
+} foley_config;
+
+/* One sampling run: conditioning + host-built index/trig tables (all device pointers). */
+typedef struct foley_plan {
+  int32_t ncfg;          /* 2 with classifier-free guidance ([uncond ; cond]), else 1 (utils.py:193-199) */
+  int32_t clips;         /* batch_size: independent clips sharing the conditioning   */
+  int32_t La, Lv, Ls, Lt;/* audio / visual / sync / text token counts                */
+  int32_t n_iter;        /* loop iterations (= steps; multi-stage solvers still do one model call per iteration) */
+  float guidance;
+  const float* text;     /* [ncfg, Lt, cond_dim]  zero-padded to Lt (utils.py:103-111) */
+  const float* clip;     /* [ncfg, Lv, clip_dim]  */
+  const float* sync;     /* [ncfg, Ls, sync_dim]  */
+  const float* t_feat;   /* [n_iter, time_freq_dim] sinusoidal timestep features (embed_layers.py:76-101) */
+  const float* rope_cos; /* [rope_len, 64] cos(pos * theta^(-2k/128)) (posemb_layers.py:117-172) */
+  const float* rope_sin;
+  int32_t rope_len;      /* >= 2*La                                                 */
+  const int32_t* pos_audio_self;  /* [La]  interleaved-RoPE position of audio token i  (= 2i)        */
+  const int32_t* pos_visual_self; /* [Lv]  interleaved-RoPE position of visual token j (hifi_foley.py:35-60) */
+  const int32_t* pos_linear;      /* [max(La,Lv,Lt)] 0,1,2,...                          */
+  const int32_t* sync_gather;     /* [La]  nearest-exact source row of the sync up-sampling (hifi_foley.py:761) */
+  const float* solver_coef;       /* [n_iter, 8] {w_new, w_acc, dt, w_store, flags,0,0,0} per iteration */
+} foley_plan;
+
+typedef void (*foley_progress_cb)(int32_t iteration, int32_t n_iter, void* user);
+
+uint32_t foley_abi_version(void);
+const char* foley_last_error(void);
+
+int foley_ctx_create(int device, const foley_config* cfg, foley_ctx** out);
+void foley_ctx_destroy(foley_ctx* ctx);
+
+/* Register one packed tensor (names and layouts: DESIGN.md "packed weight arena"). */
+int foley_set_tensor(foley_ctx* ctx, const char* name, const void* dev_ptr, int dtype, int ndim,
+                     const int64_t* shape);
+
+/* Step-invariant precompute for one run; allocates/reuses the context workspace. */
+int foley_prepare(foley_ctx* ctx, const foley_plan* plan, void* stream);
+
+/* One DiT evaluation at loop iteration `iter` (its timestep modulation): latents [clips,C,La]
+ * fp32 -> velocity rows [ncfg*clips*La, C] fp32 (row = (cfg*clips + clip)*La + l). */
+int foley_dit_forward(foley_ctx* ctx, const float* latents, int iter, float* out_rows, void* stream);
+
+/* Full denoising loop: `latents` [clips,C,La] fp32 holds the initial noise on entry and the final
+ * latents on return.  With a progress callback the stream is synchronised once per iteration.
+ * use_graph != 0 replays one captured hipGraph per iteration. */
+int foley_sample(foley_ctx* ctx, float* latents, int use_graph, foley_progress_cb cb, void* user, void* stream);
+
+/* DAC-VAE decoder: latents [clips, latent_dim, T] fp32 -> waveform [clips, 1, T*hop] fp32. */
+int foley_dac_decode(foley_ctx* ctx, const float* latents, int clips, int T, float* wave, void* stream);
+
+/* HIP-event time (ms) of the last foley_sample / foley_dac_decode call on this context (syncs). */
+int foley_last_elapsed_ms(foley_ctx* ctx, float* ms);
+
+/* ------------------------------------------------------------------ op-level entry points */
+typedef struct foley_rowbcast {  /* row-broadcast operand (AdaLN shift/scale/gate, addend) */
+  const float* p;       /* null => absent */
+  int64_t ld;
+  int32_t mode;         /* 0: one vector for all rows; 1: rows [cfg][clip][l] use operand row [cfg][l] */
+  int32_t rows_per_cfg, L;
+} foley_rowbcast;
+
+typedef struct foley_gemm_desc {
+  const void* A; const void* W; const float* bias;
+  int32_t M, N, K; int64_t lda;
+  int32_t segV, segS, taps, tapC, dil, tap0;      /* conv-as-GEMM addressing */
+  void* out0; void* out1;
+  int32_t osegV; int64_t out_seg, out_row, out_shift; int32_t out_check;
+  foley_rowbcast rb; const float* res; const float* alpha; int32_t alphaC;
+  int32_t dtype;   /* operand dtype */
+  int32_t epilogue;/* 0 store f32, 1 store T, 2 silu T, 3 gelu-tanh T, 4 silu-gate T, 5 gated residual, 6 DAC */
+  int32_t tile;    /* 0 auto */
+} foley_gemm_desc;
+
+int foley_op_gemm(const foley_gemm_desc* d, void* stream);
+int foley_op_attention(const float* q, const float* k, const float* v, int Bq, int H, int Sq, int Skv,
+                       int kv_bdiv, void* outA, void* outB, int split, int out_dtype, void* stream);
+int foley_op_ln_mod(const float* x, int M, int D, float eps, const foley_rowbcast* shift,
+                    const foley_rowbcast* scale, void* out, int out_dtype, void* stream);
+int foley_op_qkv_split(const float* qkv, int M, int L, int H, int nK, const float* const* gain,
+                       const int32_t* const* pos, float* const* dst, int S_tot, int tok_off, float eps,
+                       const float* cos_tab, const float* sin_tab, void* stream);
+int foley_op_solver_step(const float* pred, float* x, float* x_saved, float* d_acc, int clips, int C, int L,
+                         int ncfg, float guidance, const float* coef, int32_t* step_ptr, void* rows_out,
+                         int rows_dtype, void* stream);
+int foley_op_latent_rows(const float* x, int clips, int C, int L, int ncfg, void* out, int out_dtype,
+                         void* stream);
+int foley_op_dac_out(const float* s, const float* w, const float* bias, int B, int T, int C, float* out,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FOLEY_HIP_H */

@@ -1,0 +1,405 @@
+"""Generate golden vectors by RUNNING THE REFERENCE (build container only).
+
+    python tests/golden/make_golden.py [--only g1,g5,...] [--check-oracle]
+
+Imports /root/reference through `ref_harness` (stub third-party modules, the
+reference's own arithmetic untouched), feeds it the deterministic synthesised
+checkpoints of `host/synth.py`, and freezes inputs + reference outputs as small
+`.npz` fixtures next to this file.  With --check-oracle (default on) every
+fixture is also compared with `oracle/foley_oracle.py` and the script fails if
+the restatement drifts from the reference by more than 1e-5 (relative L2).
+
+Fixtures:
+  g1_scheduler   sigmas / timesteps / solver steps for all four solvers
+  g2_rope        cos/sin tables, rotary application, interleaved positions
+  g3_layers      ConvMLP k=3, snake, residual units, decoder blocks, weight-norm fold
+  g4_blocks      one full-width (D=1536) triple + single block forward
+  g5_dit_tiny    tiny-config full DiT forward
+  g6_c1_xxl      config C1 at real xxl dims: 1 s, 10 Euler steps, CFG off, bs 1 (the 1e-3 gate)
+  g7_sampler     tiny sampler: CFG 4.5 bs 2 Euler + the three multi-stage solvers
+  g9_dac         full-width DAC decoder on [1,128,10]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import ref_harness  # noqa: E402
+
+PKG = os.path.join(ROOT, "comfyui-hunyuanvideo-foley_amd")
+pkg = types.ModuleType("foley_amd")
+pkg.__path__ = [PKG]
+sys.modules.setdefault("foley_amd", pkg)
+from foley_amd.host import config as C  # noqa: E402
+from foley_amd.host import synth  # noqa: E402
+from oracle import foley_oracle as O  # noqa: E402
+
+NS = None
+CHECK = True
+TOL = 1e-5
+
+
+def rel(a: torch.Tensor, b: torch.Tensor) -> float:
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def check(name, oracle_out, ref_out, tol=None):
+    if not CHECK:
+        return
+    e = rel(oracle_out, ref_out)
+    flag = "ok" if e <= (tol or TOL) else "FAIL"
+    print(f"    oracle-vs-reference {name}: rel {e:.3e} [{flag}]")
+    if flag == "FAIL":
+        raise SystemExit(f"oracle drifted from reference on {name}")
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        out[k] = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"  wrote {name}.npz ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def ref_cfg(c: C.DiTConfig):
+    raw = yaml.safe_load(open(os.path.join(ref_harness.REFERENCE_ROOT, "configs", "hunyuanvideo-foley-xxl.yaml")))
+    raw["model_config"]["model_kwargs"].update(
+        depth_triple_blocks=c.depth_triple, depth_single_blocks=c.depth_single,
+        hidden_size=c.hidden, num_heads=c.heads)
+    return NS.cfgu.AttributeDict(raw)
+
+
+def build_ref_dit(c: C.DiTConfig, sd):
+    with torch.device("meta"):
+        m = NS.hifi.HunyuanVideoFoley(ref_cfg(c), dtype=torch.float32)
+    m.load_state_dict(sd, strict=True, assign=True)
+    return m.eval()
+
+
+def build_ref_dac(dc: C.DACConfig, sd):
+    kw = dict(NS.utils._DAC_KWARGS)
+    kw["decoder_dim"] = dc.decoder_dim
+    m = NS.dac.DAC(**kw).eval()
+    r = m.load_state_dict(sd, strict=False)
+    assert not r.unexpected_keys
+    assert all(k.startswith(("encoder", "quant_conv")) for k in r.missing_keys), r.missing_keys
+    return m
+
+
+class ModelDict(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+
+# ----------------------------------------------------------------------------- G1
+def g1():
+    out = {}
+    for n in (10, 50):
+        s = NS.sched.FlowMatchDiscreteScheduler(shift=1.0, solver="euler")
+        s.set_timesteps(n, device="cpu")
+        out[f"sigmas_{n}"], out[f"timesteps_{n}"] = s.sigmas, s.timesteps
+        check(f"sigmas{n}", O.flow_sigmas(n), s.sigmas, 0)
+        check(f"timesteps{n}", O.flow_timesteps(O.flow_sigmas(n)), s.timesteps, 0)
+    s = NS.sched.FlowMatchDiscreteScheduler(shift=3.0, solver="euler")
+    s.set_timesteps(10, device="cpu")
+    out["sigmas_10_shift3"] = s.sigmas
+    check("shift3", O.flow_sigmas(10, 3.0), s.sigmas, 1e-7)
+    g = torch.Generator().manual_seed(7)
+    x0 = torch.randn(2, 128, 16, generator=g)
+    vs = torch.randn(8, 2, 128, 16, generator=g)
+    out["x0"], out["v"] = x0, vs
+    for solver in ("euler", "heun-2", "midpoint-2", "kutta-4"):
+        s = NS.sched.FlowMatchDiscreteScheduler(shift=1.0, solver=solver)
+        s.set_timesteps(8, device="cpu")
+        st = O.SolverState(O.flow_sigmas(8), solver)
+        x, xo, tr = x0, x0, []
+        for i, t in enumerate(s.timesteps):
+            x = s.step(vs[i], t, x)[0]
+            xo = st.step(vs[i], xo)
+            tr.append(x)
+        out["trace_" + solver.replace("-", "_")] = torch.stack(tr)
+        check("solver " + solver, xo, x, 1e-7)
+    save("g1_scheduler", **out)
+
+
+# ----------------------------------------------------------------------------- G2
+def g2():
+    out = {}
+    for n in (77, 250, 500):
+        cos, sin = NS.posemb.get_nd_rotary_pos_embed([128], [n], theta=10000, use_real=True,
+                                                     theta_rescale_factor=1.0)
+        oc, os_ = O.rope_table(O.rope_positions(n), 128)
+        check(f"rope{n}", torch.stack([oc, os_]), torch.stack([cos, sin]), 1e-7)
+        if n != 500:
+            out[f"cos_{n}"], out[f"sin_{n}"] = cos, sin
+        else:   # store a strided view; the full table is 256 KB
+            out["cos_500_s7"], out["sin_500_s7"] = cos[::7], sin[::7]
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 6, 2, 128, generator=g)
+    cos, sin = O.rope_table(O.rope_positions(6), 128)
+    rq, _ = NS.attn.apply_rotary_emb(x, x, (cos, sin), head_first=False)
+    rqh, _ = NS.attn.apply_rotary_emb(x.transpose(1, 2), x.transpose(1, 2), (cos, sin), head_first=True)
+    check("apply_rope", O.apply_rope(x, cos, sin), rq, 1e-7)
+    check("apply_rope head_first", O.apply_rope(x, cos, sin).transpose(1, 2), rqh, 1e-7)
+    out["rope_x"], out["rope_y"] = x, rq
+    # interleaved audio/visual positions: run the reference interleave machinery on
+    # "position-coded" tensors and read the positions back.
+    for la, lv in ((250, 40), (50, 8), (1500, 240), (55, 8), (251, 40)):
+        a = torch.zeros(1, la, 1, 2)
+        v = torch.zeros(1, lv, 1, 2)
+        inter = NS.hifi.interleave_two_sequences(a, v)
+        pos = torch.arange(2 * la, dtype=torch.float32).view(1, 2 * la, 1, 1).expand(1, 2 * la, 1, 2)
+        pa, pv = NS.hifi.decouple_interleaved_two_sequences(inter + pos, la, lv)
+        opa, opv = O.interleaved_positions(la, lv)
+        assert torch.equal(pa[0, :, 0, 0].long(), opa) and torch.equal(pv[0, :, 0, 0].long(), opv), (la, lv)
+        # and the token identity: token j must come back as itself
+        tag = torch.arange(lv, dtype=torch.float32).view(1, lv, 1, 1).expand(1, lv, 1, 2)
+        _, tv = NS.hifi.decouple_interleaved_two_sequences(NS.hifi.interleave_two_sequences(a, tag), la, lv)
+        assert torch.equal(tv[0, :, 0, 0], torch.arange(lv, dtype=torch.float32))
+        out[f"pos_v_{la}_{lv}"] = opv
+    print("    interleaved positions verified for 5 (La, Lv) pairs")
+    save("g2_rope", **out)
+
+
+# ----------------------------------------------------------------------------- G3
+def g3():
+    import importlib
+    mlp = importlib.import_module("hunyuanvideo_foley.models.nn.mlp_layers")
+    layers = importlib.import_module("hunyuanvideo_foley.models.dac_vae.nn.layers")
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    # ConvMLP k=3 at small width incl. edge padding
+    D, Hc = 256, 768
+    cm = mlp.ConvMLP(D, D * 4, kernel_size=3, padding=1).eval()
+    sd = {"w1.weight": synth.synth_tensor("g3.w1", (Hc, D, 3), 0.03),
+          "w2.weight": synth.synth_tensor("g3.w2", (D, Hc, 3), 0.02),
+          "w3.weight": synth.synth_tensor("g3.w3", (Hc, D, 3), 0.03)}
+    cm.load_state_dict(sd)
+    x = torch.randn(2, 9, D, generator=g)
+    with torch.inference_mode():
+        y = cm(x)
+    oy = O.conv1d_cl(torch.nn.functional.silu(O.conv1d_cl(x, sd["w1.weight"], None, 1))
+                     * O.conv1d_cl(x, sd["w3.weight"], None, 1), sd["w2.weight"], None, 1)
+    check("convmlp", oy, y)
+    out["convmlp_x"], out["convmlp_y"] = x, y
+    # snake
+    al = synth.synth_tensor("g3.alpha", (1, 16, 1), 0.15, 1.0)
+    xs = torch.randn(2, 16, 33, generator=g) * 2
+    ys = layers.snake(xs, al)
+    check("snake", O.snake(xs, al), ys, 1e-7)
+    out["snake_x"], out["snake_alpha"], out["snake_y"] = xs, al, ys
+    # weight-norm fold, Conv1d vs ConvTranspose1d
+    c1 = layers.WNConv1d(8, 12, kernel_size=7, padding=3)
+    ct = layers.WNConvTranspose1d(8, 12, kernel_size=10, stride=5, padding=3, output_padding=1)
+    for nm, m in (("conv", c1), ("convT", ct)):
+        gk, vk = m.parametrizations.weight.original0, m.parametrizations.weight.original1
+        check("wn fold " + nm, O.weight_norm_fold(gk.detach(), vk.detach()), m.weight.detach(), 1e-6)
+    # residual units + decoder blocks (stride 2 and odd stride 5) at C=64 via a narrow DAC
+    dc = C.DACConfig(decoder_dim=128, rates=(5, 2))
+    dsd = synth.synth_dac_state_dict(dc)
+    kw = dict(NS.utils._DAC_KWARGS)
+    kw.update(decoder_dim=128, decoder_rates=[5, 2])
+    dac = NS.dac.DAC(**kw).eval()
+    r = dac.load_state_dict(dsd, strict=False)
+    assert not r.unexpected_keys
+    z = torch.randn(2, 128, 7, generator=g)
+    with torch.inference_mode():
+        yr = dac.decode(z)
+    taps = {}
+    yo = O.dac_decode(dsd, z, rates=(5, 2), taps=taps)
+    check("dac(5,2)", yo, yr)
+    out["dac52_z"], out["dac52_y"] = z, yr
+    out["dac52_stage0"] = taps["stage0"]
+    save("g3_layers", **out)
+
+
+# ----------------------------------------------------------------------------- G4
+def g4():
+    c = C.DiTConfig(name="xxl-1-1", depth_triple=1, depth_single=1)
+    sd = synth.synth_dit_state_dict(c)
+    m = build_ref_dit(c, sd)
+    La, Lv, Ls = C.lengths(1.0, c)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(1, 128, La, generator=g)
+    t = torch.tensor([620.0])
+    cond = torch.randn(1, 77, 768, generator=g)
+    clip = torch.randn(1, Lv, 768, generator=g)
+    sync = torch.randn(1, Ls, 768, generator=g)
+    caught = {}
+    h1 = m.triple_blocks[0].register_forward_hook(lambda mod, i, o: caught.__setitem__("triple", o))
+    h2 = m.single_blocks[0].register_forward_hook(lambda mod, i, o: caught.__setitem__("single", o))
+    with torch.inference_mode():
+        y = m(x=x, t=t, cond=cond, clip_feat=clip, sync_feat=sync)["x"]
+    h1.remove(), h2.remove()
+    taps = {}
+    yo = O.dit_forward(sd, c.heads, x, t, cond, clip, sync, taps=taps)
+    check("triple block audio", taps["triple0"], caught["triple"][0])
+    check("single block", taps["single0"], caught["single"])
+    check("forward", yo, y)
+    save("g4_blocks", x=x, t=t, cond=cond, clip=clip, sync=sync, y=y,
+         triple_audio=caught["triple"][0], triple_v=caught["triple"][2], single=caught["single"])
+
+
+# ----------------------------------------------------------------------------- G5
+def g5():
+    c = C.TINY
+    sd = synth.synth_dit_state_dict(c)
+    m = build_ref_dit(c, sd)
+    out = {}
+    g = torch.Generator().manual_seed(5)
+    for tag, dur in (("a", 1.0), ("b", 2.2)):
+        La, Lv, Ls = C.lengths(dur, c)
+        x = torch.randn(2, 128, La, generator=g)
+        t = torch.tensor([980.0, 980.0])
+        cond = torch.randn(2, 77, 768, generator=g)
+        clip = torch.randn(2, Lv, 768, generator=g)
+        sync = torch.randn(2, Ls, 768, generator=g)
+        with torch.inference_mode():
+            y = m(x=x, t=t, cond=cond, clip_feat=clip, sync_feat=sync)["x"]
+        check(f"tiny forward {tag} (La={La},Lv={Lv},Ls={Ls})", O.dit_forward(sd, c.heads, x, t, cond, clip, sync), y)
+        for k, v in (("x", x), ("t", t), ("cond", cond), ("clip", clip), ("sync", sync), ("y", y)):
+            out[f"{tag}_{k}"] = v
+    save("g5_dit_tiny", **out)
+
+
+# ----------------------------------------------------------------------------- G6
+def g6():
+    c = C.XXL
+    t0 = time.time()
+    sd = synth.synth_dit_state_dict(c)
+    dsd = synth.synth_dac_state_dict(C.DAC48K)
+    print(f"    synthesised xxl + DAC weights in {time.time() - t0:.0f}s")
+    m = build_ref_dit(c, sd)
+    dac = build_ref_dac(C.DAC48K, dsd)
+    cond = synth.synth_conditioning(c, 1.0, t2a=True, sd=sd)
+    md = ModelDict(foley_model=m, dac_model=dac, device=torch.device("cpu"))
+    # capture per-step latents through the reference scheduler
+    trace = []
+    orig_step = NS.sched.FlowMatchDiscreteScheduler.step
+
+    def spy(self, *a, **k):
+        r = orig_step(self, *a, **k)
+        trace.append(r[0].clone())
+        return r
+    NS.sched.FlowMatchDiscreteScheduler.step = spy
+    gen = torch.Generator("cpu").manual_seed(1234)
+    t0 = time.time()
+    try:
+        with torch.inference_mode():
+            audio, sr = NS.utils.denoise_process_with_generator(
+                {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]},
+                {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]},
+                1.0, md, ref_cfg(c), 1.0, 10, 1, "euler", generator=gen)
+    finally:
+        NS.sched.FlowMatchDiscreteScheduler.step = orig_step
+    print(f"    reference C1 sampler ran in {time.time() - t0:.0f}s -> {tuple(audio.shape)} @ {sr}")
+    gen = torch.Generator("cpu").manual_seed(1234)
+    noise = torch.randn((1, 128, 50), generator=gen, dtype=torch.float32)
+    otrace, taps = [], {}
+    t0 = time.time()
+    with torch.inference_mode():
+        lat = O.sample_latents(sd, c.heads, noise, cond["text"], cond["uncond_text"], cond["clip"],
+                               cond["sync"], 10, 1.0, trace=otrace)
+        wav = O.dac_decode(dsd, lat)
+        # block-level probes of the first forward, for localising drift on the GPU
+        La, Lv, Ls = C.lengths(1.0, c)
+        O.dit_forward(sd, c.heads, noise, torch.tensor([1000.0]), O.pad_or_trim_text(cond["text"]),
+                      cond["clip"], cond["sync"], taps=taps)
+    print(f"    oracle C1 sampler ran in {time.time() - t0:.0f}s")
+    check("C1 latents", torch.stack(otrace), torch.stack(trace))
+    check("C1 waveform", wav, audio)
+    probes = {k: v[0, ::7, ::48].clone() for k, v in taps.items() if v.dim() == 3}
+    norms = {k: float(v.double().norm()) for k, v in taps.items() if v.dim() == 3}
+    save("g6_c1_xxl", noise=noise, latents=torch.stack(trace), waveform=audio,
+         probe_names=np.array(list(probes.keys())), probes=torch.stack(
+             [torch.nn.functional.pad(p, (0, 0, 0, 8 - p.shape[0])) for p in probes.values()]),
+         probe_norms=np.array([norms[k] for k in probes.keys()]))
+
+
+# ----------------------------------------------------------------------------- G7
+def g7():
+    c = C.TINY
+    sd = synth.synth_dit_state_dict(c)
+    dsd = synth.synth_dac_state_dict(C.DAC_TINY)
+    m = build_ref_dit(c, sd)
+    dac = build_ref_dac(C.DAC_TINY, dsd)
+    md = ModelDict(foley_model=m, dac_model=dac, device=torch.device("cpu"))
+    out = {}
+    for tag, t2a, dur, g, bs, solver, steps in (
+            ("cfg_euler", False, 1.0, 4.5, 2, "euler", 10),
+            ("t2a_nocfg", True, 1.0, 1.0, 1, "euler", 10),
+            ("heun", False, 1.0, 4.5, 1, "heun-2", 10),
+            ("midpoint", False, 1.0, 4.5, 1, "midpoint-2", 10),
+            ("kutta", False, 1.0, 4.5, 1, "kutta-4", 12),
+            ("v2a_2s", False, 2.0, 3.0, 2, "euler", 12)):
+        cond = synth.synth_conditioning(c, dur, t2a=t2a, sd=sd)
+        if hasattr(m, "_text_len_fixed"):
+            del m._text_len_fixed
+        gen = torch.Generator("cpu").manual_seed(1234)
+        with torch.inference_mode():
+            audio, _ = NS.utils.denoise_process_with_generator(
+                {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]},
+                {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]},
+                dur, md, ref_cfg(c), g, steps, bs, solver, generator=gen)
+        gen = torch.Generator("cpu").manual_seed(1234)
+        noise = torch.randn((bs, 128, int(dur * 50)), generator=gen, dtype=torch.float32)
+        with torch.inference_mode():
+            lat = O.sample_latents(sd, c.heads, noise, cond["text"], cond["uncond_text"], cond["clip"],
+                                   cond["sync"], steps, g, solver)
+            wav = O.dac_decode(dsd, lat)
+        check(f"sampler {tag}", wav, audio, 3e-5)
+        out[tag + "_noise"], out[tag + "_latents"] = noise, lat
+        out[tag + "_wave_s5"] = audio[..., ::5]   # subsampled waveform keeps the fixture small
+    save("g7_sampler", **out)
+
+
+# ----------------------------------------------------------------------------- G9
+def g9():
+    dsd = synth.synth_dac_state_dict(C.DAC48K)
+    dac = build_ref_dac(C.DAC48K, dsd)
+    g = torch.Generator().manual_seed(9)
+    z = torch.randn(1, 128, 10, generator=g)
+    with torch.inference_mode():
+        y = dac.decode(z)
+    check("dac full width", O.dac_decode(dsd, z), y)
+    save("g9_dac", z=z, y=y)
+
+
+ALL = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7, "g9": g9}
+
+
+def main():
+    global NS, CHECK
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--no-check-oracle", action="store_true")
+    a = ap.parse_args()
+    CHECK = not a.no_check_oracle
+    NS = ref_harness.load_reference()
+    torch.set_num_threads(os.cpu_count() or 8)
+    names = [n for n in a.only.split(",") if n] or list(ALL)
+    for n in names:
+        print(f"[{n}]")
+        t0 = time.time()
+        ALL[n]()
+        print(f"  done in {time.time() - t0:.0f}s")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,188 @@
+"""End-to-end parity of the HIP path (through the C ABI) against golden vectors frozen from the
+reference (tests/golden/*.npz) and against the CPU oracle: DiT forward, blocks at full width,
+sampler loop with all solvers, DAC decoder, and the config-C1 gate at real xxl dimensions.
+"""
+import pytest
+import torch
+
+from conftest import golden, rel_err
+from foley_amd.host import config as C, sampler, synth, tables
+from oracle import foley_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _plan_single(model, text, clip, sync, La, t_values):
+    """ncfg=1, clips=1 plan evaluating the model at explicit timesteps."""
+    dev = model.device
+    Lv, Ls, Lt = clip.shape[1], sync.shape[1], text.shape[1]
+    n = len(t_values)
+    tb = tables.build_tables(La, Lv, Ls, Lt, max(n, 1), "euler", 1.0, model.cfg.time_freq_dim)
+    tb["t_feat"] = tables.timestep_features(torch.tensor(t_values, dtype=torch.float32), model.cfg.time_freq_dim)
+    plan = {"ncfg": 1, "clips": 1, "La": La, "Lv": Lv, "Ls": Ls, "Lt": Lt, "n_iter": n, "guidance": 1.0,
+            "rope_len": tb["rope_cos"].shape[0], "text": text.float().to(dev).contiguous(),
+            "clip": clip.float().to(dev).contiguous(), "sync": sync.float().to(dev).contiguous()}
+    for k in ("t_feat", "rope_cos", "rope_sin", "pos_audio_self", "pos_visual_self", "pos_linear", "sync_gather",
+              "solver_coef"):
+        plan[k] = tb[k].to(dev).contiguous()
+    return plan
+
+
+def _forward(model, x, t, cond, clip, sync):
+    """Reference-shaped forward: x [B,128,La] (per-sample conditioning) -> [B,128,La]."""
+    outs = []
+    for b in range(x.shape[0]):
+        plan = _plan_single(model, cond[b:b + 1], clip[b:b + 1], sync[b:b + 1], x.shape[2], [float(t[b])])
+        model.ctx.prepare(plan)
+        rows = model.ctx.dit_forward(x[b:b + 1].to(model.device).contiguous(), 0)
+        outs.append(rows.view(1, x.shape[2], -1).transpose(1, 2))
+    return torch.cat(outs).cpu()
+
+
+@pytest.fixture(scope="module")
+def tiny(dev):
+    sd = synth.synth_dit_state_dict(C.TINY)
+    dsd = synth.synth_dac_state_dict(C.DAC_TINY)
+    model = sampler.FoleyModel(C.TINY, sd, torch.float32, dev, dac_cfg=C.DAC_TINY)
+    dac = sampler.FoleyDAC(dsd, dev, C.DAC_TINY)
+    return sd, dsd, model, dac
+
+
+def test_dit_forward_tiny_golden(tiny):
+    """G5: tiny-config full forward, two length sets incl. non-multiple-of-32 token counts."""
+    _sd, _dsd, model, _dac = tiny
+    g = golden("g5_dit_tiny")
+    for tag in ("a", "b"):
+        y = _forward(model, g[tag + "_x"], g[tag + "_t"], g[tag + "_cond"], g[tag + "_clip"], g[tag + "_sync"])
+        assert rel_err(y, g[tag + "_y"]) < 2e-5, tag
+
+
+def test_blocks_full_width_golden(dev):
+    """G4: one triple + one single block at D=1536 (exercises every production GEMM shape class)."""
+    c = C.DiTConfig(name="xxl-1-1", depth_triple=1, depth_single=1)
+    model = sampler.FoleyModel(c, synth.synth_dit_state_dict(c, device=dev), torch.float32, dev)
+    g = golden("g4_blocks")
+    y = _forward(model, g["x"], g["t"], g["cond"], g["clip"], g["sync"])
+    assert rel_err(y, g["y"]) < 2e-5
+
+
+@pytest.mark.parametrize("tag,t2a,dur,guid,bs,solver,steps", [
+    ("cfg_euler", False, 1.0, 4.5, 2, "euler", 10),
+    ("t2a_nocfg", True, 1.0, 1.0, 1, "euler", 10),
+    ("heun", False, 1.0, 4.5, 1, "heun-2", 10),
+    ("midpoint", False, 1.0, 4.5, 1, "midpoint-2", 10),
+    ("kutta", False, 1.0, 4.5, 1, "kutta-4", 12),
+    ("v2a_2s", False, 2.0, 3.0, 2, "euler", 12)])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_sampler_golden(tiny, tag, t2a, dur, guid, bs, solver, steps, use_graph):
+    """G7: whole loop + DAC vs the reference's denoise_process_with_generator (1e-3 gate)."""
+    sd, _dsd, model, dac = tiny
+    g = golden("g7_sampler")
+    cond = synth.synth_conditioning(C.TINY, dur, t2a=t2a, sd=sd)
+    audio, sr, lat = sampler.denoise_process_with_generator(
+        {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]},
+        {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]},
+        dur, model, dac, guid, steps, bs, solver, noise=g[tag + "_noise"], use_graph=use_graph,
+        return_latents=True)
+    assert sr == 48000 and audio.shape == (bs, 1, int(dur * 50) * 960)
+    assert rel_err(lat, g[tag + "_latents"]) < 1e-4
+    assert rel_err(audio[..., ::5], g[tag + "_wave_s5"]) < 1e-3
+
+
+def test_sampler_noise_matches_reference_draw(tiny):
+    """The CPU-generator draw (utils.py:114-121) must reproduce the committed golden noise."""
+    g = golden("g7_sampler")
+    gen = torch.Generator("cpu").manual_seed(1234)
+    n = sampler.draw_noise(2, 128, 50, torch.float32, gen)
+    assert torch.equal(n, g["cfg_euler_noise"])
+
+
+def test_dac_golden_narrow(dev):
+    """G3: rates (5, 2) decoder - odd stride exercises output_padding."""
+    dc = C.DACConfig(decoder_dim=128, rates=(5, 2))
+    dit = C.TINY
+    model = sampler.FoleyModel(dit, synth.synth_dit_state_dict(dit), torch.float32, dev, dac_cfg=dc)
+    dac = sampler.FoleyDAC(synth.synth_dac_state_dict(dc), dev, dc)
+    model.attach_dac(dac)
+    g = golden("g3_layers")
+    y = model.ctx.dac_decode(g["dac52_z"].to(dev).contiguous())
+    assert rel_err(y, g["dac52_y"]) < 2e-5
+
+
+def test_dac_golden_full_width(dev):
+    """G9: the real 2048-wide decoder, rates (8,5,4,3,2), on 10 latent frames -> 9600 samples."""
+    model = sampler.FoleyModel(C.TINY, synth.synth_dit_state_dict(C.TINY), torch.float32, dev, dac_cfg=C.DAC48K)
+    dac = sampler.FoleyDAC(synth.synth_dac_state_dict(C.DAC48K, device=dev), dev, C.DAC48K)
+    model.attach_dac(dac)
+    g = golden("g9_dac")
+    y = model.ctx.dac_decode(g["z"].to(dev).contiguous())
+    assert y.shape == (1, 1, 9600)
+    assert rel_err(y, g["y"]) < 2e-5
+    # batch of 3 with different latents == three independent decodes (segment handling)
+    z3 = torch.randn(3, 128, 7, generator=torch.Generator().manual_seed(4)).to(dev)
+    y3 = model.ctx.dac_decode(z3)
+    for i in range(3):
+        assert rel_err(y3[i:i + 1], model.ctx.dac_decode(z3[i:i + 1].contiguous())) < 1e-6
+
+
+def test_batch_equals_independent_clips(tiny):
+    """Clips in a batch are independent: bs=3 must equal three bs=1 runs."""
+    sd, _dsd, model, dac = tiny
+    cond = synth.synth_conditioning(C.TINY, 1.0, t2a=False, sd=sd)
+    feats = ({"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]},
+             {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]})
+    noise = torch.randn(3, 128, 50, generator=torch.Generator().manual_seed(8))
+    _a, _sr, lat3 = sampler.denoise_process_with_generator(*feats, 1.0, model, dac, 4.5, 10, 3, "euler",
+                                                           noise=noise, return_latents=True)
+    for i in range(3):
+        _a, _sr, lat1 = sampler.denoise_process_with_generator(*feats, 1.0, model, dac, 4.5, 10, 1, "euler",
+                                                               noise=noise[i:i + 1], return_latents=True)
+        assert rel_err(lat3[i:i + 1], lat1) < 1e-5
+
+
+def test_bf16_mode_forward(dev):
+    """Throughput mode: bf16 GEMM operands, fp32 accumulate/residual.  Checked against the oracle
+    run on bf16-rounded weights with a bf16-appropriate tolerance (the 1e-3 gate is an fp32-mode
+    gate)."""
+    c = C.TINY
+    sd = synth.synth_dit_state_dict(c)
+    sdq = {k: (v.to(torch.bfloat16).float() if v.dim() >= 2 and "pos_emb" not in k and "empty" not in k else v)
+           for k, v in sd.items()}
+    model = sampler.FoleyModel(c, sd, torch.bfloat16, dev, dac_cfg=C.DAC_TINY)
+    g = golden("g5_dit_tiny")
+    x, t, cond, clip, sync = (g["a_" + k] for k in ("x", "t", "cond", "clip", "sync"))
+    xq = x.to(torch.bfloat16).float()
+    y = _forward(model, xq, t, cond, clip, sync)
+    with torch.inference_mode():
+        ref = O.dit_forward(sdq, c.heads, xq, t, cond, clip, sync)
+    assert rel_err(y, ref) < 3e-2
+
+
+def test_c1_xxl_golden(dev):
+    """G6 - the parity gate of BASELINE.json: config C1 (T2A 1 s, 10 Euler steps, CFG off, bs 1)
+    at real xxl dimensions, HIP fp32 mode vs the reference fp32 CPU sampler: 1e-3 relative on
+    the 48 kHz waveform; per-step latents localise any drift."""
+    g = golden("g6_c1_xxl")
+    cfg = C.XXL
+    sd = synth.synth_dit_state_dict(cfg, device=dev)
+    cond = synth.synth_conditioning(cfg, 1.0, t2a=True, sd=sd, device=dev)
+    model = sampler.FoleyModel(cfg, sd, torch.float32, dev)
+    del sd
+    torch.cuda.empty_cache()
+    dac = sampler.FoleyDAC(synth.synth_dac_state_dict(C.DAC48K, device=dev), dev)
+    trace = []
+    La = 50
+    plan = sampler.build_plan(model, {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]},
+                              {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]}, La, 1.0, 10, 1,
+                              "euler")
+    model.attach_dac(dac)
+    model.ctx.prepare(plan)
+    lat = g["noise"].to(dev).contiguous()
+    model.ctx.sample(lat, use_graph=False, progress=lambda i, n: trace.append(lat.clone().cpu()))
+    errs = [rel_err(trace[i], g["latents"][i]) for i in range(10)]
+    print("per-step latent rel err:", ["%.2e" % e for e in errs])
+    wave = model.ctx.dac_decode(lat)
+    werr = rel_err(wave, g["waveform"])
+    print("waveform rel err: %.3e" % werr)
+    assert max(errs) < 1e-4
+    assert werr < 1e-3

@@ -1,0 +1,279 @@
+"""Op-level parity tests: every HIP kernel family, called through the C ABI (foley_op_*),
+against a plain PyTorch fp32 CPU statement of the same op.  fp32 operands must agree to fp32
+round-off (the MFMA fp32 path is an exact FMA chain); bf16 operands are compared against the
+same math on bf16-rounded inputs with a bf16-appropriate tolerance.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+from foley_amd.host import packers, runtime as rt, tables
+from oracle import foley_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 2e-6
+BF16_TOL = 6e-3
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _rand(shape, seed, scale=1.0):
+    return torch.randn(*shape, generator=_g(seed)) * scale
+
+
+def _tol(dtype):
+    return F32_TOL if dtype == torch.float32 else BF16_TOL
+
+
+def _q(t, dtype):   # round a CPU reference operand through the compute dtype
+    return t.to(dtype).to(torch.float32)
+
+
+# ----------------------------------------------------------------------------- GEMM: plain linear
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,tile", [
+    (500, 1536, 1536, 0), (500, 1536, 1536, 1), (500, 1536, 1536, 2), (500, 1536, 1536, 3),
+    (37, 200, 256, 0), (130, 128, 128, 0), (10, 13824, 1536, 0), (4000, 64, 128, 4), (77, 3072, 768, 0),
+])
+def test_gemm_linear(dev, dtype, M, N, K, tile):
+    A, W, b = _rand((M, K), 1), _rand((N, K), 2, 1 / math.sqrt(K)), _rand((N,), 3, 0.1)
+    ref = F.linear(_q(A, dtype), _q(W, dtype), b)
+    out = torch.full((M, N), float("nan"), device=dev)
+    rt.op_gemm(A.to(dev, dtype), W.to(dev, dtype), b.to(dev), out0=out, tile=tile)
+    assert rel_err(out, ref) < _tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_transpose_detecting(dev, dtype):
+    """A = I with an asymmetric W: catches a swapped C/D row/column mapping."""
+    K = 128
+    A = torch.eye(K)
+    W = torch.arange(192 * K, dtype=torch.float32).view(192, K) % 251 / 16.0
+    out = torch.empty(K, 192, device=dev)
+    rt.op_gemm(A.to(dev, dtype), W.to(dev, dtype), None, out0=out)
+    assert torch.equal(out.cpu(), W.t().contiguous())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("epi", ["store_t", "silu", "gelu", "silugate", "gate_res_vec", "gate_res_tok", "addend"])
+def test_gemm_epilogues(dev, dtype, epi):
+    M, N, K = 300, 512, 256
+    clips, L = 3, 50                     # rows ordered [cfg=2][clip=3][l=50]
+    A, W, b = _rand((M, K), 4), _rand((N, K), 5, 1 / math.sqrt(K)), _rand((N,), 6, 0.1)
+    y = F.linear(_q(A, dtype), _q(W, dtype), b)
+    Ad, Wd, bd = A.to(dev, dtype), W.to(dev, dtype), b.to(dev)
+    if epi in ("store_t", "silu", "gelu"):
+        out = torch.empty(M, N, device=dev, dtype=dtype)
+        code = {"store_t": rt.EPI_STORE_T, "silu": rt.EPI_SILU_T, "gelu": rt.EPI_GELU_T}[epi]
+        rt.op_gemm(Ad, Wd, bd, out0=out, epilogue=code)
+        ref = {"store_t": y, "silu": F.silu(y), "gelu": F.gelu(y, approximate="tanh")}[epi]
+        assert rel_err(out.float(), ref) < max(_tol(dtype), 4e-3 if dtype == torch.bfloat16 else 0)
+    elif epi == "silugate":
+        w1, w3 = W[: N // 2], W[N // 2:]
+        Wp = packers.interleave_gate(w1, w3)
+        out = torch.empty(M, N // 2, device=dev, dtype=dtype)
+        rt.op_gemm(Ad, Wp.to(dev, dtype), None, out0=out, epilogue=rt.EPI_SILUGATE_T)
+        ref = F.silu(F.linear(_q(A, dtype), _q(w1, dtype))) * F.linear(_q(A, dtype), _q(w3, dtype))
+        assert rel_err(out.float(), ref) < _tol(dtype) * (1 if dtype == torch.float32 else 1.5)
+    elif epi == "gate_res_vec":
+        x0, gate = _rand((M, N), 7), _rand((N,), 8)
+        x = x0.to(dev).clone()
+        rt.op_gemm(Ad, Wd, bd, out0=x, epilogue=rt.EPI_GATE_RES, rb=rt.rowbcast(gate.to(dev), 0))
+        assert rel_err(x, x0 + y * gate) < _tol(dtype)
+    elif epi == "gate_res_tok":
+        x0, gate = _rand((M, N), 7), _rand((2, L, N), 8)
+        x = x0.to(dev).clone()
+        rt.op_gemm(Ad, Wd, bd, out0=x, epilogue=rt.EPI_GATE_RES,
+                   rb=rt.rowbcast(gate.to(dev), 1, rows_per_cfg=clips * L, L=L))
+        ref = x0 + y * gate[:, None].expand(2, clips, L, N).reshape(M, N)
+        assert rel_err(x, ref) < _tol(dtype)
+    else:
+        add = _rand((2, L, N), 9)
+        out = torch.empty(M, N, device=dev)
+        rt.op_gemm(Ad, Wd, bd, out0=out, rb=rt.rowbcast(add.to(dev), 1, rows_per_cfg=clips * L, L=L))
+        ref = y + add[:, None].expand(2, clips, L, N).reshape(M, N)
+        assert rel_err(out, ref) < _tol(dtype)
+
+
+# ----------------------------------------------------------------------------- GEMM: conv addressing
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,L,Cin,Cout", [(2, 50, 256, 384), (3, 7, 128, 64), (1, 250, 1536, 256)])
+def test_conv3_channels_last(dev, dtype, B, L, Cin, Cout):
+    """ChannelLastConv1d k=3 pad=1 (mlp_layers.py:104-110) as a GEMM over overlapping rows."""
+    x, w, b = _rand((B, L, Cin), 10), _rand((Cout, Cin, 3), 11, 1 / math.sqrt(3 * Cin)), _rand((Cout,), 12, 0.1)
+    ref = O.conv1d_cl(_q(x, dtype), _q(w, dtype), b, 1).reshape(B * L, Cout)
+    out = torch.empty(B * L, Cout, device=dev)
+    rt.op_gemm(x.reshape(B * L, Cin).to(dev, dtype), packers.conv_to_gemm(w).to(dev, dtype), b.to(dev),
+               out0=out, conv=(L, Cin, 3, 1))
+    assert rel_err(out, ref) < _tol(dtype)
+
+
+@pytest.mark.parametrize("dil", [1, 3, 9])
+@pytest.mark.parametrize("B,T,C", [(2, 100, 64), (1, 37, 128)])
+def test_dac_conv7_snake(dev, dil, B, T, C):
+    """Dilated conv k=7 + snake epilogue; residual 1x1 conv + snake (dac.py:28-44)."""
+    x, w, b = _rand((B, C, T), 13), _rand((C, C, 7), 14, 1 / math.sqrt(7 * C)), _rand((C,), 15, 0.1)
+    a2 = 1 + 0.2 * _rand((C,), 16)
+    ref = O.snake(F.conv1d(x, w, b, dilation=dil, padding=3 * dil), a2.view(1, C, 1)).transpose(1, 2)
+    xs = x.transpose(1, 2).contiguous().to(dev)                       # [B, T, C]
+    out1 = torch.empty(B, T, C, device=dev)
+    rt.op_gemm(xs, packers.conv_to_gemm(w).to(dev), b.to(dev), out1=out1, conv=(T, C, 7, dil),
+               epilogue=rt.EPI_DAC, alpha=a2.to(dev), alphaC=C)
+    assert rel_err(out1, ref) < 3e-6
+    # 1x1 conv with residual, both outputs
+    w1, b1 = _rand((C, C, 1), 17, 1 / math.sqrt(C)), _rand((C,), 18, 0.1)
+    res = _rand((B, T, C), 19)
+    y = F.conv1d(x, w1, b1).transpose(1, 2) + res
+    xo = res.to(dev).clone()
+    so = torch.empty(B, T, C, device=dev)
+    rt.op_gemm(xs.view(B * T, C), w1.squeeze(-1).contiguous().to(dev), b1.to(dev), out0=xo, out1=so, res=xo,
+               epilogue=rt.EPI_DAC, alpha=a2.to(dev), alphaC=C)
+    assert rel_err(xo, y) < 3e-6
+    assert rel_err(so, O.snake(y.transpose(1, 2), a2.view(1, C, 1)).transpose(1, 2)) < 3e-6
+
+
+@pytest.mark.parametrize("s", [2, 3, 4, 5, 8])
+def test_dac_conv_transpose(dev, s):
+    """ConvTranspose1d(k=2s, stride s, pad ceil(s/2), out_pad s%2) (dac.py:102-109) as one GEMM."""
+    B, Tin, Cin, Cout = 2, 23, 128, 64
+    x, w, b = _rand((B, Cin, Tin), 20), _rand((Cin, Cout, 2 * s), 21, 1 / math.sqrt(2 * Cin)), _rand((Cout,), 22, 0.1)
+    a = 1 + 0.2 * _rand((Cout,), 23)
+    y = F.conv_transpose1d(x, w, b, stride=s, padding=math.ceil(s / 2), output_padding=s % 2)
+    assert y.shape[-1] == Tin * s
+    X = torch.full((B, Tin * s, Cout), float("nan"), device=dev)
+    S = torch.full((B, Tin * s, Cout), float("nan"), device=dev)
+    rt.op_gemm(x.transpose(1, 2).contiguous().to(dev), packers.convT_to_gemm(w, s).to(dev), b.repeat(s).to(dev),
+               out0=X, out1=S, convT=(Tin, Cin, s, Cout), epilogue=rt.EPI_DAC, alpha=a.to(dev), alphaC=Cout)
+    assert rel_err(X, y.transpose(1, 2)) < 3e-6
+    assert rel_err(S, O.snake(y, a.view(1, Cout, 1)).transpose(1, 2)) < 3e-6
+
+
+# ----------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Sq,Skv,split,kv_bdiv", [
+    (2, 2, 58, 58, 8, 1), (4, 3, 290, 77, 40, 2), (2, 12, 250, 250, 0, 1), (1, 1, 33, 31, 5, 1)])
+def test_attention(dev, out_dtype, B, H, Sq, Skv, split, kv_bdiv):
+    q, k, v = _rand((B, H, Sq, 128), 30), _rand((B // kv_bdiv, H, Skv, 128), 31), _rand((B // kv_bdiv, H, Skv, 128), 32)
+    ke, ve = k.repeat_interleave(kv_bdiv, 0), v.repeat_interleave(kv_bdiv, 0)
+    ref = O.sdpa(q, ke, ve).transpose(1, 2).reshape(B, Sq, H * 128)
+    oa = torch.full((B, max(split, 1), H * 128), float("nan"), device=dev, dtype=out_dtype)
+    ob = torch.full((B, Sq - split, H * 128), float("nan"), device=dev, dtype=out_dtype)
+    rt.op_attention(q.to(dev), k.to(dev), v.to(dev), oa, ob, split, kv_bdiv)
+    tol = 3e-6 if out_dtype == torch.float32 else 4e-3
+    if split:
+        assert rel_err(oa.float(), ref[:, :split]) < tol
+    assert rel_err(ob.float(), ref[:, split:]) < tol
+
+
+def test_attention_spiky_scores(dev):
+    """Forces the online-softmax running max to jump between key tiles."""
+    q, k, v = _rand((1, 1, 64, 128), 33), _rand((1, 1, 200, 128), 34), _rand((1, 1, 200, 128), 35)
+    k[0, 0, 150] = q[0, 0, 7] * 5.0
+    k[0, 0, 40] = q[0, 0, 9] * 3.0
+    ref = O.sdpa(q, k, v).transpose(1, 2).reshape(1, 64, 128)
+    ob = torch.empty(1, 64, 128, device=dev)
+    rt.op_attention(q.to(dev), k.to(dev), v.to(dev), ob, ob, 0)
+    assert rel_err(ob, ref) < 3e-6
+
+
+# ----------------------------------------------------------------------------- row kernels
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("D,eps", [(1536, 1e-6), (256, 1e-5), (1408, 1e-6)])
+def test_ln_mod(dev, out_dtype, D, eps):
+    clips, L = 2, 13
+    M = 2 * clips * L
+    x = _rand((M, D), 40) * 3 + 0.5
+    tol = 2e-6 if out_dtype == torch.float32 else 4e-3
+    # plain LayerNorm
+    out = torch.empty(M, D, device=dev, dtype=out_dtype)
+    rt.op_ln_mod(x.to(dev), eps, None, None, out)
+    assert rel_err(out.float(), O.layer_norm(x, eps)) < tol
+    # vector shift/scale (triple blocks)
+    sh, sc = _rand((D,), 41), _rand((D,), 42) * 0.3
+    rt.op_ln_mod(x.to(dev), eps, rt.rowbcast(sh.to(dev)), rt.rowbcast(sc.to(dev)), out)
+    assert rel_err(out.float(), O.layer_norm(x, eps) * (1 + sc) + sh) < tol
+    # per-(cfg, token) shift/scale taken from a wider table (single blocks: chunks of [.., 6D])
+    tab = _rand((2, L, 6 * D), 43) * 0.3
+    tb = tab.to(dev)
+    rt.op_ln_mod(x.to(dev), eps, rt.rowbcast(tb[..., 3 * D:], 1, clips * L, L, ld=6 * D),
+                 rt.rowbcast(tb[..., 4 * D:], 1, clips * L, L, ld=6 * D), out)
+    e = lambda t: t[:, None].expand(2, clips, L, D).reshape(M, D)
+    ref = O.layer_norm(x, eps) * (1 + e(tab[..., 4 * D:5 * D])) + e(tab[..., 3 * D:4 * D])
+    assert rel_err(out.float(), ref) < tol
+
+
+def test_rowbcast_view_pointer(dev):
+    """rowbcast() must pass the *view's* data pointer (chunk offset inside a wider table)."""
+    t = torch.arange(24, dtype=torch.float32, device=dev).view(2, 12)
+    v = t[:, 4:8]
+    assert v.data_ptr() == t.data_ptr() + 16
+
+
+@pytest.mark.parametrize("eps", [1e-6, 1.1920928955078125e-07])
+def test_qkv_split(dev, eps):
+    """'(K H D)' split + RMSNorm + RoPE into [B, H, S, 128] at a token offset."""
+    B, L, H, Lv = 2, 11, 3, 4
+    S = L + Lv
+    qkv = _rand((B * L, 3 * H * 128), 50)
+    gq, gk = 1 + 0.1 * _rand((128,), 51), 1 + 0.1 * _rand((128,), 52)
+    pos = (2 * torch.arange(L)).to(torch.int32)
+    cos, sin = tables.rope_table(2 * L + 1)
+    q, k, v = qkv.view(B, L, 3, H, 128).unbind(2)
+    c2, s2 = cos[pos.long()].repeat_interleave(2, 1), sin[pos.long()].repeat_interleave(2, 1)
+    rq = O.apply_rope(O.rms_norm(q, gq, eps), c2, s2).transpose(1, 2)       # [B, H, L, 128]
+    rk = O.apply_rope(O.rms_norm(k, gk, eps), c2, s2).transpose(1, 2)
+    dq, dk, dv = (torch.zeros(B, H, S, 128, device=dev) for _ in range(3))
+    rt.op_qkv_split(qkv.to(dev), L, H, [gq.to(dev), gk.to(dev), None], [pos.to(dev), pos.to(dev), None],
+                    [dq, dk, dv], S, Lv, eps, cos.to(dev), sin.to(dev))
+    assert rel_err(dq[:, :, Lv:], rq) < 2e-6 and rel_err(dk[:, :, Lv:], rk) < 2e-6
+    assert torch.equal(dv[:, :, Lv:].cpu(), v.transpose(1, 2))
+    assert float(dq[:, :, :Lv].abs().max()) == 0.0
+
+
+def test_latent_rows(dev):
+    x = _rand((3, 128, 50), 60)
+    out = torch.empty(2 * 3 * 50, 128, device=dev, dtype=torch.bfloat16)
+    rt.op_latent_rows(x.to(dev), 2, out)
+    ref = x.transpose(1, 2).reshape(150, 128).to(torch.bfloat16)
+    assert torch.equal(out.cpu()[:150], ref) and torch.equal(out.cpu()[150:], ref)
+
+
+@pytest.mark.parametrize("solver", ["euler", "heun-2", "midpoint-2", "kutta-4"])
+@pytest.mark.parametrize("ncfg", [1, 2])
+def test_solver_step(dev, solver, ncfg):
+    """Device solver state machine vs the oracle's restatement of FlowMatchDiscreteScheduler.step."""
+    clips, C, L, n = 2, 128, 50, 8
+    g = 4.5
+    sig = O.flow_sigmas(n)
+    st = O.SolverState(sig, solver)
+    coef = tables.solver_table(sig, solver, n).to(dev)
+    x0 = _rand((clips, C, L), 70)
+    x = x0.to(dev).clone()
+    xs, da = torch.zeros_like(x), torch.zeros_like(x)
+    ctr = torch.zeros(1, dtype=torch.int32, device=dev)
+    rows = torch.empty(ncfg * clips * L, C, device=dev)
+    xr = x0.clone()
+    for i in range(n):
+        pred = _rand((ncfg * clips * L, C), 71 + i)
+        rt.op_solver_step(pred.to(dev), x, xs, da, ncfg, g, coef, ctr, rows)
+        p = pred.view(ncfg, clips, L, C).transpose(2, 3)
+        v = p[0] + g * (p[1] - p[0]) if ncfg == 2 else p[0]
+        xr = st.step(v, xr)
+        assert rel_err(x, xr) < 2e-6, (solver, i)
+        assert rel_err(rows.view(ncfg, clips, L, C)[-1], xr.transpose(1, 2)) < 2e-6
+    assert int(ctr.item()) == n
+
+
+def test_dac_out(dev):
+    B, T, C = 2, 300, 64
+    s, w, b = _rand((B, T, C), 80), _rand((1, C, 7), 81, 0.1), _rand((1,), 82, 0.1)
+    ref = torch.tanh(F.conv1d(s.transpose(1, 2), w, b, padding=3))
+    out = torch.empty(B, 1, T, device=dev)
+    rt.op_dac_out(s.to(dev), w[0].permute(1, 0).reshape(-1).contiguous().to(dev), b.to(dev), out)
+    assert rel_err(out, ref) < 2e-6
