@@ -251,6 +251,7 @@ def rowbcast(t: Optional[torch.Tensor], mode: int = 0, rows_per_cfg: int = 1, L:
     r.p = t.data_ptr() if t is not None else None     # views allowed: rows are addressed through `ld`
     r.ld = int(ld if ld is not None else (t.shape[-1] if t is not None else 0))
     r.mode, r.rows_per_cfg, r.L = mode, rows_per_cfg, L
+    r._keepalive = t    # the struct only carries a raw pointer: keep the tensor alive with it
     return r
 
 

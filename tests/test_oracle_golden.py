@@ -1,0 +1,111 @@
+"""Pins the CPU oracle (oracle/foley_oracle.py) against golden vectors frozen from the REFERENCE
+itself (tests/golden/*.npz, produced by tests/golden/make_golden.py in the build container).
+Runs anywhere - no GPU, no /root/reference.  G6 (xxl, ~3 min of weight synthesis) is opt-in
+(FOLEY_SLOW=1); it was checked when the fixture was generated.
+"""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import golden, rel_err
+from foley_amd.host import config as C, synth
+from oracle import foley_oracle as O
+
+torch.set_num_threads(min(8, os.cpu_count() or 1))
+
+
+def test_g1_scheduler():
+    g = golden("g1_scheduler")
+    for n in (10, 50):
+        assert torch.equal(O.flow_sigmas(n), g[f"sigmas_{n}"])
+        assert torch.equal(O.flow_timesteps(O.flow_sigmas(n)), g[f"timesteps_{n}"])
+    assert rel_err(O.flow_sigmas(10, 3.0), g["sigmas_10_shift3"]) < 1e-7
+    for solver in ("euler", "heun-2", "midpoint-2", "kutta-4"):
+        st, x = O.SolverState(O.flow_sigmas(8), solver), g["x0"]
+        for i in range(8):
+            x = st.step(g["v"][i], x)
+            assert rel_err(x, g["trace_" + solver.replace("-", "_")][i]) < 1e-7, (solver, i)
+
+
+def test_g2_rope():
+    g = golden("g2_rope")
+    for n in (77, 250):
+        cos, sin = O.rope_table(O.rope_positions(n))
+        assert torch.equal(cos, g[f"cos_{n}"]) and torch.equal(sin, g[f"sin_{n}"])
+    cos, sin = O.rope_table(O.rope_positions(6))
+    assert rel_err(O.apply_rope(g["rope_x"], cos, sin), g["rope_y"]) < 1e-7
+    for la, lv in ((250, 40), (50, 8), (1500, 240), (55, 8), (251, 40)):
+        assert torch.equal(O.interleaved_positions(la, lv)[1], g[f"pos_v_{la}_{lv}"])
+
+
+def test_g3_layers():
+    g = golden("g3_layers")
+    sd = {k: synth.synth_tensor("g3." + k, s, sc) for k, s, sc in
+          (("w1", (768, 256, 3), 0.03), ("w2", (256, 768, 3), 0.02), ("w3", (768, 256, 3), 0.03))}
+    x = g["convmlp_x"]
+    y = O.conv1d_cl(F.silu(O.conv1d_cl(x, sd["w1"], None, 1)) * O.conv1d_cl(x, sd["w3"], None, 1), sd["w2"], None, 1)
+    assert rel_err(y, g["convmlp_y"]) < 1e-6
+    assert rel_err(O.snake(g["snake_x"], g["snake_alpha"]), g["snake_y"]) < 1e-7
+    dc = C.DACConfig(decoder_dim=128, rates=(5, 2))
+    taps = {}
+    y = O.dac_decode(synth.synth_dac_state_dict(dc), g["dac52_z"], rates=(5, 2), taps=taps)
+    assert rel_err(y, g["dac52_y"]) < 1e-5 and rel_err(taps["stage0"], g["dac52_stage0"]) < 1e-5
+
+
+def test_g4_full_width_blocks():
+    g = golden("g4_blocks")
+    c = C.DiTConfig(name="xxl-1-1", depth_triple=1, depth_single=1)
+    sd = synth.synth_dit_state_dict(c)
+    taps = {}
+    with torch.inference_mode():
+        y = O.dit_forward(sd, c.heads, g["x"], g["t"], g["cond"], g["clip"], g["sync"], taps=taps)
+    assert rel_err(taps["triple0"], g["triple_audio"]) < 1e-5
+    assert rel_err(taps["single0"], g["single"]) < 1e-5
+    assert rel_err(y, g["y"]) < 1e-5
+
+
+def test_g5_tiny_forward():
+    g = golden("g5_dit_tiny")
+    sd = synth.synth_dit_state_dict(C.TINY)
+    for tag in ("a", "b"):
+        with torch.inference_mode():
+            y = O.dit_forward(sd, C.TINY.heads, *(g[f"{tag}_{k}"] for k in ("x", "t", "cond", "clip", "sync")))
+        assert rel_err(y, g[tag + "_y"]) < 1e-5
+
+
+@pytest.mark.parametrize("tag,t2a,dur,guid,bs,solver,steps", [
+    ("cfg_euler", False, 1.0, 4.5, 2, "euler", 10), ("t2a_nocfg", True, 1.0, 1.0, 1, "euler", 10),
+    ("heun", False, 1.0, 4.5, 1, "heun-2", 10), ("midpoint", False, 1.0, 4.5, 1, "midpoint-2", 10),
+    ("kutta", False, 1.0, 4.5, 1, "kutta-4", 12), ("v2a_2s", False, 2.0, 3.0, 2, "euler", 12)])
+def test_g7_sampler(tag, t2a, dur, guid, bs, solver, steps):
+    g = golden("g7_sampler")
+    sd, dsd = synth.synth_dit_state_dict(C.TINY), synth.synth_dac_state_dict(C.DAC_TINY)
+    cond = synth.synth_conditioning(C.TINY, dur, t2a=t2a, sd=sd)
+    with torch.inference_mode():
+        lat = O.sample_latents(sd, C.TINY.heads, g[tag + "_noise"], cond["text"], cond["uncond_text"], cond["clip"],
+                               cond["sync"], steps, guid, solver)
+        wav = O.dac_decode(dsd, lat)
+    assert rel_err(lat, g[tag + "_latents"]) < 1e-5
+    assert rel_err(wav[..., ::5], g[tag + "_wave_s5"]) < 3e-5
+
+
+def test_g9_dac_full_width():
+    g = golden("g9_dac")
+    with torch.inference_mode():
+        y = O.dac_decode(synth.synth_dac_state_dict(C.DAC48K), g["z"])
+    assert rel_err(y, g["y"]) < 1e-5
+
+
+@pytest.mark.slow
+def test_g6_c1_xxl():
+    g = golden("g6_c1_xxl")
+    sd = synth.synth_dit_state_dict(C.XXL)
+    cond = synth.synth_conditioning(C.XXL, 1.0, t2a=True, sd=sd)
+    trace = []
+    with torch.inference_mode():
+        lat = O.sample_latents(sd, C.XXL.heads, g["noise"], cond["text"], cond["uncond_text"], cond["clip"],
+                               cond["sync"], 10, 1.0, trace=trace)
+        wav = O.dac_decode(synth.synth_dac_state_dict(C.DAC48K), lat)
+    assert rel_err(torch.stack(trace), g["latents"]) < 1e-5 and rel_err(wav, g["waveform"]) < 3e-5
