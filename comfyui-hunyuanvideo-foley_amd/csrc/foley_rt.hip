@@ -88,9 +88,16 @@ struct foley_ctx {
   float* x_saved = nullptr;         // [clips, C, La]
   float* d_acc = nullptr;
   int* step_ctr = nullptr;
-  // graph
+  float* x_cur = nullptr;           // [clips, C, La] the sample being denoised (ctx-owned => stable address)
+  // ctx-owned copies of the plan's lookup tables (stable addresses across foley_prepare calls)
+  float *rope_cos = nullptr, *rope_sin = nullptr, *solver_coef = nullptr;
+  int *pos_audio_self = nullptr, *pos_visual_self = nullptr, *pos_linear = nullptr, *sync_gather = nullptr;
+  void *tA = nullptr, *tB = nullptr;  // precompute scratch
+  float* tF = nullptr;
+  bool have_buffers = false;        // workspace allocated for `plan`'s dimensions
+  // graph: one captured loop iteration; valid while the workspace and weights stay put
   hipGraphExec_t graph_exec = nullptr;
-  float* graph_latents = nullptr;   // latents pointer baked into the captured iteration
+  float graph_guidance = 0.f;
   // timing
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
@@ -118,6 +125,19 @@ static void ctx_free_plan(foley_ctx* c) {
   for (auto& b : c->owned) hipFree(b.p);
   c->owned.clear();
   c->prepared = false;
+  c->have_buffers = false;
+}
+
+static void ctx_drop_graph(foley_ctx* c) {
+  if (c->graph_exec) {
+    hipGraphExecDestroy(c->graph_exec);
+    c->graph_exec = nullptr;
+  }
+}
+
+static bool same_dims(const foley_plan& a, const foley_plan& b) {
+  return a.ncfg == b.ncfg && a.clips == b.clips && a.La == b.La && a.Lv == b.Lv && a.Ls == b.Ls && a.Lt == b.Lt &&
+         a.n_iter == b.n_iter && a.rope_len == b.rope_len;
 }
 
 static int grow(DevBuf& b, size_t bytes) {
@@ -215,8 +235,8 @@ extern "C" int foley_ctx_create(int device, const foley_config* cfg, foley_ctx**
   foley_ctx* c = new foley_ctx();
   c->device = device;
   c->cfg = *cfg;
-  hipEventCreate(&c->ev0);
-  hipEventCreate(&c->ev1);
+  (void)hipEventCreate(&c->ev0);
+  (void)hipEventCreate(&c->ev1);
   *out = c;
   return 0;
 }
@@ -240,6 +260,8 @@ extern "C" int foley_set_tensor(foley_ctx* c, const char* name, const void* p, i
   t.p = p;
   t.dtype = dtype;
   t.shape.assign(shape, shape + ndim);
+  auto it = c->tensors.find(name);
+  if (it != c->tensors.end() && it->second.p != p) ctx_drop_graph(c);  // captured kernels hold the old address
   c->tensors[name] = t;
   c->prepared = false;  // cached tables depend on the weights
   return 0;
@@ -265,51 +287,81 @@ extern "C" int foley_prepare(foley_ctx* c, const foley_plan* pl, void* stream_v)
     return FAIL(FOLEY_ERR_INVALID, "bad plan dimensions");
   if (pl->rope_len < 2 * pl->La) return FAIL(FOLEY_ERR_INVALID, "rope table shorter than 2*La");
   HIPTRY(hipStreamSynchronize(st));
-  ctx_free_plan(c);
-  c->plan = *pl;
+  const bool reuse = c->have_buffers && same_dims(c->plan, *pl);
+  if (!reuse) ctx_free_plan(c);
+  c->prepared = false;
 
   const int D = f.hidden, H = f.heads, C = f.latent_dim, T = f.compute_dtype;
   const size_t es = esize(T);
   const int ncfg = pl->ncfg, clips = pl->clips, La = pl->La, Lv = pl->Lv, Ls = pl->Ls, Lt = pl->Lt;
   const int Bc = ncfg * clips, M = Bc * La, Mv = Bc * Lv, S = La + Lv, NI = pl->n_iter;
   const int hidmax = f.mlp_hidden > f.conv_hidden ? f.mlp_hidden : f.conv_hidden;
+  const int Lmax = std::max(std::max(La, Lv), Lt);
+  const int rmax = std::max(std::max(NI, ncfg * Lt), std::max(ncfg * Lv, ncfg * Ls));
+  const size_t tcols = std::max(std::max(D, f.sync_hidden), 768);
 
 #define ALLOC(ptr, bytes) TRY(ctx_alloc(c, (bytes), (void**)&(ptr)))
-  ALLOC(c->vec_table, (size_t)NI * D * 4);
-  ALLOC(c->modtab, (size_t)f.depth_triple * 2 * NI * 9 * D * 4);
-  ALLOC(c->txt_k, (size_t)f.depth_triple * ncfg * H * Lt * 128 * 4);
-  ALLOC(c->txt_v, (size_t)f.depth_triple * ncfg * H * Lt * 128 * 4);
-  ALLOC(c->v_cond0, (size_t)ncfg * Lv * D * 4);
-  ALLOC(c->add_sync, (size_t)ncfg * La * D * 4);
-  ALLOC(c->xin, (size_t)M * C * es);
-  ALLOC(c->audio, (size_t)M * D * 4);
-  ALLOC(c->vcond, (size_t)Mv * D * 4);
-  ALLOC(c->xn_a, (size_t)M * D * es);
-  ALLOC(c->xn_v, (size_t)Mv * D * es);
-  ALLOC(c->qkv_a, (size_t)M * 3 * D * 4);
-  ALLOC(c->qkv_v, (size_t)Mv * 3 * D * 4);
-  ALLOC(c->Q, (size_t)Bc * H * S * 128 * 4);
-  ALLOC(c->K, (size_t)Bc * H * S * 128 * 4);
-  ALLOC(c->V, (size_t)Bc * H * S * 128 * 4);
-  ALLOC(c->att_a, (size_t)M * D * es);
-  ALLOC(c->att_v, (size_t)Mv * D * es);
-  ALLOC(c->hid_a, (size_t)M * hidmax * es);
-  ALLOC(c->hid_v, (size_t)Mv * f.mlp_hidden * es);
-  ALLOC(c->svec, (size_t)ncfg * La * D * es);
-  ALLOC(c->smod, (size_t)ncfg * La * 6 * D * 4);
-  ALLOC(c->pred, (size_t)M * C * 4);
-  ALLOC(c->x_saved, (size_t)clips * C * La * 4);
-  ALLOC(c->d_acc, (size_t)clips * C * La * 4);
-  ALLOC(c->step_ctr, 256);
+  if (!reuse) {
+    ALLOC(c->vec_table, (size_t)NI * D * 4);
+    ALLOC(c->modtab, (size_t)f.depth_triple * 2 * NI * 9 * D * 4);
+    ALLOC(c->txt_k, (size_t)f.depth_triple * ncfg * H * Lt * 128 * 4);
+    ALLOC(c->txt_v, (size_t)f.depth_triple * ncfg * H * Lt * 128 * 4);
+    ALLOC(c->v_cond0, (size_t)ncfg * Lv * D * 4);
+    ALLOC(c->add_sync, (size_t)ncfg * La * D * 4);
+    ALLOC(c->xin, (size_t)M * C * es);
+    ALLOC(c->audio, (size_t)M * D * 4);
+    ALLOC(c->vcond, (size_t)Mv * D * 4);
+    ALLOC(c->xn_a, (size_t)M * D * es);
+    ALLOC(c->xn_v, (size_t)Mv * D * es);
+    ALLOC(c->qkv_a, (size_t)M * 3 * D * 4);
+    ALLOC(c->qkv_v, (size_t)Mv * 3 * D * 4);
+    ALLOC(c->Q, (size_t)Bc * H * S * 128 * 4);
+    ALLOC(c->K, (size_t)Bc * H * S * 128 * 4);
+    ALLOC(c->V, (size_t)Bc * H * S * 128 * 4);
+    ALLOC(c->att_a, (size_t)M * D * es);
+    ALLOC(c->att_v, (size_t)Mv * D * es);
+    ALLOC(c->hid_a, (size_t)M * hidmax * es);
+    ALLOC(c->hid_v, (size_t)Mv * f.mlp_hidden * es);
+    ALLOC(c->svec, (size_t)ncfg * La * D * es);
+    ALLOC(c->smod, (size_t)ncfg * La * 6 * D * 4);
+    ALLOC(c->pred, (size_t)M * C * 4);
+    ALLOC(c->x_saved, (size_t)clips * C * La * 4);
+    ALLOC(c->d_acc, (size_t)clips * C * La * 4);
+    ALLOC(c->x_cur, (size_t)clips * C * La * 4);
+    ALLOC(c->step_ctr, 256);
+    ALLOC(c->rope_cos, (size_t)pl->rope_len * 64 * 4);
+    ALLOC(c->rope_sin, (size_t)pl->rope_len * 64 * 4);
+    ALLOC(c->solver_coef, (size_t)NI * 8 * 4);
+    ALLOC(c->pos_audio_self, (size_t)La * 4);
+    ALLOC(c->pos_visual_self, (size_t)Lv * 4);
+    ALLOC(c->pos_linear, (size_t)Lmax * 4);
+    ALLOC(c->sync_gather, (size_t)La * 4);
+    // scratch of the precompute
+    ALLOC(c->tA, (size_t)rmax * tcols * es);
+    ALLOC(c->tB, (size_t)rmax * tcols * es);
+    ALLOC(c->tF, (size_t)rmax * 2 * D * 4);
+    c->have_buffers = true;
+  }
+  if (c->graph_exec && c->graph_guidance != pl->guidance) ctx_drop_graph(c);
+  // the plan's lookup tables are copied so that captured kernels keep valid addresses
+  const foley_plan in = *pl;
+  c->plan = in;
+#define COPYTAB(field, bytes) \
+  HIPTRY(hipMemcpyAsync((void*)c->field, in.field, (bytes), hipMemcpyDeviceToDevice, st)); \
+  c->plan.field = c->field
+  COPYTAB(rope_cos, (size_t)in.rope_len * 64 * 4);
+  COPYTAB(rope_sin, (size_t)in.rope_len * 64 * 4);
+  COPYTAB(solver_coef, (size_t)NI * 8 * 4);
+  COPYTAB(pos_audio_self, (size_t)La * 4);
+  COPYTAB(pos_visual_self, (size_t)Lv * 4);
+  COPYTAB(pos_linear, (size_t)Lmax * 4);
+  COPYTAB(sync_gather, (size_t)La * 4);
+#undef COPYTAB
+  pl = &c->plan;
   HIPTRY(hipMemsetAsync(c->step_ctr, 0, 256, st));
-
-  // scratch for the precompute (freed with the plan; small)
-  const int rmax = std::max(std::max(NI, ncfg * Lt), std::max(ncfg * Lv, ncfg * Ls));
-  void *tA, *tB;
-  float* tF;
-  ALLOC(tA, (size_t)rmax * std::max(std::max(D, f.sync_hidden), 768) * es);
-  ALLOC(tB, (size_t)rmax * std::max(std::max(D, f.sync_hidden), 768) * es);
-  ALLOC(tF, (size_t)rmax * 2 * D * 4);
+  void* tA = c->tA;
+  void* tB = c->tB;
+  float* tF = c->tF;
 
   // 1. time embedding table: t_feat -> Linear -> SiLU -> Linear   (embed_layers.py:104-136)
   Lin time0, time2;
@@ -564,11 +616,11 @@ extern "C" int foley_dit_forward(foley_ctx* c, const float* latents, int iter, f
 }
 
 // --------------------------------------------------------------------------- sampler loop
-static int run_iteration(foley_ctx* c, float* latents, hipStream_t st) {
+static int run_iteration(foley_ctx* c, hipStream_t st) {
   const foley_plan& pl = c->plan;
   TRY(run_forward(c, st));
   StepArgs s{};
-  s.pred = c->pred; s.x = latents; s.x_saved = c->x_saved; s.d_acc = c->d_acc;
+  s.pred = c->pred; s.x = c->x_cur; s.x_saved = c->x_saved; s.d_acc = c->d_acc;
   s.clips = pl.clips; s.C = c->cfg.latent_dim; s.L = pl.La; s.ncfg = pl.ncfg;
   s.guidance = pl.guidance; s.coef = pl.solver_coef; s.step_ptr = c->step_ctr;
   s.rows_out = c->xin; s.rows_dtype = c->cfg.compute_dtype;
@@ -582,50 +634,43 @@ extern "C" int foley_sample(foley_ctx* c, float* latents, int use_graph, foley_p
   hipStream_t st = (hipStream_t)stream_v;
   HIPTRY(hipSetDevice(c->device));
   const foley_plan& pl = c->plan;
+  const size_t xbytes = (size_t)pl.clips * c->cfg.latent_dim * pl.La * 4;
+  if (use_graph && !c->graph_exec) {
+    // Every per-iteration value is read from device memory (step counter, tables) and every
+    // buffer is context-owned, so ONE captured iteration replays for the whole loop and for
+    // later runs of the same shape.
+    hipStream_t cs;
+    HIPTRY(hipStreamSynchronize(st));
+    HIPTRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+    int rc = 0;
+    if (e == hipSuccess) {
+      rc = run_iteration(c, cs);
+      hipError_t e2 = hipStreamEndCapture(cs, &graph);
+      if (e == hipSuccess) e = e2;
+    }
+    if (e == hipSuccess && rc == 0) e = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipStreamDestroy(cs);
+    if (rc != 0) return rc;
+    if (e != hipSuccess) return FAIL(FOLEY_ERR_HIP, hipGetErrorString(e));
+    c->graph_guidance = pl.guidance;
+  }
   HIPTRY(hipEventRecord(c->ev0, st));
+  HIPTRY(hipMemcpyAsync(c->x_cur, latents, xbytes, hipMemcpyDeviceToDevice, st));
   HIPTRY(hipMemsetAsync(c->step_ctr, 0, sizeof(int), st));
-  TRY(launch_latent_rows(latents, pl.clips, c->cfg.latent_dim, pl.La, pl.ncfg, c->xin, c->cfg.compute_dtype, st));
-  if (use_graph) {
-    if (c->graph_exec && c->graph_latents != latents) {
-      hipGraphExecDestroy(c->graph_exec);
-      c->graph_exec = nullptr;
-    }
-    if (!c->graph_exec) {
-      c->graph_latents = latents;
-      // every per-iteration value is read from device memory (step counter), so one captured
-      // iteration replays for the whole loop
-      hipStream_t cs;
-      HIPTRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-      hipGraph_t graph = nullptr;
+  TRY(launch_latent_rows(c->x_cur, pl.clips, c->cfg.latent_dim, pl.La, pl.ncfg, c->xin, c->cfg.compute_dtype, st));
+  for (int it = 0; it < pl.n_iter; ++it) {
+    if (use_graph) HIPTRY(hipGraphLaunch(c->graph_exec, st));
+    else TRY(run_iteration(c, st));
+    if (cb) {
+      HIPTRY(hipMemcpyAsync(latents, c->x_cur, xbytes, hipMemcpyDeviceToDevice, st));
       HIPTRY(hipStreamSynchronize(st));
-      hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
-      int rc = 0;
-      if (e == hipSuccess) {
-        rc = run_iteration(c, latents, cs);
-        e = hipStreamEndCapture(cs, &graph);
-      }
-      if (e == hipSuccess && rc == 0) e = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
-      if (graph) hipGraphDestroy(graph);
-      hipStreamDestroy(cs);
-      if (rc != 0) return rc;
-      if (e != hipSuccess) return FAIL(FOLEY_ERR_HIP, hipGetErrorString(e));
-    }
-    for (int it = 0; it < pl.n_iter; ++it) {
-      HIPTRY(hipGraphLaunch(c->graph_exec, st));
-      if (cb) {
-        HIPTRY(hipStreamSynchronize(st));
-        cb(it + 1, pl.n_iter, user);
-      }
-    }
-  } else {
-    for (int it = 0; it < pl.n_iter; ++it) {
-      TRY(run_iteration(c, latents, st));
-      if (cb) {
-        HIPTRY(hipStreamSynchronize(st));
-        cb(it + 1, pl.n_iter, user);
-      }
+      cb(it + 1, pl.n_iter, user);
     }
   }
+  HIPTRY(hipMemcpyAsync(latents, c->x_cur, xbytes, hipMemcpyDeviceToDevice, st));
   HIPTRY(hipEventRecord(c->ev1, st));
   c->timed = true;
   return 0;

@@ -72,8 +72,9 @@ XL = DiTConfig(name="xl", depth_triple=12, depth_single=24, hidden=1408, heads=1
 # small configuration used by fast tests; head_dim stays 128 like the real models
 TINY = DiTConfig(name="tiny", depth_triple=2, depth_single=2, hidden=256, heads=2)
 DAC48K = DACConfig()
-# narrow decoder for fast tests (same topology: 5 stages, same rates)
-DAC_TINY = DACConfig(decoder_dim=256)
+# narrow decoder for fast tests (same topology: 5 stages, same rates); the last stage keeps 32
+# channels = one 128-byte fp32 K-slice, the engine's minimum tap width
+DAC_TINY = DACConfig(decoder_dim=1024)
 
 _BY_NAME = {"xxl": XXL, "xl": XL, "tiny": TINY}
 

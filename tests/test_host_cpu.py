@@ -120,9 +120,9 @@ def test_pack_dit_and_arena_roundtrip():
 def test_pack_dac_shapes():
     dc = C.DAC_TINY
     p = packers.pack_dac(synth.synth_dac_state_dict(dc), dc)
-    assert p["dac.in.w"].shape == (256, 7 * 128) and p["dac.0.up.w"].shape == (8 * 128, 2 * 256)
-    assert p["dac.0.up.b"].shape == (8 * 128,) and p["dac.4.2.c1.w"].shape == (8, 8)
-    assert p["dac.out.w"].shape == (7 * 8,) and p["dac.out.alpha"].shape == (8,)
+    assert p["dac.in.w"].shape == (1024, 7 * 128) and p["dac.0.up.w"].shape == (8 * 512, 2 * 1024)
+    assert p["dac.0.up.b"].shape == (8 * 512,) and p["dac.4.2.c1.w"].shape == (32, 32)
+    assert p["dac.out.w"].shape == (7 * 32,) and p["dac.out.alpha"].shape == (32,)
 
 
 # ----------------------------------------------------------------------------- tables
