@@ -1,0 +1,44 @@
+"""Profiling driver: a few loop iterations + one DAC decode of the C2 workload (xxl, 5 s, CFG),
+meant to be wrapped by `rocprofv3 --kernel-trace --stats -- python tools/profile_run.py`."""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+load_package()
+from foley_amd.host import config as C, packers, sampler, synth  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--iters", type=int, default=4)
+ap.add_argument("--bs", type=int, default=1)
+ap.add_argument("--precision", default="bf16")
+ap.add_argument("--model", default="xxl")
+ap.add_argument("--graph", action="store_true")
+ap.add_argument("--no-dac", action="store_true")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+cfg = C.dit_config(a.model)
+dtype = packers.torch_dtype(a.precision)
+sd = synth.synth_dit_state_dict(cfg, device=dev)
+cond = synth.synth_conditioning(cfg, 5.0, t2a=True, sd=sd, device=dev)
+model = sampler.FoleyModel(cfg, sd, dtype, dev)
+del sd
+dac = sampler.FoleyDAC(synth.synth_dac_state_dict(C.DAC48K, device=dev), dev)
+model.attach_dac(dac)
+plan = sampler.build_plan(model, {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]},
+                          {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]}, 250, 4.5, a.iters,
+                          a.bs, "euler")
+model.ctx.prepare(plan)
+lat = torch.randn(a.bs, 128, 250, device=dev)
+model.ctx.sample(lat, use_graph=a.graph)
+torch.cuda.synchronize()
+print("loop ms/iter:", model.ctx.last_elapsed_ms() / a.iters)
+if not a.no_dac:
+    model.ctx.dac_decode(lat)
+    torch.cuda.synchronize()
+    print("dac ms:", model.ctx.last_elapsed_ms())
