@@ -6,6 +6,7 @@
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;  // 16-byte staging register (native vector: stays in VGPRs)
 typedef uint16_t bf16_t;  // storage type for bf16 in global/LDS memory
 
 // ---- dtype codes shared with include/foley_hip.h -------------------------------------------

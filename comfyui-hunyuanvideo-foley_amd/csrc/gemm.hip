@@ -3,10 +3,11 @@
 // One workgroup = 4 wavefronts (256 lanes) computes a BM x BN output tile with 32x32 MFMA
 // fragments: v_mfma_f32_32x32x2_f32 for fp32 operands (exact fp32 FMA chain - the parity mode)
 // and v_mfma_f32_32x32x16_bf16 for bf16 operands, both accumulating in fp32.  Operand tiles are
-// 128-byte K-slices (32 fp32 / 64 bf16) staged through LDS with a 144-byte row pitch, which makes
-// the ds_read_b128 fragment reads bank-conflict free (MI355X_MICROARCH.md, LDS table).  Global
-// loads of tile k+1 are issued into registers before the MFMA block of tile k (register-prefetch
-// pipeline).  Workgroup ids are remapped so tiles that share a weight panel run on one XCD (L2).
+// 128-byte K-slices (32 fp32 / 64 bf16) staged through a double-buffered LDS tile with a 144-byte
+// row pitch, which makes the ds_read_b128 fragment reads bank-conflict free (MI355X_MICROARCH.md,
+// LDS table).  A ring of NS register stages keeps NS-1 K-slices of global loads in flight behind
+// the MFMA block (one barrier per slice).  Workgroup ids are remapped so tiles that share a
+// weight panel run on one XCD (L2).
 #include "kernels.h"
 
 namespace {
@@ -27,19 +28,19 @@ __device__ __forceinline__ float act_epi(float v, int epi) {
   return v;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int EPI>
+template <typename T, int BM, int BN, int WM, int WN, int NS, int EPI>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
   constexpr int NT = WM * WN * 64;
-  static_assert(NT == 256, "tile loader assumes 256 threads");
   constexpr int EPC = Frag<T>::EPC;
   constexpr int BK = 8 * EPC;
+  constexpr int RPP = NT / 8;  // rows covered by one loader pass (8 lanes x 16 B per row)
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
-  constexpr int RA = BM / 32, RB = BN / 32;
+  constexpr int RA = BM / RPP, RB = BN / RPP;
+  constexpr int STAGE = (BM + BN) * LDS_PITCH;
+  static_assert(BM % RPP == 0 && BN % RPP == 0 && TM % 32 == 0 && TN % 32 == 0, "bad tile");
   static_assert(EPI != EPI_SILUGATE_T || (FN % 2 == 0), "gated epilogue needs fragment pairs");
 
-  __shared__ __attribute__((aligned(16))) unsigned char lds[(BM + BN) * LDS_PITCH];
-  unsigned char* As = lds;
-  unsigned char* Bs = lds + BM * LDS_PITCH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 stages (double buffer)
 
   const int tiles_m = (g.M + BM - 1) / BM;
   const int tiles_n = (g.N + BN - 1) / BN;
@@ -56,51 +57,32 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
   const int wm = wave / WN, wn = wave % WN;
   const int chunk = tid & 7, lrow = tid >> 3;
 
-  long a_base[RA];
+  // Per-thread row descriptors.  Loads are ALWAYS issued (from a clamped, in-bounds address) and
+  // masked with a register select when they are written to LDS: a load under a branch would make
+  // the compiler wait for each one separately.
+  const T* ap[RA];
   int a_q[RA];
   bool a_ok[RA];
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
-    const int r = m0 + lrow + i * 32;
+    const int r = m0 + lrow + i * RPP;
     a_ok[i] = r < g.M;
     const int rr = a_ok[i] ? r : 0;
     const int b = rr / g.segV, q = rr - b * g.segV;
-    a_base[i] = ((long)b * g.segS + q) * g.lda;
+    ap[i] = (const T*)g.A + ((long)b * g.segS + q) * g.lda + chunk * EPC;
     a_q[i] = q;
   }
-  long w_off[RB];
+  const T* wp[RB];
   bool w_ok[RB];
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
-    const int n = n0 + lrow + i * 32;
+    const int n = n0 + lrow + i * RPP;
     w_ok[i] = n < g.N;
-    w_off[i] = (long)(w_ok[i] ? n : 0) * g.K;
+    wp[i] = (const T*)g.W + (long)(w_ok[i] ? n : 0) * g.K + chunk * EPC;
   }
 
-  const T* __restrict__ Ag = (const T*)g.A;
-  const T* __restrict__ Wg = (const T*)g.W;
-  uint4 ra[RA], rw[RB];
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
-
-  auto gload = [&](int kt) {
-    const int k0 = kt * BK;
-    const int tap = k0 / g.tapC;
-    const int c0 = k0 - tap * g.tapC;
-    const int toff = g.tap0 + tap * g.dil;
-#pragma unroll
-    for (int i = 0; i < RA; ++i) {
-      const int st = a_q[i] + toff;
-      const bool v = a_ok[i] && st >= 0 && st < g.segS;
-      const T* p = Ag + a_base[i] + (long)toff * g.lda + c0 + chunk * EPC;
-      ra[i] = v ? *(const uint4*)p : zero4;
-    }
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      const T* p = Wg + w_off[i] + k0 + chunk * EPC;
-      rw[i] = w_ok[i] ? *(const uint4*)p : zero4;
-    }
-  };
-
+  u32x4 ra[NS][RA], rw[NS][RB];  // register ring: NS-1 K-slices in flight
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
   f32x16 acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
@@ -111,63 +93,102 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
 
   const int fi = lane & 31, kh = lane >> 5;
   const int nk = g.K / BK;
-  gload(0);
-  for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < RA; ++i) *(uint4*)(As + (lrow + i * 32) * LDS_PITCH + chunk * 16) = ra[i];
-#pragma unroll
-    for (int i = 0; i < RB; ++i) *(uint4*)(Bs + (lrow + i * 32) * LDS_PITCH + chunk * 16) = rw[i];
-    __syncthreads();
-    if (kt + 1 < nk) gload(kt + 1);
+  const bool plain_a = g.taps == 1;
 
-    if constexpr (sizeof(T) == 4) {
-      // lane (fi, kh) owns k = kh*16 .. kh*16+15 of its row; MFMA step j contracts the k pair
-      // (j, 16 + j) - any pairing is valid as long as A and B use the same one.
-      float a[FM][16], b[FN][16];
+#define FOLEY_GLOAD(slot, kt)                                                              \
+  {                                                                                        \
+    const int k0_ = (kt)*BK;                                                               \
+    int c0_ = k0_, toff_ = 0;                                                              \
+    if (!plain_a) {                                                                        \
+      const int tap_ = k0_ / g.tapC;                                                       \
+      c0_ = k0_ - tap_ * g.tapC;                                                           \
+      toff_ = g.tap0 + tap_ * g.dil;                                                       \
+    }                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                       \
+      const int st_ = a_q[i] + toff_;                                                      \
+      const long off_ = (st_ >= 0 && st_ < g.segS) ? (long)toff_ * g.lda : 0;              \
+      ra[slot][i] = *(const u32x4*)(ap[i] + off_ + c0_);                                   \
+    }                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < RB; ++i) rw[slot][i] = *(const u32x4*)(wp[i] + k0_); \
+  }
+
 #pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        const unsigned char* p = As + (wm * TM + i * 32 + fi) * LDS_PITCH + kh * 64;
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nk) FOLEY_GLOAD(s, s);
+
+  for (int kt0 = 0; kt0 < nk; kt0 += NS) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const f32x4 v = *(const f32x4*)(p + c * 16);
-          a[i][c * 4 + 0] = v[0]; a[i][c * 4 + 1] = v[1]; a[i][c * 4 + 2] = v[2]; a[i][c * 4 + 3] = v[3];
+    for (int j = 0; j < NS; ++j) {
+      const int kt = kt0 + j;
+      if (kt < nk) {
+        if (kt + NS - 1 < nk) FOLEY_GLOAD((j + NS - 1) % NS, kt + NS - 1);
+        unsigned char* As = lds + (kt & 1) * STAGE;
+        unsigned char* Bs = As + BM * LDS_PITCH;
+        int toff = 0;
+        if (!plain_a) toff = g.tap0 + ((kt * BK) / g.tapC) * g.dil;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+          const int st = a_q[i] + toff;
+          const bool v = a_ok[i] && st >= 0 && st < g.segS;
+          *(u32x4*)(As + (lrow + i * RPP) * LDS_PITCH + chunk * 16) = v ? ra[j][i] : zero4;
         }
-      }
 #pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const unsigned char* p = Bs + (wn * TN + j * 32 + fi) * LDS_PITCH + kh * 64;
+        for (int i = 0; i < RB; ++i)
+          *(u32x4*)(Bs + (lrow + i * RPP) * LDS_PITCH + chunk * 16) = w_ok[i] ? rw[j][i] : zero4;
+        // one barrier per K-slice: the stage written now was last read two slices ago, and every
+        // wave has passed the previous barrier since
+        __syncthreads();
+
+        if constexpr (sizeof(T) == 4) {
+          // lane (fi, kh) owns k = kh*16 .. kh*16+15 of its row; MFMA step s contracts the k pair
+          // (s, 16 + s) - any pairing is valid as long as A and B use the same one.
+          float a[FM][16], b[FN][16];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const f32x4 v = *(const f32x4*)(p + c * 16);
-          b[j][c * 4 + 0] = v[0]; b[j][c * 4 + 1] = v[1]; b[j][c * 4 + 2] = v[2]; b[j][c * 4 + 3] = v[3];
+          for (int i = 0; i < FM; ++i) {
+            const unsigned char* p = As + (wm * TM + i * 32 + fi) * LDS_PITCH + kh * 64;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const f32x4 v = *(const f32x4*)(p + c * 16);
+              a[i][c * 4 + 0] = v[0]; a[i][c * 4 + 1] = v[1]; a[i][c * 4 + 2] = v[2]; a[i][c * 4 + 3] = v[3];
+            }
+          }
+#pragma unroll
+          for (int jj = 0; jj < FN; ++jj) {
+            const unsigned char* p = Bs + (wn * TN + jj * 32 + fi) * LDS_PITCH + kh * 64;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const f32x4 v = *(const f32x4*)(p + c * 16);
+              b[jj][c * 4 + 0] = v[0]; b[jj][c * 4 + 1] = v[1]; b[jj][c * 4 + 2] = v[2]; b[jj][c * 4 + 3] = v[3];
+            }
+          }
+#pragma unroll
+          for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+              for (int jj = 0; jj < FN; ++jj)
+                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[jj][s], acc[i][jj], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            bf16x8 a[FM], b[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+              a[i] = *(const bf16x8*)(As + (wm * TM + i * 32 + fi) * LDS_PITCH + s * 32 + kh * 16);
+#pragma unroll
+            for (int jj = 0; jj < FN; ++jj)
+              b[jj] = *(const bf16x8*)(Bs + (wn * TN + jj * 32 + fi) * LDS_PITCH + s * 32 + kh * 16);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+              for (int jj = 0; jj < FN; ++jj)
+                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[jj], acc[i][jj], 0, 0, 0);
+          }
         }
-      }
-#pragma unroll
-      for (int s = 0; s < 16; ++s)
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int j = 0; j < FN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
-    } else {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        bf16x8 a[FM], b[FN];
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-          a[i] = *(const bf16x8*)(As + (wm * TM + i * 32 + fi) * LDS_PITCH + s * 32 + kh * 16);
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-          b[j] = *(const bf16x8*)(Bs + (wn * TN + j * 32 + fi) * LDS_PITCH + s * 32 + kh * 16);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int j = 0; j < FN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
       }
     }
   }
+#undef FOLEY_GLOAD
 
   // ------------------------------------------------------------------ epilogue
   // C/D layout of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
@@ -241,41 +262,41 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
   }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
-int launch_tile(const GemmArgs& g, int epi, hipStream_t st) {
+template <typename T, int BM, int BN, int WM, int WN, int NS, int EPI>
+int launch_one(const GemmArgs& g, hipStream_t st) {
   const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-  dim3 grid(tiles), block(WM * WN * 64);
-#define FOLEY_CASE(E)                                                                        \
-  case E:                                                                                    \
-    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, E>), grid, block, 0, st, g);          \
-    break;
-  switch (epi) {
-    FOLEY_CASE(EPI_STORE_F32)
-    FOLEY_CASE(EPI_STORE_T)
-    FOLEY_CASE(EPI_SILU_T)
-    FOLEY_CASE(EPI_GELU_T)
-    FOLEY_CASE(EPI_GATE_RES)
-    case EPI_SILUGATE_T:
-      if constexpr ((BN / WN) % 64 == 0) {
-        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, EPI_SILUGATE_T>), grid, block, 0, st, g);
-      } else {
-        return foley_set_err("gated epilogue needs a 64-wide wave tile", __FILE__, __LINE__);
-      }
-      break;
-    case EPI_DAC:
-      if constexpr (sizeof(T) == 4) {
-        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, EPI_DAC>), grid, block, 0, st, g);
-      } else {
-        return foley_set_err("DAC epilogue is fp32 only", __FILE__, __LINE__);
-      }
-      break;
-    default:
-      return foley_set_err("unknown GEMM epilogue", __FILE__, __LINE__);
+  constexpr size_t lds = 2 * (size_t)(BM + BN) * LDS_PITCH;
+  auto k = gemm_kernel<T, BM, BN, WM, WN, NS, EPI>;
+  if (lds > 64 * 1024) {
+    static bool raised = false;   // per instantiation
+    if (!raised) {
+      hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);
+      raised = true;
+    }
   }
-#undef FOLEY_CASE
+  hipLaunchKernelGGL(k, dim3(tiles), dim3(WM * WN * 64), lds, st, g);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);
   return 0;
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int NS>
+int launch_tile(const GemmArgs& g, int epi, hipStream_t st) {
+  switch (epi) {
+    case EPI_STORE_F32: return launch_one<T, BM, BN, WM, WN, NS, EPI_STORE_F32>(g, st);
+    case EPI_STORE_T: return launch_one<T, BM, BN, WM, WN, NS, EPI_STORE_T>(g, st);
+    case EPI_SILU_T: return launch_one<T, BM, BN, WM, WN, NS, EPI_SILU_T>(g, st);
+    case EPI_GELU_T: return launch_one<T, BM, BN, WM, WN, NS, EPI_GELU_T>(g, st);
+    case EPI_GATE_RES: return launch_one<T, BM, BN, WM, WN, NS, EPI_GATE_RES>(g, st);
+    case EPI_SILUGATE_T:
+      if constexpr ((BN / WN) % 64 == 0) return launch_one<T, BM, BN, WM, WN, NS, EPI_SILUGATE_T>(g, st);
+      else return foley_set_err("gated epilogue needs a 64-wide wave tile", __FILE__, __LINE__);
+    case EPI_DAC:
+      if constexpr (sizeof(T) == 4) return launch_one<T, BM, BN, WM, WN, NS, EPI_DAC>(g, st);
+      else return foley_set_err("DAC epilogue is fp32 only", __FILE__, __LINE__);
+  }
+  return foley_set_err("unknown GEMM epilogue", __FILE__, __LINE__);
 }
 
 template <typename T>
@@ -286,18 +307,22 @@ int launch_typed(const GemmArgs& g, int epi, int tile, hipStream_t st) {
   if (((uintptr_t)g.A | (uintptr_t)g.W) & 15)
     return foley_set_err("GEMM: operands must be 16-byte aligned", __FILE__, __LINE__);
   if (tile == 0) {
-    // pick the largest tile that still yields >= ~3/4 of a wave of workgroups over 256 CUs
+    // Tile choice for 256 CUs (measured on the M=500 / M=4000 shapes of the xxl DiT,
+    // tools/gemm_bench.py): the 128x128 / 8-wave tile wins whenever it fills the chip without a
+    // ragged last wave of workgroups; otherwise many small 64x64 tiles hide latency better.
     auto nblk = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn); };
+    const long b128 = nblk(128, 128);
+    const long rem = b128 % 256;
     if (g.N <= 64 && epi != EPI_SILUGATE_T) tile = nblk(128, 64) >= 192 ? 4 : 3;
-    else if (nblk(128, 128) >= 192) tile = 1;
-    else if (nblk(64, 128) >= 192 || epi == EPI_SILUGATE_T) tile = 2;
+    else if (b128 >= 100 && (b128 <= 256 || rem == 0 || rem >= 128 || b128 >= 2048)) tile = 1;
+    else if (epi == EPI_SILUGATE_T) tile = nblk(64, 128) >= 192 ? 2 : 1;
     else tile = 3;
   }
   switch (tile) {
-    case 1: return launch_tile<T, 128, 128, 2, 2>(g, epi, st);
-    case 2: return launch_tile<T, 64, 128, 2, 2>(g, epi, st);
-    case 3: return launch_tile<T, 64, 64, 2, 2>(g, epi, st);
-    case 4: return launch_tile<T, 128, 64, 4, 1>(g, epi, st);
+    case 1: return launch_tile<T, 128, 128, 4, 2, 4>(g, epi, st);
+    case 2: return launch_tile<T, 64, 128, 2, 2, 3>(g, epi, st);
+    case 3: return launch_tile<T, 64, 64, 2, 2, 4>(g, epi, st);
+    case 4: return launch_tile<T, 128, 64, 4, 1, 3>(g, epi, st);
   }
   return foley_set_err("GEMM: bad tile id", __FILE__, __LINE__);
 }
@@ -306,6 +331,11 @@ int launch_typed(const GemmArgs& g, int epi, int tile, hipStream_t st) {
 
 int launch_gemm(const GemmArgs& g, int dtype, int epi, int tile, hipStream_t st) {
   if (g.M <= 0 || g.N <= 0) return 0;
+  if (tile >= 100) {
+    if (dtype != FOLEY_BF16 || epi != EPI_STORE_F32 || g.taps != 1)
+      return foley_set_err("experimental GEMM variants: bf16 plain store only", __FILE__, __LINE__);
+    return launch_gemm_exp(g, tile, st);
+  }
   if (dtype == FOLEY_F32) return launch_typed<float>(g, epi, tile, st);
   if (dtype == FOLEY_BF16) return launch_typed<bf16_t>(g, epi, tile, st);
   return foley_set_err("GEMM: unsupported operand dtype", __FILE__, __LINE__);

@@ -46,6 +46,8 @@ struct GemmArgs {
 
 // dtype: FOLEY_F32 or FOLEY_BF16 operands (accumulation is always fp32). tile: 0 = auto.
 int launch_gemm(const GemmArgs& g, int dtype, int epi, int tile, hipStream_t st);
+// experimental mainloop variants (bf16, plain fp32 store), tile codes >= 100 - see gemm_exp.hip
+int launch_gemm_exp(const GemmArgs& g, int code, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // Attention: O = softmax(Q K^T / sqrt(128)) V, no mask.  Q [Bq, H, Sq, 128], K/V [Bkv, H, Skv, 128]

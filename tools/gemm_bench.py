@@ -1,0 +1,62 @@
+"""GEMM micro-benchmark on the C2 (bs=1 -> M=500) and bs=8 (M=4000) shapes of the xxl DiT.
+Weights rotate through enough copies to defeat the 256 MB Infinity Cache (in the real loop every
+weight matrix is streamed from HBM once per iteration).  HIP-event timed, median of `--reps`."""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+load_package()
+from foley_amd.host import runtime as rt  # noqa: E402
+
+SHAPES = {  # name: (N, K) ; M given by --m
+    "qkv": (4608, 1536), "proj": (1536, 1536), "mod6": (9216, 1536), "fc1": (6144, 1536), "fc2": (1536, 6144),
+    "lin1": (1536, 4608), "w13": (8192, 4608), "w2": (1536, 12288),
+}
+ap = argparse.ArgumentParser()
+ap.add_argument("--m", type=int, default=500)
+ap.add_argument("--tiles", default="1,2,3")
+ap.add_argument("--shapes", default=",".join(SHAPES))
+ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--check", action="store_true")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+tiles = [int(t) for t in a.tiles.split(",")]
+print(f"M={a.m} dtype={a.dtype}")
+for name in a.shapes.split(","):
+    N, K = SHAPES[name]
+    ncopy = max(2, int(600e6 // (N * K * (2 if dt == torch.bfloat16 else 4))) + 1)
+    Ws = [(torch.randn(N, K, device=dev) / K ** 0.5).to(dt) for _ in range(ncopy)]
+    A = torch.randn(a.m, K, device=dev).to(dt)
+    out = torch.empty(a.m, N, device=dev)
+    ref = None
+    if a.check:
+        ref = (A.float() @ Ws[0].float().t())
+    line = f"{name:5s} N={N:5d} K={K:5d} |"
+    for t in tiles:
+        try:
+            rt.op_gemm(A, Ws[0], None, out0=out, tile=t)
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            line += f" t{t}: ERR({str(e)[-40:]})"
+            continue
+        err = ""
+        if ref is not None:
+            err = f" e={float((out - ref).norm() / ref.norm()):.0e}"
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.reps)]
+        for i, (e0, e1) in enumerate(evs):
+            e0.record()
+            rt.op_gemm(A, Ws[i % ncopy], None, out0=out, tile=t)
+            e1.record()
+        torch.cuda.synchronize()
+        ts = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+        us = ts[len(ts) // 2] * 1e3
+        line += f" t{t}:{us:7.1f}us {2 * a.m * N * K / us / 1e6:6.0f}TF{err} |"
+    print(line, flush=True)
