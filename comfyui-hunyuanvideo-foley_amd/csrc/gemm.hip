@@ -93,44 +93,50 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
 
   const int fi = lane & 31, kh = lane >> 5;
   const int nk = g.K / BK;
-  const bool plain_a = g.taps == 1;
+  // Loader / LDS-writer cursors over the K axis, advanced incrementally (no per-slice division):
+  // channel offset inside the current tap, the tap's source-row offset, and that offset in elements.
+  const long tap_step = (long)g.dil * g.lda;
+  int ld_k0 = 0, ld_c0 = 0, ld_toff = g.tap0;
+  long ld_roff = (long)g.tap0 * g.lda;
+  int wr_c0 = 0, wr_toff = g.tap0;
 
-#define FOLEY_GLOAD(slot, kt)                                                              \
+#define FOLEY_GLOAD(slot)                                                                  \
   {                                                                                        \
-    const int k0_ = (kt)*BK;                                                               \
-    int c0_ = k0_, toff_ = 0;                                                              \
-    if (!plain_a) {                                                                        \
-      const int tap_ = k0_ / g.tapC;                                                       \
-      c0_ = k0_ - tap_ * g.tapC;                                                           \
-      toff_ = g.tap0 + tap_ * g.dil;                                                       \
-    }                                                                                      \
     _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                       \
-      const int st_ = a_q[i] + toff_;                                                      \
-      const long off_ = (st_ >= 0 && st_ < g.segS) ? (long)toff_ * g.lda : 0;              \
-      ra[slot][i] = *(const u32x4*)(ap[i] + off_ + c0_);                                   \
+      const bool in_ = (unsigned)(a_q[i] + ld_toff) < (unsigned)g.segS;                    \
+      ra[slot][i] = *(const u32x4*)(ap[i] + (in_ ? ld_roff : 0L) + ld_c0);                 \
     }                                                                                      \
-    _Pragma("unroll") for (int i = 0; i < RB; ++i) rw[slot][i] = *(const u32x4*)(wp[i] + k0_); \
+    _Pragma("unroll") for (int i = 0; i < RB; ++i) rw[slot][i] = *(const u32x4*)(wp[i] + ld_k0); \
+    ld_k0 += BK;                                                                           \
+    ld_c0 += BK;                                                                           \
+    if (ld_c0 >= g.tapC) {                                                                 \
+      ld_c0 = 0;                                                                           \
+      ld_toff += g.dil;                                                                    \
+      ld_roff += tap_step;                                                                 \
+    }                                                                                      \
   }
 
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
-    if (s < nk) FOLEY_GLOAD(s, s);
+    if (s < nk) FOLEY_GLOAD(s);
 
   for (int kt0 = 0; kt0 < nk; kt0 += NS) {
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
       const int kt = kt0 + j;
       if (kt < nk) {
-        if (kt + NS - 1 < nk) FOLEY_GLOAD((j + NS - 1) % NS, kt + NS - 1);
+        if (kt + NS - 1 < nk) FOLEY_GLOAD((j + NS - 1) % NS);
         unsigned char* As = lds + (kt & 1) * STAGE;
         unsigned char* Bs = As + BM * LDS_PITCH;
-        int toff = 0;
-        if (!plain_a) toff = g.tap0 + ((kt * BK) / g.tapC) * g.dil;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-          const int st = a_q[i] + toff;
-          const bool v = a_ok[i] && st >= 0 && st < g.segS;
+          const bool v = a_ok[i] && (unsigned)(a_q[i] + wr_toff) < (unsigned)g.segS;
           *(u32x4*)(As + (lrow + i * RPP) * LDS_PITCH + chunk * 16) = v ? ra[j][i] : zero4;
+        }
+        wr_c0 += BK;
+        if (wr_c0 >= g.tapC) {
+          wr_c0 = 0;
+          wr_toff += g.dil;
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i)
