@@ -20,9 +20,9 @@ __global__ __launch_bounds__(64) void attn_kernel(const AttnArgs a) {
   const int q0 = blockIdx.x * 32;
   const int h = blockIdx.y, b = blockIdx.z;
   const int bk = b / a.kv_bdiv;
-  const float* __restrict__ Q = a.q + ((long)(b * a.H + h) * a.Sq) * HD;
-  const float* __restrict__ K = a.k + ((long)(bk * a.H + h) * a.Skv) * HD;
-  const float* __restrict__ V = a.v + ((long)(bk * a.H + h) * a.Skv) * HD;
+  const float* __restrict__ Q = (const float*)a.q + ((long)(b * a.H + h) * a.Sq) * HD;
+  const float* __restrict__ K = (const float*)a.k + ((long)(bk * a.H + h) * a.Skv) * HD;
+  const float* __restrict__ V = (const float*)a.v + ((long)(bk * a.H + h) * a.Skv) * HD;
   const float scale = 0.08838834764831845f;  // 1/sqrt(128)
 
   // B operand of S^T = K Q^T: lane (j, kh) holds Q[q0 + j][kh*64 .. kh*64+63]
@@ -114,11 +114,154 @@ __global__ __launch_bounds__(64) void attn_kernel(const AttnArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 throughput variant: Q, K [B,H,S,128] bf16 and V *transposed* [B,H,128,vt_pitch] bf16 (written
+// that way by the head-split kernel), v_mfma_f32_32x32x16_bf16, fp32 softmax/accumulate.
+// A workgroup = 4 waves sharing one 32-query block; each wave walks a quarter of the key tiles and
+// the four partial (m, l, O) triples are merged through LDS (flash-decoding style), which gives
+// 4x the waves of the fp32 kernel on these short sequences (S <= 3480, typically 250-290).
+// Key rows are fed to the first MFMA in a permuted order (pi) chosen so that each lane's 16
+// scores belong to 16 CONSECUTIVE keys: the exponentiated scores then form, in place, the
+// key-contiguous B operand of the second MFMA, and V^T rows are plain 16-byte loads.
+template <typename OutT>
+__global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
+  __shared__ float sO[4][3][16][64];  // partial O of the d-fragments a wave does not finalise itself
+  __shared__ float sM[4][32], sL[4][32];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int j = lane & 31, kh = lane >> 5;
+  const int q0 = blockIdx.x * 32;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int bk = b / a.kv_bdiv;
+  const bf16_t* __restrict__ Q = (const bf16_t*)a.q + ((long)(b * a.H + h) * a.Sq) * HD;
+  const bf16_t* __restrict__ K = (const bf16_t*)a.k + ((long)(bk * a.H + h) * a.Skv) * HD;
+  const bf16_t* __restrict__ VT = (const bf16_t*)a.v + ((long)(bk * a.H + h) * HD) * a.vt_pitch;
+  const float scale = 0.08838834764831845f;
+
+  bf16x8 qf[8];
+  {
+    const bf16_t* p = Q + (long)min(q0 + j, a.Sq - 1) * HD + 8 * kh;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) qf[s] = *(const bf16x8*)(p + 16 * s);
+  }
+  f32x16 o[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int nt = (a.Skv + 31) >> 5;
+  const int t0 = (nt * w) >> 2, t1 = (nt * (w + 1)) >> 2;
+  const int pi = 16 * ((j >> 2) & 1) + (j & 3) + 4 * (j >> 3);  // A-row j carries key kt + pi
+  for (int t = t0; t < t1; ++t) {
+    const int kt = t * 32;
+    f32x16 s;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+    {
+      const bf16_t* p = K + (long)min(kt + pi, a.Skv - 1) * HD + 8 * kh;
+#pragma unroll
+      for (int st = 0; st < 8; ++st)
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(p + 16 * st), qf[st], s, 0, 0, 0);
+    }
+    // s[e] = score(key kt + 16*kh + e, query q0 + j)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      s[e] = (kt + 16 * kh + e < a.Skv) ? s[e] * scale : -INFINITY;
+      mx = fmaxf(mx, s[e]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = expf(m_run - m_new);
+    float ps = 0.f;
+    bf16x8 pb[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float pv = expf(s[e] - m_new);
+      ps += pv;
+      pb[e >> 3][e & 7] = (__bf16)pv;
+    }
+    ps += __shfl_xor(ps, 32, 64);
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const bf16x8 vf = *(const bf16x8*)(VT + (long)(d * 32 + j) * a.vt_pitch + kt + 16 * kh + 8 * u);
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[u], o[d], 0, 0, 0);
+      }
+  }
+
+  // merge the four key ranges: wave w finalises d-fragment w
+  if (kh == 0) {
+    sM[w][j] = m_run;
+    sL[w][j] = l_run;
+  }
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    if (d == w) continue;
+    const int slot = d < w ? d : d - 1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sO[w][slot][e][lane] = o[d][e];
+  }
+  __syncthreads();
+  float mstar = -INFINITY;
+#pragma unroll
+  for (int x = 0; x < 4; ++x) mstar = fmaxf(mstar, sM[x][j]);
+  float wt[4], L = 0.f;
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    wt[x] = expf(sM[x][j] - mstar);
+    L += wt[x] * sL[x][j];
+  }
+  const int tok = q0 + j;
+  if (tok >= a.Sq) return;
+  const float inv = 1.0f / L;
+  OutT* dst;
+  if (tok < a.split) dst = (OutT*)a.outA + ((long)b * a.split + tok) * (a.H * HD);
+  else dst = (OutT*)a.outB + ((long)b * (a.Sq - a.split) + (tok - a.split)) * (a.H * HD);
+  dst += h * HD + w * 32;
+  const int slot_mine = 0;  // unused for own fragment
+  (void)slot_mine;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    float acc = 0.f;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      float v;
+      if (x == w) {
+        // own fragment is still in registers; select it without dynamic register indexing
+        v = w == 0 ? o[0][e] : (w == 1 ? o[1][e] : (w == 2 ? o[2][e] : o[3][e]));
+      } else {
+        const int slot = w < x ? w : w - 1;
+        v = sO[x][slot][e][lane];
+      }
+      acc += wt[x] * v;
+    }
+    dst[(e & 3) + 8 * (e >> 2) + 4 * kh] = Cvt<OutT>::to(acc * inv);
+  }
+}
+
 }  // namespace
 
 int launch_attention(const AttnArgs& a, int out_dtype, hipStream_t st) {
   if (a.Sq <= 0 || a.Skv <= 0) return foley_set_err("attention: empty sequence", __FILE__, __LINE__);
   dim3 grid((a.Sq + 31) / 32, a.H, a.Bq), block(64);
+  if (a.in_dtype == FOLEY_BF16) {
+    if (a.vt_pitch < ((a.Skv + 31) & ~31) || (a.vt_pitch & 7))
+      return foley_set_err("attention: V^T pitch must cover Skv rounded up to 32 (multiple of 8)", __FILE__, __LINE__);
+    if (out_dtype == FOLEY_BF16) hipLaunchKernelGGL(attn_bf16_kernel<bf16_t>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(attn_bf16_kernel<float>, grid, dim3(256), 0, st, a);
+    hipError_t e2 = hipGetLastError();
+    if (e2 != hipSuccess) return foley_set_err(hipGetErrorString(e2), __FILE__, __LINE__);
+    return 0;
+  }
   if (out_dtype == FOLEY_F32) hipLaunchKernelGGL(attn_kernel<float>, grid, block, 0, st, a);
   else if (out_dtype == FOLEY_BF16) hipLaunchKernelGGL(attn_kernel<bf16_t>, grid, block, 0, st, a);
   else return foley_set_err("attention: bad output dtype", __FILE__, __LINE__);

@@ -62,8 +62,8 @@ struct foley_ctx {
   // prepared tables
   float* vec_table = nullptr;       // [n_iter, D]
   float* modtab = nullptr;          // [n_triple][2][n_iter][9D]
-  float* txt_k = nullptr;           // [n_triple][ncfg, H, Lt, 128]
-  float* txt_v = nullptr;
+  void* txt_k = nullptr;            // [n_triple][ncfg, H, Lt, 128]     (same dtype rule as Q/K/V)
+  void* txt_v = nullptr;            // [n_triple][ncfg, H, Lt, 128] or transposed [.., 128, ceil32(Lt)]
   float* v_cond0 = nullptr;         // [ncfg, Lv, D]
   float* add_sync = nullptr;        // [ncfg, La, D]
   int* ident_idx = nullptr;         // 0..max(Lv,La)-1
@@ -75,9 +75,9 @@ struct foley_ctx {
   void* xn_v = nullptr;             // T [Mv, D]
   float* qkv_a = nullptr;           // [M, 3D]
   float* qkv_v = nullptr;           // [Mv, 3D]
-  float* Q = nullptr;               // [Bc, H, S, 128]
-  float* K = nullptr;
-  float* V = nullptr;
+  void* Q = nullptr;                // [Bc, H, S, 128]   fp32 (parity mode) or bf16
+  void* K = nullptr;
+  void* V = nullptr;                // fp32 [Bc, H, S, 128] or bf16 transposed [Bc, H, 128, ceil32(S)]
   void* att_a = nullptr;            // T [M, D]
   void* att_v = nullptr;            // T [Mv, D]
   void* hid_a = nullptr;            // T [M, max(mlp_hidden, conv_hidden)]
@@ -304,8 +304,9 @@ extern "C" int foley_prepare(foley_ctx* c, const foley_plan* pl, void* stream_v)
   if (!reuse) {
     ALLOC(c->vec_table, (size_t)NI * D * 4);
     ALLOC(c->modtab, (size_t)f.depth_triple * 2 * NI * 9 * D * 4);
-    ALLOC(c->txt_k, (size_t)f.depth_triple * ncfg * H * Lt * 128 * 4);
-    ALLOC(c->txt_v, (size_t)f.depth_triple * ncfg * H * Lt * 128 * 4);
+    ALLOC(c->txt_k, (size_t)f.depth_triple * ncfg * H * Lt * 128 * es);
+    ALLOC(c->txt_v, (size_t)f.depth_triple * ncfg * H * ((Lt + 31) & ~31) * 128 * es);
+    HIPTRY(hipMemsetAsync(c->txt_v, 0, (size_t)f.depth_triple * ncfg * H * ((Lt + 31) & ~31) * 128 * es, st));
     ALLOC(c->v_cond0, (size_t)ncfg * Lv * D * 4);
     ALLOC(c->add_sync, (size_t)ncfg * La * D * 4);
     ALLOC(c->xin, (size_t)M * C * es);
@@ -315,9 +316,10 @@ extern "C" int foley_prepare(foley_ctx* c, const foley_plan* pl, void* stream_v)
     ALLOC(c->xn_v, (size_t)Mv * D * es);
     ALLOC(c->qkv_a, (size_t)M * 3 * D * 4);
     ALLOC(c->qkv_v, (size_t)Mv * 3 * D * 4);
-    ALLOC(c->Q, (size_t)Bc * H * S * 128 * 4);
-    ALLOC(c->K, (size_t)Bc * H * S * 128 * 4);
-    ALLOC(c->V, (size_t)Bc * H * S * 128 * 4);
+    ALLOC(c->Q, (size_t)Bc * H * S * 128 * es);
+    ALLOC(c->K, (size_t)Bc * H * S * 128 * es);
+    ALLOC(c->V, (size_t)Bc * H * ((S + 31) & ~31) * 128 * es);
+    HIPTRY(hipMemsetAsync(c->V, 0, (size_t)Bc * H * ((S + 31) & ~31) * 128 * es, st));  // V^T pad stays finite
     ALLOC(c->att_a, (size_t)M * D * es);
     ALLOC(c->att_v, (size_t)Mv * D * es);
     ALLOC(c->hid_a, (size_t)M * hidmax * es);
@@ -398,8 +400,10 @@ extern "C" int foley_prepare(foley_ctx* c, const foley_plan* pl, void* stream_v)
       QkvSplitArgs q{};
       q.qkv = tF; q.M = ncfg * Lt; q.L = Lt; q.H = H; q.nK = 2;
       q.gain[0] = (const float*)kn; q.pos[0] = pl->pos_linear;
-      q.dst[0] = c->txt_k + (size_t)b * ncfg * H * Lt * 128;
-      q.dst[1] = c->txt_v + (size_t)b * ncfg * H * Lt * 128;
+      const int Ltp = (Lt + 31) & ~31;
+      q.dst[0] = (char*)c->txt_k + (size_t)b * ncfg * H * Lt * 128 * es;
+      q.dst[1] = (char*)c->txt_v + (size_t)b * ncfg * H * (T == FOLEY_BF16 ? Ltp : Lt) * 128 * es;
+      q.out_dtype = T; q.vt_pitch = T == FOLEY_BF16 ? Ltp : 0;
       q.S_tot = Lt; q.tok_off = 0; q.eps = 1e-6f; q.cos_tab = pl->rope_cos; q.sin_tab = pl->rope_sin;
       TRY(launch_qkv_split(q, st));
     }
@@ -448,6 +452,9 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
   const int D = f.hidden, H = f.heads, C = f.latent_dim, T = f.compute_dtype;
   const int ncfg = pl.ncfg, clips = pl.clips, La = pl.La, Lv = pl.Lv, Lt = pl.Lt, NI = pl.n_iter;
   const int Bc = ncfg * clips, M = Bc * La, Mv = Bc * Lv, S = La + Lv;
+  const bool bf = T == FOLEY_BF16;
+  const size_t es = esize(T);
+  const int Sp = (S + 31) & ~31, Lap = (La + 31) & ~31;  // V^T row pitches (bf16 attention)
   const int* sp = c->step_ctr;
 
   // audio_embedder (conv k=1 == linear over the transposed latents) + add_sync (hifi_foley.py:768, 838-839)
@@ -487,11 +494,12 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
       q.gain[0] = (const float*)qn; q.gain[1] = (const float*)kn;
       q.pos[0] = z.pos; q.pos[1] = z.pos;
       q.dst[0] = c->Q; q.dst[1] = c->K; q.dst[2] = c->V;
+      q.out_dtype = T; q.vt_pitch = bf ? Sp : 0;
       q.S_tot = S; q.tok_off = z.tok_off; q.eps = 1e-6f; q.cos_tab = pl.rope_cos; q.sin_tab = pl.rope_sin;
       TRY(launch_qkv_split(q, st));
     }
     {
-      AttnArgs a{c->Q, c->K, c->V, Bc, H, S, S, 1, c->att_v, c->att_a, Lv};
+      AttnArgs a{c->Q, c->K, c->V, Bc, H, S, S, 1, c->att_v, c->att_a, Lv, T, bf ? Sp : 0};
       TRY(launch_attention(a, T, st));
     }
     for (int s = 0; s < 2; ++s) {
@@ -514,12 +522,16 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
       QkvSplitArgs q{};
       q.qkv = z.qkv; q.M = z.rows; q.L = z.L; q.H = H; q.nK = 1;
       q.gain[0] = (const float*)qn; q.pos[0] = pl.pos_linear; q.dst[0] = c->Q;
+      q.out_dtype = T; q.vt_pitch = 0;
       q.S_tot = S; q.tok_off = z.tok_off; q.eps = 1e-6f; q.cos_tab = pl.rope_cos; q.sin_tab = pl.rope_sin;
       TRY(launch_qkv_split(q, st));
     }
     {
-      const size_t off = (size_t)blk * ncfg * H * Lt * 128;
-      AttnArgs a{c->Q, c->txt_k + off, c->txt_v + off, Bc, H, S, Lt, clips, c->att_v, c->att_a, Lv};
+      const int Ltp = (Lt + 31) & ~31;
+      const size_t offk = (size_t)blk * ncfg * H * Lt * 128 * es;
+      const size_t offv = (size_t)blk * ncfg * H * (bf ? Ltp : Lt) * 128 * es;
+      AttnArgs a{c->Q, (char*)c->txt_k + offk, (char*)c->txt_v + offv, Bc, H, S, Lt, clips, c->att_v, c->att_a, Lv,
+                 T, bf ? Ltp : 0};
       TRY(launch_attention(a, T, st));
     }
     for (int s = 0; s < 2; ++s) {
@@ -568,11 +580,12 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
     q.gain[0] = (const float*)qn; q.gain[1] = (const float*)kn;
     q.pos[0] = pl.pos_linear; q.pos[1] = pl.pos_linear;
     q.dst[0] = c->Q; q.dst[1] = c->K; q.dst[2] = c->V;
+    q.out_dtype = T; q.vt_pitch = bf ? Lap : 0;
     q.S_tot = La; q.tok_off = 0; q.eps = 1.1920928955078125e-07f;  // nn.RMSNorm(eps=None) -> finfo(fp32).eps
     q.cos_tab = pl.rope_cos; q.sin_tab = pl.rope_sin;
     TRY(launch_qkv_split(q, st));
     {
-      AttnArgs a{c->Q, c->K, c->V, Bc, H, La, La, 1, c->att_a, c->att_a, 0};
+      AttnArgs a{c->Q, c->K, c->V, Bc, H, La, La, 1, c->att_a, c->att_a, 0, T, bf ? Lap : 0};
       TRY(launch_attention(a, T, st));
     }
     {
@@ -794,9 +807,10 @@ extern "C" int foley_op_gemm(const foley_gemm_desc* d, void* stream) {
   return launch_gemm(g, d->dtype, d->epilogue, d->tile, (hipStream_t)stream);
 }
 
-extern "C" int foley_op_attention(const float* q, const float* k, const float* v, int Bq, int H, int Sq, int Skv,
-                                  int kv_bdiv, void* outA, void* outB, int split, int out_dtype, void* stream) {
-  AttnArgs a{q, k, v, Bq, H, Sq, Skv, kv_bdiv > 0 ? kv_bdiv : 1, outA, outB, split};
+extern "C" int foley_op_attention(const void* q, const void* k, const void* v, int in_dtype, int vt_pitch, int Bq,
+                                  int H, int Sq, int Skv, int kv_bdiv, void* outA, void* outB, int split,
+                                  int out_dtype, void* stream) {
+  AttnArgs a{q, k, v, Bq, H, Sq, Skv, kv_bdiv > 0 ? kv_bdiv : 1, outA, outB, split, in_dtype, vt_pitch};
   return launch_attention(a, out_dtype, (hipStream_t)stream);
 }
 
@@ -806,8 +820,9 @@ extern "C" int foley_op_ln_mod(const float* x, int M, int D, float eps, const fo
 }
 
 extern "C" int foley_op_qkv_split(const float* qkv, int M, int L, int H, int nK, const float* const* gain,
-                                  const int32_t* const* pos, float* const* dst, int S_tot, int tok_off, float eps,
-                                  const float* cos_tab, const float* sin_tab, void* stream) {
+                                  const int32_t* const* pos, void* const* dst, int out_dtype, int vt_pitch,
+                                  int S_tot, int tok_off, float eps, const float* cos_tab, const float* sin_tab,
+                                  void* stream) {
   if (nK < 1 || nK > 3) return FAIL(FOLEY_ERR_INVALID, "nK must be 1..3");
   QkvSplitArgs a{};
   a.qkv = qkv; a.M = M; a.L = L; a.H = H; a.nK = nK;
@@ -816,6 +831,7 @@ extern "C" int foley_op_qkv_split(const float* qkv, int M, int L, int H, int nK,
     a.pos[i] = pos ? pos[i] : nullptr;
     a.dst[i] = dst[i];
   }
+  a.out_dtype = out_dtype; a.vt_pitch = vt_pitch;
   a.S_tot = S_tot; a.tok_off = tok_off; a.eps = eps; a.cos_tab = cos_tab; a.sin_tab = sin_tab;
   return launch_qkv_split(a, (hipStream_t)stream);
 }

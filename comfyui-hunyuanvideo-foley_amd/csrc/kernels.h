@@ -55,14 +55,18 @@ int launch_gemm_exp(const GemmArgs& g, int code, hipStream_t st);
 // dtype `out_dtype`; tokens [0, split) go to outA (clip-major rows of `split` tokens), the rest
 // to outB.
 // ---------------------------------------------------------------------------------------------
+// in_dtype FOLEY_BF16 selects the throughput kernel: Q/K bf16 [B,H,S,128], V transposed bf16
+// [B,H,128,vt_pitch] (vt_pitch >= Skv rounded up to 32; the pad must hold finite values).
 struct AttnArgs {
-  const float* q;
-  const float* k;
-  const float* v;
+  const void* q;
+  const void* k;
+  const void* v;
   int Bq, H, Sq, Skv, kv_bdiv;
   void* outA;
   void* outB;
   int split;
+  int in_dtype;
+  int vt_pitch;
 };
 int launch_attention(const AttnArgs& a, int out_dtype, hipStream_t st);
 
@@ -78,8 +82,10 @@ struct QkvSplitArgs {
   int M, L, H, nK;   // rows ordered [clip][l], L tokens per clip
   const float* gain[3];  // RMSNorm gain per operand, null => copy only
   const int* pos[3];     // RoPE position per token l, null => no rotation
-  float* dst[3];         // [clips, H, S_tot, 128]
+  void* dst[3];          // [clips, H, S_tot, 128] (out_dtype); see vt_pitch for the last operand
   int S_tot, tok_off;
+  int out_dtype;         // FOLEY_F32 or FOLEY_BF16
+  int vt_pitch;          // > 0: the LAST operand (V) is stored transposed [clips, H, 128, vt_pitch]
   float eps;
   const float* cos_tab;  // [P, 64]
   const float* sin_tab;

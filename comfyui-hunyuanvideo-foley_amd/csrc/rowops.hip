@@ -14,6 +14,21 @@ namespace {
 // ------------------------------------------------------------------ LayerNorm (+ AdaLN modulate)
 // reference: nn.LayerNorm(elementwise_affine=False) + modulate() (modulate_layers.py:19-30) and
 // SingleStreamBlock's norm*(1+scale)+shift (hifi_foley.py:368,387)
+template <typename OutT> struct Pack4;
+template <> struct Pack4<float> {
+  static __device__ __forceinline__ void store(float* p, const f32x4 v) { *(f32x4*)p = v; }
+};
+template <> struct Pack4<bf16_t> {
+  static __device__ __forceinline__ void store(bf16_t* p, const f32x4 v) {
+    uint2 w;
+    w.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+    w.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    *(uint2*)p = w;
+  }
+};
+
+// One wave per row; every global load of the row (x, shift, scale) is issued before the first
+// reduction so the kernel pays one memory round trip, results leave as 8/16-byte vector stores.
 template <typename OutT, int MAXV>
 __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x, int M, int D, float eps,
                                                      RowBcast shift, RowBcast scale, OutT* __restrict__ out) {
@@ -22,44 +37,42 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x
   if (row >= M) return;
   const int nv = D >> 2;  // float4 per row
   const f32x4* xr = (const f32x4*)(x + (long)row * D);
-  f32x4 v[MAXV];
-  float s = 0.f;
+  const f32x4* sh = shift.p ? (const f32x4*)rb_row(shift, row) : nullptr;
+  const f32x4* sc = scale.p ? (const f32x4*)rb_row(scale, row) : nullptr;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 v[MAXV], hv[MAXV], cv[MAXV];
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int c = lane + i * 64;
-    if (c < nv) {
-      v[i] = xr[c];
-      s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-    }
+    const int c = min(lane + i * 64, nv - 1);  // clamped: loads stay unconditional
+    v[i] = xr[c];
+    hv[i] = sh ? sh[c] : z4;
+    cv[i] = sc ? sc[c] : z4;
   }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+    if (lane + i * 64 < nv) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
   const float mean = wave_sum(s) / (float)D;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int c = lane + i * 64;
-    if (c < nv) {
+  for (int i = 0; i < MAXV; ++i)
+    if (lane + i * 64 < nv) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const float d = v[i][u] - mean;
         q += d * d;
       }
     }
-  }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
-  const float* sh = shift.p ? rb_row(shift, row) : nullptr;
-  const float* sc = scale.p ? rb_row(scale, row) : nullptr;
   OutT* orow = out + (long)row * D;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = lane + i * 64;
     if (c < nv) {
+      f32x4 y;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        float y = (v[i][u] - mean) * rstd;
-        if (sc) y = y * (1.0f + sc[c * 4 + u]);
-        if (sh) y = y + sh[c * 4 + u];
-        orow[c * 4 + u] = Cvt<OutT>::to(y);
-      }
+      for (int u = 0; u < 4; ++u) y[u] = (v[i][u] - mean) * rstd * (1.0f + cv[i][u]) + hv[i][u];
+      Pack4<OutT>::store(orow + c * 4, y);
     }
   }
 }
@@ -68,6 +81,7 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x
 // reference: rearrange "(K H D)", RMSNorm (norm_layers.py:36-52 / nn.RMSNorm), apply_rotary_emb
 // (attn_layers.py:112-146).  One wave per (row, head, operand); lane owns the rotation pair
 // (2*lane, 2*lane+1).
+template <typename OutT>
 __global__ __launch_bounds__(256) void qkv_split_kernel(const QkvSplitArgs a) {
   const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -93,9 +107,16 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const QkvSplitArgs a) {
     x0 = y0;
     x1 = y1;
   }
-  float* dst = a.dst[w] + (((long)b * a.H + h) * a.S_tot + a.tok_off + l) * 128 + 2 * lane;
-  dst[0] = x0;
-  dst[1] = x1;
+  if (a.vt_pitch > 0 && w == a.nK - 1) {
+    // V^T [clip, H, 128, vt_pitch]: the attention kernel wants key-contiguous rows per channel
+    OutT* dst = (OutT*)a.dst[w] + (((long)b * a.H + h) * 128 + 2 * lane) * a.vt_pitch + a.tok_off + l;
+    dst[0] = Cvt<OutT>::to(x0);
+    dst[a.vt_pitch] = Cvt<OutT>::to(x1);
+  } else {
+    OutT* dst = (OutT*)a.dst[w] + (((long)b * a.H + h) * a.S_tot + a.tok_off + l) * 128 + 2 * lane;
+    dst[0] = Cvt<OutT>::to(x0);
+    dst[1] = Cvt<OutT>::to(x1);
+  }
 }
 
 // ------------------------------------------------------------------ small elementwise helpers
@@ -286,7 +307,10 @@ int launch_ln_mod(const float* x, int M, int D, float eps, const RowBcast& shift
 
 int launch_qkv_split(const QkvSplitArgs& a, hipStream_t st) {
   const long waves = (long)a.M * a.H * a.nK;
-  hipLaunchKernelGGL(qkv_split_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
+  if (a.out_dtype == FOLEY_BF16)
+    hipLaunchKernelGGL(qkv_split_kernel<bf16_t>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(qkv_split_kernel<float>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
   FOLEY_LAUNCH_CHECK();
   return 0;
 }

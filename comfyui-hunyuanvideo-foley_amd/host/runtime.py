@@ -76,13 +76,13 @@ _SIGNATURES = {
     "foley_dac_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "foley_last_elapsed_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "foley_op_gemm": (C.c_int, [C.POINTER(GemmDescC), C.c_void_p]),
-    "foley_op_attention": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+    "foley_op_attention": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                                                         C.c_void_p]),
     "foley_op_ln_mod": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.POINTER(RowBcastC),
                                   C.POINTER(RowBcastC), C.c_void_p, C.c_int, C.c_void_p]),
     "foley_op_qkv_split": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
-                                     C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_float,
-                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+                                     C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "foley_op_solver_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_void_p, C.c_void_p,
                                                                           C.c_void_p, C.c_int, C.c_void_p]),
     "foley_op_latent_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
@@ -294,11 +294,13 @@ def op_gemm(A, W, bias=None, *, M=None, epilogue=EPI_STORE_F32, out0=None, out1=
 
 
 def op_attention(q, k, v, outA, outB, split: int, kv_bdiv: int = 1):
+    """fp32 q/k/v [B,H,S,128], or bf16 q/k [B,H,S,128] with v transposed [B,H,128,pitch]."""
     lib = load_library()
     Bq, H, Sq, _ = q.shape
     Skv = k.shape[2]
-    _check(lib, lib.foley_op_attention(_ptr(q), _ptr(k), _ptr(v), Bq, H, Sq, Skv, kv_bdiv, _ptr(outA), _ptr(outB),
-                                       split, dt_of(outB), _stream()), "foley_op_attention")
+    vt_pitch = v.shape[3] if q.dtype == torch.bfloat16 else 0
+    _check(lib, lib.foley_op_attention(_ptr(q), _ptr(k), _ptr(v), dt_of(q), vt_pitch, Bq, H, Sq, Skv, kv_bdiv,
+                                       _ptr(outA), _ptr(outB), split, dt_of(outB), _stream()), "foley_op_attention")
 
 
 def op_ln_mod(x, eps, shift: Optional[RowBcastC], scale: Optional[RowBcastC], out):
@@ -309,13 +311,15 @@ def op_ln_mod(x, eps, shift: Optional[RowBcastC], scale: Optional[RowBcastC], ou
            "foley_op_ln_mod")
 
 
-def op_qkv_split(qkv, L, H, gains: Sequence, poss: Sequence, dsts: Sequence, S_tot, tok_off, eps, cos, sin):
+def op_qkv_split(qkv, L, H, gains: Sequence, poss: Sequence, dsts: Sequence, S_tot, tok_off, eps, cos, sin,
+                 vt_pitch: int = 0):
     lib = load_library()
     nK = len(dsts)
     M = qkv.shape[0]
     arr = lambda xs: (C.c_void_p * nK)(*[(_ptr(x) if x is not None else None) for x in xs])
-    _check(lib, lib.foley_op_qkv_split(_ptr(qkv), M, L, H, nK, arr(gains), arr(poss), arr(dsts), S_tot, tok_off,
-                                       eps, _ptr(cos), _ptr(sin), _stream()), "foley_op_qkv_split")
+    _check(lib, lib.foley_op_qkv_split(_ptr(qkv), M, L, H, nK, arr(gains), arr(poss), arr(dsts), dt_of(dsts[0]),
+                                       vt_pitch, S_tot, tok_off, eps, _ptr(cos), _ptr(sin), _stream()),
+           "foley_op_qkv_split")
 
 
 def op_solver_step(pred, x, x_saved, d_acc, ncfg, guidance, coef, step_ptr, rows_out):

@@ -135,13 +135,17 @@ typedef struct foley_gemm_desc {
 } foley_gemm_desc;
 
 int foley_op_gemm(const foley_gemm_desc* d, void* stream);
-int foley_op_attention(const float* q, const float* k, const float* v, int Bq, int H, int Sq, int Skv,
-                       int kv_bdiv, void* outA, void* outB, int split, int out_dtype, void* stream);
+/* in_dtype f32: q,k,v [B,H,S,128] fp32 (exact fp32 MFMA).  in_dtype bf16: q,k bf16 [B,H,S,128] and v
+ * TRANSPOSED bf16 [B,H,128,vt_pitch], vt_pitch >= Skv rounded up to 32 with a finite pad. */
+int foley_op_attention(const void* q, const void* k, const void* v, int in_dtype, int vt_pitch, int Bq, int H,
+                       int Sq, int Skv, int kv_bdiv, void* outA, void* outB, int split, int out_dtype,
+                       void* stream);
 int foley_op_ln_mod(const float* x, int M, int D, float eps, const foley_rowbcast* shift,
                     const foley_rowbcast* scale, void* out, int out_dtype, void* stream);
+/* vt_pitch > 0: the last operand is written transposed [clips, H, 128, vt_pitch] (see above). */
 int foley_op_qkv_split(const float* qkv, int M, int L, int H, int nK, const float* const* gain,
-                       const int32_t* const* pos, float* const* dst, int S_tot, int tok_off, float eps,
-                       const float* cos_tab, const float* sin_tab, void* stream);
+                       const int32_t* const* pos, void* const* dst, int out_dtype, int vt_pitch, int S_tot,
+                       int tok_off, float eps, const float* cos_tab, const float* sin_tab, void* stream);
 int foley_op_solver_step(const float* pred, float* x, float* x_saved, float* d_acc, int clips, int C, int L,
                          int ncfg, float guidance, const float* coef, int32_t* step_ptr, void* rows_out,
                          int rows_dtype, void* stream);

@@ -171,6 +171,38 @@ def test_attention(dev, out_dtype, B, H, Sq, Skv, split, kv_bdiv):
     assert rel_err(ob.float(), ref[:, split:]) < tol
 
 
+@pytest.mark.parametrize("B,H,Sq,Skv,split,kv_bdiv", [
+    (2, 2, 58, 58, 8, 1), (4, 3, 290, 77, 40, 2), (2, 12, 250, 250, 0, 1), (1, 1, 33, 31, 5, 1), (1, 2, 100, 1500, 0, 1)])
+def test_attention_bf16(dev, B, H, Sq, Skv, split, kv_bdiv):
+    """Throughput kernel: bf16 Q/K, transposed bf16 V with a padded pitch, 4-wave key split."""
+    q, k, v = _rand((B, H, Sq, 128), 30), _rand((B // kv_bdiv, H, Skv, 128), 31), _rand((B // kv_bdiv, H, Skv, 128), 32)
+    qb, kb, vb = (t.to(torch.bfloat16) for t in (q, k, v))
+    ke, ve = kb.float().repeat_interleave(kv_bdiv, 0), vb.float().repeat_interleave(kv_bdiv, 0)
+    ref = O.sdpa(qb.float(), ke, ve).transpose(1, 2).reshape(B, Sq, H * 128)
+    pitch = (Skv + 31) // 32 * 32
+    vt = torch.full((B // kv_bdiv, H, 128, pitch), 7.0, dtype=torch.bfloat16)       # finite garbage in the pad
+    vt[..., :Skv] = vb.transpose(2, 3)
+    oa = torch.full((B, max(split, 1), H * 128), float("nan"), device=dev, dtype=torch.bfloat16)
+    ob = torch.full((B, Sq - split, H * 128), float("nan"), device=dev, dtype=torch.bfloat16)
+    rt.op_attention(qb.to(dev), kb.to(dev), vt.to(dev), oa, ob, split, kv_bdiv)
+    if split:
+        assert rel_err(oa.float(), ref[:, :split]) < 1e-2
+    assert rel_err(ob.float(), ref[:, split:]) < 1e-2
+
+
+def test_attention_bf16_spiky(dev):
+    q, k, v = _rand((1, 1, 64, 128), 33), _rand((1, 1, 200, 128), 34), _rand((1, 1, 200, 128), 35)
+    k[0, 0, 150] = q[0, 0, 7] * 5.0
+    k[0, 0, 40] = q[0, 0, 9] * 3.0
+    qb, kb, vb = (t.to(torch.bfloat16) for t in (q, k, v))
+    ref = O.sdpa(qb.float(), kb.float(), vb.float()).transpose(1, 2).reshape(1, 64, 128)
+    vt = torch.zeros(1, 1, 128, 224, dtype=torch.bfloat16)
+    vt[..., :200] = vb.transpose(2, 3)
+    ob = torch.empty(1, 64, 128, device=dev, dtype=torch.bfloat16)
+    rt.op_attention(qb.to(dev), kb.to(dev), vt.to(dev), ob, ob, 0)
+    assert rel_err(ob.float(), ref) < 1e-2
+
+
 def test_attention_spiky_scores(dev):
     """Forces the online-softmax running max to jump between key tiles."""
     q, k, v = _rand((1, 1, 64, 128), 33), _rand((1, 1, 200, 128), 34), _rand((1, 1, 200, 128), 35)
@@ -234,6 +266,26 @@ def test_qkv_split(dev, eps):
     assert rel_err(dq[:, :, Lv:], rq) < 2e-6 and rel_err(dk[:, :, Lv:], rk) < 2e-6
     assert torch.equal(dv[:, :, Lv:].cpu(), v.transpose(1, 2))
     assert float(dq[:, :, :Lv].abs().max()) == 0.0
+
+
+def test_qkv_split_bf16_transposed_v(dev):
+    """bf16 outputs with V written transposed [B, H, 128, pitch] for the bf16 attention kernel."""
+    B, L, H, Lv = 2, 11, 3, 4
+    S, pitch = L + Lv, 32
+    qkv = _rand((B * L, 3 * H * 128), 50)
+    g = 1 + 0.1 * _rand((128,), 51)
+    pos = torch.arange(L, dtype=torch.int32)
+    cos, sin = tables.rope_table(L + 1)
+    q, k, v = qkv.view(B, L, 3, H, 128).unbind(2)
+    c2, s2 = cos[:L].repeat_interleave(2, 1), sin[:L].repeat_interleave(2, 1)
+    rq = O.apply_rope(O.rms_norm(q, g, 1e-6), c2, s2).transpose(1, 2)
+    dq, dk = (torch.zeros(B, H, S, 128, device=dev, dtype=torch.bfloat16) for _ in range(2))
+    dv = torch.zeros(B, H, 128, pitch, device=dev, dtype=torch.bfloat16)
+    rt.op_qkv_split(qkv.to(dev), L, H, [g.to(dev), g.to(dev), None], [pos.to(dev), pos.to(dev), None],
+                    [dq, dk, dv], S, Lv, 1e-6, cos.to(dev), sin.to(dev), vt_pitch=pitch)
+    assert rel_err(dq[:, :, Lv:].float(), rq) < 4e-3
+    assert torch.equal(dv[..., Lv:Lv + L].cpu(), v.transpose(1, 2).transpose(2, 3).to(torch.bfloat16))
+    assert float(dv[..., :Lv].abs().max()) == 0.0 and float(dv[..., S:].abs().max()) == 0.0
 
 
 def test_latent_rows(dev):
