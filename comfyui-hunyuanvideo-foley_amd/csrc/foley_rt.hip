@@ -803,6 +803,7 @@ extern "C" int foley_op_gemm(const foley_gemm_desc* d, void* stream) {
   g.out0 = d->out0; g.out1 = d->out1; g.osegV = d->osegV; g.out_seg = d->out_seg; g.out_row = d->out_row;
   g.out_shift = d->out_shift; g.out_check = d->out_check; g.rb = to_rb(&d->rb); g.res = d->res;
   g.alpha = d->alpha; g.alphaC = d->alphaC > 0 ? d->alphaC : 1;
+  g.ksplit = d->ksplit;
   if (g.segV < 1 || g.segS < 1 || g.osegV < 1 || g.taps < 1) return FAIL(FOLEY_ERR_INVALID, "bad GEMM descriptor");
   return launch_gemm(g, d->dtype, d->epilogue, d->tile, (hipStream_t)stream);
 }

@@ -46,10 +46,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
   const int tiles_n = (g.N + BN - 1) / BN;
   int bid = blockIdx.x;
   {  // bijective XCD remap: consecutive tile ids (same weight panel) share an XCD / L2
-    const int nwg = tiles_m * tiles_n;
+    const int nwg = tiles_m * tiles_n * (EPI == EPI_GATE_RES ? g.ksplit : 1);
     const int xcd = bid & 7, slot = bid >> 3;
     const int q = nwg >> 3, r = nwg & 7;
     bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  int ks = 0;
+  if constexpr (EPI == EPI_GATE_RES) {
+    ks = bid % g.ksplit;
+    bid /= g.ksplit;
   }
   const int tm = bid % tiles_m, tn = bid / tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
@@ -92,13 +97,24 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int fi = lane & 31, kh = lane >> 5;
-  const int nk = g.K / BK;
+  int kt_begin = 0, nk = g.K / BK;
+  if constexpr (EPI == EPI_GATE_RES) {  // this workgroup's K range
+    const int tot = nk;
+    kt_begin = (int)((long)tot * ks / g.ksplit);
+    nk = (int)((long)tot * (ks + 1) / g.ksplit) - kt_begin;
+  }
   // Loader / LDS-writer cursors over the K axis, advanced incrementally (no per-slice division):
   // channel offset inside the current tap, the tap's source-row offset, and that offset in elements.
   const long tap_step = (long)g.dil * g.lda;
-  int ld_k0 = 0, ld_c0 = 0, ld_toff = g.tap0;
-  long ld_roff = (long)g.tap0 * g.lda;
-  int wr_c0 = 0, wr_toff = g.tap0;
+  int ld_k0 = kt_begin * BK;
+  int ld_c0 = ld_k0, ld_toff = g.tap0;
+  if (kt_begin > 0) {
+    const int tap = ld_k0 / g.tapC;
+    ld_c0 = ld_k0 - tap * g.tapC;
+    ld_toff = g.tap0 + tap * g.dil;
+  }
+  long ld_roff = (long)ld_toff * g.lda;
+  int wr_c0 = ld_c0, wr_toff = ld_toff;
 
 #define FOLEY_GLOAD(slot)                                                                  \
   {                                                                                        \
@@ -248,13 +264,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
           if (g.out_check && (rel < 0 || rel >= g.out_seg)) continue;
           const long off = obase + rel;
           float v = acc[i][j][e];
-          if (g.bias) v += g.bias[col];
+          if (g.bias && ks == 0) v += g.bias[col];
           if constexpr (EPI == EPI_STORE_F32) {
             if (rbp) v += rbp[col];
             ((float*)g.out0)[off] = v;
           } else if constexpr (EPI == EPI_GATE_RES) {
             float* x = (float*)g.out0;
-            x[off] = x[off] + v * rbp[col];
+            if (g.ksplit > 1) unsafeAtomicAdd(x + off, v * rbp[col]);  // global_atomic_add_f32
+            else x[off] = x[off] + v * rbp[col];
           } else if constexpr (EPI == EPI_DAC) {
             if (g.res) v += g.res[off];
             if (g.out0) ((float*)g.out0)[off] = v;
@@ -270,7 +287,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
 
 template <typename T, int BM, int BN, int WM, int WN, int NS, int EPI>
 int launch_one(const GemmArgs& g, hipStream_t st) {
-  const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+  const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * (EPI == EPI_GATE_RES ? g.ksplit : 1);
   constexpr size_t lds = 2 * (size_t)(BM + BN) * LDS_PITCH;
   auto k = gemm_kernel<T, BM, BN, WM, WN, NS, EPI>;
   if (lds > 64 * 1024) {
@@ -306,7 +323,8 @@ int launch_tile(const GemmArgs& g, int epi, hipStream_t st) {
 }
 
 template <typename T>
-int launch_typed(const GemmArgs& g, int epi, int tile, hipStream_t st) {
+int launch_typed(const GemmArgs& g_in, int epi, int tile, hipStream_t st) {
+  GemmArgs g = g_in;
   constexpr int BK = 8 * Frag<T>::EPC;
   if (g.K % BK || g.tapC % BK || g.taps * g.tapC != g.K || g.lda % Frag<T>::EPC)
     return foley_set_err("GEMM: K / tap width / lda must be multiples of the 128-byte K-slice", __FILE__, __LINE__);
@@ -323,6 +341,17 @@ int launch_typed(const GemmArgs& g, int epi, int tile, hipStream_t st) {
     else if (b128 >= 100 && (b128 <= 256 || rem == 0 || rem >= 128 || b128 >= 2048)) tile = 1;
     else if (epi == EPI_SILUGATE_T) tile = nblk(64, 128) >= 192 ? 2 : 1;
     else tile = 3;
+  }
+  if (epi != EPI_GATE_RES || g.ksplit == 1 || (g.ksplit == 0 && sizeof(T) == 4)) {
+    g.ksplit = 1;   // fp32 (parity) mode keeps a fixed summation order
+  } else if (g.ksplit == 0) {
+    // fill ~3 workgroups per CU, keep >= 12 K-slices per range
+    static const int bm[5] = {0, 128, 64, 64, 128}, bn[5] = {0, 128, 128, 64, 64};
+    const long blocks = (long)((g.M + bm[tile] - 1) / bm[tile]) * ((g.N + bn[tile] - 1) / bn[tile]);
+    const int nk = g.K / BK;
+    long want = (768 + blocks - 1) / blocks;
+    if (want > nk / 12) want = nk / 12;
+    g.ksplit = (int)(want < 1 ? 1 : (want > 16 ? 16 : want));
   }
   switch (tile) {
     case 1: return launch_tile<T, 128, 128, 4, 2, 4>(g, epi, st);

@@ -42,6 +42,8 @@ struct GemmArgs {
   const float* res;   // EPI_DAC residual (same mapping as out0) or null
   const float* alpha; // EPI_DAC snake alpha, indexed n % alphaC
   int alphaC;
+  int ksplit;         // EPI_GATE_RES only: K is cut into `ksplit` ranges whose partial products are
+                      // accumulated with hardware fp32 atomics (0 = auto; 1 = deterministic)
 };
 
 // dtype: FOLEY_F32 or FOLEY_BF16 operands (accumulation is always fp32). tile: 0 = auto.

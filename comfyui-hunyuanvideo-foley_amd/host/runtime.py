@@ -58,7 +58,7 @@ class GemmDescC(C.Structure):
         ("osegV", C.c_int32), ("out_seg", C.c_int64), ("out_row", C.c_int64), ("out_shift", C.c_int64),
         ("out_check", C.c_int32),
         ("rb", RowBcastC), ("res", C.c_void_p), ("alpha", C.c_void_p), ("alphaC", C.c_int32),
-        ("dtype", C.c_int32), ("epilogue", C.c_int32), ("tile", C.c_int32),
+        ("dtype", C.c_int32), ("epilogue", C.c_int32), ("tile", C.c_int32), ("ksplit", C.c_int32),
     ]
 
 
@@ -256,14 +256,14 @@ def rowbcast(t: Optional[torch.Tensor], mode: int = 0, rows_per_cfg: int = 1, L:
 
 
 def op_gemm(A, W, bias=None, *, M=None, epilogue=EPI_STORE_F32, out0=None, out1=None, ldc=None, conv=None,
-            convT=None, rb: Optional[RowBcastC] = None, res=None, alpha=None, alphaC=1, tile=0):
+            convT=None, rb: Optional[RowBcastC] = None, res=None, alpha=None, alphaC=1, tile=0, ksplit=0):
     """Thin wrapper over foley_op_gemm.  conv=(seg, C, taps, dil) ; convT=(Tin, Cin, stride, Cout)."""
     lib = load_library()
     d = GemmDescC()
     N, K = W.shape
     d.A, d.W, d.bias = _ptr(A), _ptr(W), _ptr(bias) if bias is not None else None
     d.N, d.K = N, K
-    d.dtype, d.epilogue, d.tile = dt_of(W), epilogue, tile
+    d.dtype, d.epilogue, d.tile, d.ksplit = dt_of(W), epilogue, tile, ksplit
     if convT is not None:
         Tin, Cin, s, Cout = convT
         clips = A.numel() // (Tin * Cin)

@@ -132,6 +132,7 @@ typedef struct foley_gemm_desc {
   int32_t dtype;   /* operand dtype */
   int32_t epilogue;/* 0 store f32, 1 store T, 2 silu T, 3 gelu-tanh T, 4 silu-gate T, 5 gated residual, 6 DAC */
   int32_t tile;    /* 0 auto */
+  int32_t ksplit;  /* gated-residual epilogue: K ranges accumulated with fp32 atomics (0 auto, 1 deterministic) */
 } foley_gemm_desc;
 
 int foley_op_gemm(const foley_gemm_desc* d, void* stream);

@@ -101,6 +101,27 @@ def test_gemm_epilogues(dev, dtype, epi):
         assert rel_err(out, ref) < _tol(dtype)
 
 
+@pytest.mark.parametrize("ksplit", [0, 1, 2, 5])
+@pytest.mark.parametrize("conv", [False, True])
+def test_gemm_split_k(dev, ksplit, conv):
+    """Gated-residual epilogue with K ranges accumulated by fp32 atomics (bf16 mode), incl. the
+    conv addressing whose tap cursor must start mid-way for the later ranges."""
+    B, L, C, N = 2, 50, 256, 192
+    x, w, b = _rand((B, L, C), 24), _rand((N, C, 3), 25, 1 / math.sqrt(3 * C)), _rand((N,), 26, 0.1)
+    dt = torch.bfloat16
+    res0, gate = _rand((B * L, N), 27), _rand((N,), 28)
+    if conv:
+        y = O.conv1d_cl(_q(x, dt), _q(w, dt), b, 1).reshape(B * L, N)
+        Wp, kw = packers.conv_to_gemm(w), dict(conv=(L, C, 3, 1))
+    else:
+        y = F.linear(_q(x, dt).reshape(B * L, C), _q(w[:, :, 0], dt), b)
+        Wp, kw = w[:, :, 0].contiguous(), {}
+    out = res0.to(dev).clone()
+    rt.op_gemm(x.reshape(B * L, C).to(dev, dt), Wp.to(dev, dt), b.to(dev), out0=out, epilogue=rt.EPI_GATE_RES,
+               rb=rt.rowbcast(gate.to(dev), 0), ksplit=ksplit, **kw)
+    assert rel_err(out, res0 + y * gate) < 1e-5
+
+
 # ----------------------------------------------------------------------------- GEMM: conv addressing
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,L,Cin,Cout", [(2, 50, 256, 384), (3, 7, 128, 64), (1, 250, 1536, 256)])

@@ -25,6 +25,7 @@ ap.add_argument("--shapes", default=",".join(SHAPES))
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--check", action="store_true")
+ap.add_argument("--ksplits", default="", help="comma list: benchmark the gated-residual epilogue with these K splits")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -40,6 +41,24 @@ for name in a.shapes.split(","):
     if a.check:
         ref = (A.float() @ Ws[0].float().t())
     line = f"{name:5s} N={N:5d} K={K:5d} |"
+    if a.ksplits:
+        gate = torch.randn(N, device=dev)
+        x = torch.zeros(a.m, N, device=dev)
+        for t in tiles:
+            for ksp in [int(v) for v in a.ksplits.split(",")]:
+                rt.op_gemm(A, Ws[0], None, out0=x, tile=t, epilogue=rt.EPI_GATE_RES, rb=rt.rowbcast(gate, 0), ksplit=ksp)
+                torch.cuda.synchronize()
+                evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.reps)]
+                for i, (e0, e1) in enumerate(evs):
+                    e0.record()
+                    rt.op_gemm(A, Ws[i % ncopy], None, out0=x, tile=t, epilogue=rt.EPI_GATE_RES, rb=rt.rowbcast(gate, 0), ksplit=ksp)
+                    e1.record()
+                torch.cuda.synchronize()
+                ts = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+                us = ts[len(ts) // 2] * 1e3
+                line += f" t{t}k{ksp}:{us:6.1f}us {2 * a.m * N * K / us / 1e6:4.0f}TF |"
+        print(line, flush=True)
+        continue
     for t in tiles:
         try:
             rt.op_gemm(A, Ws[0], None, out0=out, tile=t)
