@@ -479,80 +479,85 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
     struct Stream { const char* pre; float* x; void* xn; float* qkv; void* att; void* hid; int rows, L, tok_off; const int* pos; };
     Stream ss[2] = {{"a_", c->audio, c->xn_a, c->qkv_a, c->att_a, c->hid_a, M, La, Lv, pl.pos_audio_self},
                     {"v_", c->vcond, c->xn_v, c->qkv_v, c->att_v, c->hid_v, Mv, Lv, 0, pl.pos_visual_self}};
-    // 1. joint self attention (hifi_foley.py:215-269)
-    for (int s = 0; s < 2; ++s) {
+    // Both streams go through the same sequence of ops with their own weights; each op is ONE
+    // launch covering the audio problem and the (much smaller) visual problem.
+    auto lin2 = [&](const char* name, int N, int K, Lin* la, Lin* lv) -> int {
+      TRY(get_lin(c, p + "a_" + name, T, N, K, true, la));
+      return get_lin(c, p + "v_" + name, T, N, K, true, lv);
+    };
+    auto ln2 = [&](int c_shift, int c_scale) -> int {
+      LnArgs a0{ss[0].x, ss[0].rows, tb(0, c_shift), tb(0, c_scale), ss[0].xn};
+      LnArgs a1{ss[1].x, ss[1].rows, tb(1, c_shift), tb(1, c_scale), ss[1].xn};
+      return launch_ln_mod_pair(a0, a1, D, 1e-6f, T, st);
+    };
+    auto gated2 = [&](const Lin& la, const Lin& lv, bool from_hid, int c_gate) -> int {
+      GemmArgs g0 = gemm_plain(from_hid ? ss[0].hid : ss[0].att, ss[0].rows, la, ss[0].x, D);
+      GemmArgs g1 = gemm_plain(from_hid ? ss[1].hid : ss[1].att, ss[1].rows, lv, ss[1].x, D);
+      g0.rb = tb(0, c_gate);
+      g1.rb = tb(1, c_gate);
+      return launch_gemm_pair(g0, g1, T, EPI_GATE_RES, st);
+    };
+    auto split_args = [&](int s, int nK, const void* gq, const void* gk, const int* pos) {
       Stream& z = ss[s];
-      Lin qkv;
-      const void *qn, *kn;
-      TRY(get_lin(c, p + z.pre + "qkv", T, 3 * D, D, true, &qkv));
-      TRY(get_tensor(c, p + z.pre + "qn", FOLEY_F32, {128}, &qn));
-      TRY(get_tensor(c, p + z.pre + "kn", FOLEY_F32, {128}, &kn));
-      TRY(launch_ln_mod(z.x, z.rows, D, 1e-6f, tb(s, 0), tb(s, 1), z.xn, T, st));
-      TRY(launch_gemm(gemm_plain(z.xn, z.rows, qkv, z.qkv, 3 * D), T, EPI_STORE_F32, 0, st));
       QkvSplitArgs q{};
-      q.qkv = z.qkv; q.M = z.rows; q.L = z.L; q.H = H; q.nK = 3;
-      q.gain[0] = (const float*)qn; q.gain[1] = (const float*)kn;
-      q.pos[0] = z.pos; q.pos[1] = z.pos;
+      q.qkv = z.qkv; q.M = z.rows; q.L = z.L; q.H = H; q.nK = nK;
+      q.gain[0] = (const float*)gq; q.gain[1] = (const float*)gk;
+      q.pos[0] = pos; q.pos[1] = nK > 1 ? pos : nullptr;
       q.dst[0] = c->Q; q.dst[1] = c->K; q.dst[2] = c->V;
-      q.out_dtype = T; q.vt_pitch = bf ? Sp : 0;
+      q.out_dtype = T; q.vt_pitch = (bf && nK == 3) ? Sp : 0;
       q.S_tot = S; q.tok_off = z.tok_off; q.eps = 1e-6f; q.cos_tab = pl.rope_cos; q.sin_tab = pl.rope_sin;
-      TRY(launch_qkv_split(q, st));
-    }
+      return q;
+    };
+    // 1. joint self attention (hifi_foley.py:215-269)
     {
+      Lin qa, qv;
+      const void *aqn, *akn, *vqn, *vkn;
+      TRY(lin2("qkv", 3 * D, D, &qa, &qv));
+      TRY(get_tensor(c, p + "a_qn", FOLEY_F32, {128}, &aqn));
+      TRY(get_tensor(c, p + "a_kn", FOLEY_F32, {128}, &akn));
+      TRY(get_tensor(c, p + "v_qn", FOLEY_F32, {128}, &vqn));
+      TRY(get_tensor(c, p + "v_kn", FOLEY_F32, {128}, &vkn));
+      TRY(ln2(0, 1));
+      TRY(launch_gemm_pair(gemm_plain(ss[0].xn, ss[0].rows, qa, ss[0].qkv, 3 * D),
+                           gemm_plain(ss[1].xn, ss[1].rows, qv, ss[1].qkv, 3 * D), T, EPI_STORE_F32, st));
+      TRY(launch_qkv_split_pair(split_args(0, 3, aqn, akn, ss[0].pos), split_args(1, 3, vqn, vkn, ss[1].pos), st));
       AttnArgs a{c->Q, c->K, c->V, Bc, H, S, S, 1, c->att_v, c->att_a, Lv, T, bf ? Sp : 0};
       TRY(launch_attention(a, T, st));
-    }
-    for (int s = 0; s < 2; ++s) {
-      Stream& z = ss[s];
-      Lin proj;
-      TRY(get_lin(c, p + z.pre + "proj", T, D, D, true, &proj));
-      GemmArgs g = gemm_plain(z.att, z.rows, proj, z.x, D);
-      g.rb = tb(s, 2);
-      TRY(launch_gemm(g, T, EPI_GATE_RES, 0, st));
+      Lin pa, pv;
+      TRY(lin2("proj", D, D, &pa, &pv));
+      TRY(gated2(pa, pv, false, 2));
     }
     // 2. cross attention to the (cached) text keys/values (hifi_foley.py:271-319)
-    for (int s = 0; s < 2; ++s) {
-      Stream& z = ss[s];
-      Lin cq;
-      const void* qn;
-      TRY(get_lin(c, p + z.pre + "cq", T, D, D, true, &cq));
-      TRY(get_tensor(c, p + z.pre + "cqn", FOLEY_F32, {128}, &qn));
-      TRY(launch_ln_mod(z.x, z.rows, D, 1e-6f, tb(s, 3), tb(s, 4), z.xn, T, st));
-      TRY(launch_gemm(gemm_plain(z.xn, z.rows, cq, z.qkv, D), T, EPI_STORE_F32, 0, st));
-      QkvSplitArgs q{};
-      q.qkv = z.qkv; q.M = z.rows; q.L = z.L; q.H = H; q.nK = 1;
-      q.gain[0] = (const float*)qn; q.pos[0] = pl.pos_linear; q.dst[0] = c->Q;
-      q.out_dtype = T; q.vt_pitch = 0;
-      q.S_tot = S; q.tok_off = z.tok_off; q.eps = 1e-6f; q.cos_tab = pl.rope_cos; q.sin_tab = pl.rope_sin;
-      TRY(launch_qkv_split(q, st));
-    }
     {
+      Lin qa, qv;
+      const void *aqn, *vqn;
+      TRY(lin2("cq", D, D, &qa, &qv));
+      TRY(get_tensor(c, p + "a_cqn", FOLEY_F32, {128}, &aqn));
+      TRY(get_tensor(c, p + "v_cqn", FOLEY_F32, {128}, &vqn));
+      TRY(ln2(3, 4));
+      TRY(launch_gemm_pair(gemm_plain(ss[0].xn, ss[0].rows, qa, ss[0].qkv, D),
+                           gemm_plain(ss[1].xn, ss[1].rows, qv, ss[1].qkv, D), T, EPI_STORE_F32, st));
+      TRY(launch_qkv_split_pair(split_args(0, 1, aqn, nullptr, pl.pos_linear),
+                                split_args(1, 1, vqn, nullptr, pl.pos_linear), st));
       const int Ltp = (Lt + 31) & ~31;
       const size_t offk = (size_t)blk * ncfg * H * Lt * 128 * es;
       const size_t offv = (size_t)blk * ncfg * H * (bf ? Ltp : Lt) * 128 * es;
       AttnArgs a{c->Q, (char*)c->txt_k + offk, (char*)c->txt_v + offv, Bc, H, S, Lt, clips, c->att_v, c->att_a, Lv,
                  T, bf ? Ltp : 0};
       TRY(launch_attention(a, T, st));
-    }
-    for (int s = 0; s < 2; ++s) {
-      Stream& z = ss[s];
-      Lin proj;
-      TRY(get_lin(c, p + z.pre + "cproj", T, D, D, true, &proj));
-      GemmArgs g = gemm_plain(z.att, z.rows, proj, z.x, D);
-      g.rb = tb(s, 5);
-      TRY(launch_gemm(g, T, EPI_GATE_RES, 0, st));
+      Lin pa, pv;
+      TRY(lin2("cproj", D, D, &pa, &pv));
+      TRY(gated2(pa, pv, false, 5));
     }
     // 3. GELU-tanh MLPs (hifi_foley.py:321-331)
-    for (int s = 0; s < 2; ++s) {
-      Stream& z = ss[s];
-      Lin fc1, fc2;
-      TRY(get_lin(c, p + z.pre + "fc1", T, f.mlp_hidden, D, true, &fc1));
-      TRY(get_lin(c, p + z.pre + "fc2", T, D, f.mlp_hidden, true, &fc2));
-      TRY(launch_ln_mod(z.x, z.rows, D, 1e-6f, tb(s, 6), tb(s, 7), z.xn, T, st));
-      TRY(launch_gemm(gemm_plain(z.xn, z.rows, fc1, z.hid, f.mlp_hidden), T, EPI_GELU_T, 0, st));
-      GemmArgs g = gemm_plain(z.hid, z.rows, fc2, z.x, D);
-      g.rb = tb(s, 8);
-      TRY(launch_gemm(g, T, EPI_GATE_RES, 0, st));
+    {
+      Lin f1a, f1v, f2a, f2v;
+      TRY(lin2("fc1", f.mlp_hidden, D, &f1a, &f1v));
+      TRY(lin2("fc2", D, f.mlp_hidden, &f2a, &f2v));
+      TRY(ln2(6, 7));
+      TRY(launch_gemm_pair(gemm_plain(ss[0].xn, ss[0].rows, f1a, ss[0].hid, f.mlp_hidden),
+                           gemm_plain(ss[1].xn, ss[1].rows, f1v, ss[1].hid, f.mlp_hidden), T, EPI_GELU_T, st));
+      TRY(gated2(f2a, f2v, true, 8));
     }
   }
 

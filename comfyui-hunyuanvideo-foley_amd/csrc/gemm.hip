@@ -28,8 +28,15 @@ __device__ __forceinline__ float act_epi(float v, int epi) {
   return v;
 }
 
+struct GemmPair {
+  GemmArgs g[2];
+  int tiles0;  // workgroups belonging to g[0]; the rest run g[1]
+};
+
 template <typename T, int BM, int BN, int WM, int WN, int NS, int EPI>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmPair pr) {
+  const int sel = (int)blockIdx.x >= pr.tiles0 ? 1 : 0;  // wave-uniform
+  const GemmArgs& g = pr.g[sel];
   constexpr int NT = WM * WN * 64;
   constexpr int EPC = Frag<T>::EPC;
   constexpr int BK = 8 * EPC;
@@ -44,7 +51,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
 
   const int tiles_m = (g.M + BM - 1) / BM;
   const int tiles_n = (g.N + BN - 1) / BN;
-  int bid = blockIdx.x;
+  int bid = (int)blockIdx.x - (sel ? pr.tiles0 : 0);
   {  // bijective XCD remap: consecutive tile ids (same weight panel) share an XCD / L2
     const int nwg = tiles_m * tiles_n * (EPI == EPI_GATE_RES ? g.ksplit : 1);
     const int xcd = bid & 7, slot = bid >> 3;
@@ -286,8 +293,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NS, int EPI>
-int launch_one(const GemmArgs& g, hipStream_t st) {
-  const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * (EPI == EPI_GATE_RES ? g.ksplit : 1);
+int launch_one(const GemmArgs& g, const GemmArgs* g1, hipStream_t st) {
+  auto ntiles = [](const GemmArgs& q) {
+    return ((q.M + BM - 1) / BM) * ((q.N + BN - 1) / BN) * (EPI == EPI_GATE_RES ? q.ksplit : 1);
+  };
+  GemmPair pr;
+  pr.g[0] = g;
+  pr.g[1] = g1 ? *g1 : g;
+  pr.tiles0 = ntiles(g);
+  const int tiles = pr.tiles0 + (g1 ? ntiles(*g1) : 0);
   constexpr size_t lds = 2 * (size_t)(BM + BN) * LDS_PITCH;
   auto k = gemm_kernel<T, BM, BN, WM, WN, NS, EPI>;
   if (lds > 64 * 1024) {
@@ -298,33 +312,50 @@ int launch_one(const GemmArgs& g, hipStream_t st) {
       raised = true;
     }
   }
-  hipLaunchKernelGGL(k, dim3(tiles), dim3(WM * WN * 64), lds, st, g);
+  hipLaunchKernelGGL(k, dim3(tiles), dim3(WM * WN * 64), lds, st, pr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);
   return 0;
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NS>
-int launch_tile(const GemmArgs& g, int epi, hipStream_t st) {
+int launch_tile(const GemmArgs& g, const GemmArgs* g1, int epi, hipStream_t st) {
   switch (epi) {
-    case EPI_STORE_F32: return launch_one<T, BM, BN, WM, WN, NS, EPI_STORE_F32>(g, st);
-    case EPI_STORE_T: return launch_one<T, BM, BN, WM, WN, NS, EPI_STORE_T>(g, st);
-    case EPI_SILU_T: return launch_one<T, BM, BN, WM, WN, NS, EPI_SILU_T>(g, st);
-    case EPI_GELU_T: return launch_one<T, BM, BN, WM, WN, NS, EPI_GELU_T>(g, st);
-    case EPI_GATE_RES: return launch_one<T, BM, BN, WM, WN, NS, EPI_GATE_RES>(g, st);
+    case EPI_STORE_F32: return launch_one<T, BM, BN, WM, WN, NS, EPI_STORE_F32>(g, g1, st);
+    case EPI_STORE_T: return launch_one<T, BM, BN, WM, WN, NS, EPI_STORE_T>(g, g1, st);
+    case EPI_SILU_T: return launch_one<T, BM, BN, WM, WN, NS, EPI_SILU_T>(g, g1, st);
+    case EPI_GELU_T: return launch_one<T, BM, BN, WM, WN, NS, EPI_GELU_T>(g, g1, st);
+    case EPI_GATE_RES: return launch_one<T, BM, BN, WM, WN, NS, EPI_GATE_RES>(g, g1, st);
     case EPI_SILUGATE_T:
-      if constexpr ((BN / WN) % 64 == 0) return launch_one<T, BM, BN, WM, WN, NS, EPI_SILUGATE_T>(g, st);
+      if constexpr ((BN / WN) % 64 == 0) return launch_one<T, BM, BN, WM, WN, NS, EPI_SILUGATE_T>(g, g1, st);
       else return foley_set_err("gated epilogue needs a 64-wide wave tile", __FILE__, __LINE__);
     case EPI_DAC:
-      if constexpr (sizeof(T) == 4) return launch_one<T, BM, BN, WM, WN, NS, EPI_DAC>(g, st);
+      if constexpr (sizeof(T) == 4) return launch_one<T, BM, BN, WM, WN, NS, EPI_DAC>(g, g1, st);
       else return foley_set_err("DAC epilogue is fp32 only", __FILE__, __LINE__);
   }
   return foley_set_err("unknown GEMM epilogue", __FILE__, __LINE__);
 }
 
 template <typename T>
-int launch_typed(const GemmArgs& g_in, int epi, int tile, hipStream_t st) {
+int check_args(const GemmArgs& g) {
+  constexpr int BK = 8 * Frag<T>::EPC;
+  if (g.K % BK || g.tapC % BK || g.taps * g.tapC != g.K || g.lda % Frag<T>::EPC)
+    return foley_set_err("GEMM: K / tap width / lda must be multiples of the 128-byte K-slice", __FILE__, __LINE__);
+  if (((uintptr_t)g.A | (uintptr_t)g.W) & 15)
+    return foley_set_err("GEMM: operands must be 16-byte aligned", __FILE__, __LINE__);
+  return 0;
+}
+
+template <typename T>
+int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile, hipStream_t st) {
   GemmArgs g = g_in;
+  GemmArgs g1s;
+  const GemmArgs* g1 = nullptr;
+  if (g1_in) {
+    if (int rc = check_args<T>(*g1_in)) return rc;
+    g1s = *g1_in;
+    g1 = &g1s;
+  }
   constexpr int BK = 8 * Frag<T>::EPC;
   if (g.K % BK || g.tapC % BK || g.taps * g.tapC != g.K || g.lda % Frag<T>::EPC)
     return foley_set_err("GEMM: K / tap width / lda must be multiples of the 128-byte K-slice", __FILE__, __LINE__);
@@ -353,11 +384,12 @@ int launch_typed(const GemmArgs& g_in, int epi, int tile, hipStream_t st) {
     if (want > nk / 12) want = nk / 12;
     g.ksplit = (int)(want < 1 ? 1 : (want > 16 ? 16 : want));
   }
+  if (g1) g1s.ksplit = g.ksplit;
   switch (tile) {
-    case 1: return launch_tile<T, 128, 128, 4, 2, 4>(g, epi, st);
-    case 2: return launch_tile<T, 64, 128, 2, 2, 3>(g, epi, st);
-    case 3: return launch_tile<T, 64, 64, 2, 2, 4>(g, epi, st);
-    case 4: return launch_tile<T, 128, 64, 4, 1, 3>(g, epi, st);
+    case 1: return launch_tile<T, 128, 128, 4, 2, 4>(g, g1, epi, st);
+    case 2: return launch_tile<T, 64, 128, 2, 2, 3>(g, g1, epi, st);
+    case 3: return launch_tile<T, 64, 64, 2, 2, 4>(g, g1, epi, st);
+    case 4: return launch_tile<T, 128, 64, 4, 1, 3>(g, g1, epi, st);
   }
   return foley_set_err("GEMM: bad tile id", __FILE__, __LINE__);
 }
@@ -371,7 +403,15 @@ int launch_gemm(const GemmArgs& g, int dtype, int epi, int tile, hipStream_t st)
       return foley_set_err("experimental GEMM variants: bf16 plain store only", __FILE__, __LINE__);
     return launch_gemm_exp(g, tile, st);
   }
-  if (dtype == FOLEY_F32) return launch_typed<float>(g, epi, tile, st);
-  if (dtype == FOLEY_BF16) return launch_typed<bf16_t>(g, epi, tile, st);
+  if (dtype == FOLEY_F32) return launch_typed<float>(g, nullptr, epi, tile, st);
+  if (dtype == FOLEY_BF16) return launch_typed<bf16_t>(g, nullptr, epi, tile, st);
+  return foley_set_err("GEMM: unsupported operand dtype", __FILE__, __LINE__);
+}
+
+int launch_gemm_pair(const GemmArgs& g0, const GemmArgs& g1, int dtype, int epi, hipStream_t st) {
+  if (g1.M <= 0 || g1.N <= 0) return launch_gemm(g0, dtype, epi, 0, st);
+  if (g0.M <= 0 || g0.N <= 0) return launch_gemm(g1, dtype, epi, 0, st);
+  if (dtype == FOLEY_F32) return launch_typed<float>(g0, &g1, epi, 0, st);
+  if (dtype == FOLEY_BF16) return launch_typed<bf16_t>(g0, &g1, epi, 0, st);
   return foley_set_err("GEMM: unsupported operand dtype", __FILE__, __LINE__);
 }

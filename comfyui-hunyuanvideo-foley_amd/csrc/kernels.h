@@ -48,6 +48,10 @@ struct GemmArgs {
 
 // dtype: FOLEY_F32 or FOLEY_BF16 operands (accumulation is always fp32). tile: 0 = auto.
 int launch_gemm(const GemmArgs& g, int dtype, int epi, int tile, hipStream_t st);
+// Two independent problems of the same dtype / epilogue in ONE launch (the audio and the visual
+// stream of a two-stream block): the small problem's workgroups hide in the large one's shadow.
+// Tile shape and K split are chosen for g0.
+int launch_gemm_pair(const GemmArgs& g0, const GemmArgs& g1, int dtype, int epi, hipStream_t st);
 // experimental mainloop variants (bf16, plain fp32 store), tile codes >= 100 - see gemm_exp.hip
 int launch_gemm_exp(const GemmArgs& g, int code, hipStream_t st);
 
@@ -78,6 +82,14 @@ int launch_attention(const AttnArgs& a, int out_dtype, hipStream_t st);
 // out(T)[r, :] = LayerNorm(x[r, :]; eps) * (1 + scale) + shift   (scale/shift optional)
 int launch_ln_mod(const float* x, int M, int D, float eps, const RowBcast& shift, const RowBcast& scale,
                   void* out, int out_dtype, hipStream_t st);
+struct LnArgs {
+  const float* x;
+  int M;
+  RowBcast shift, scale;
+  void* out;
+};
+// two row sets (same D / eps / dtype) in one launch
+int launch_ln_mod_pair(const LnArgs& a0, const LnArgs& a1, int D, float eps, int out_dtype, hipStream_t st);
 
 struct QkvSplitArgs {
   const float* qkv;  // [M, nK * H * 128]
@@ -93,6 +105,7 @@ struct QkvSplitArgs {
   const float* sin_tab;
 };
 int launch_qkv_split(const QkvSplitArgs& a, hipStream_t st);
+int launch_qkv_split_pair(const QkvSplitArgs& a0, const QkvSplitArgs& a1, hipStream_t st);
 
 // out(T)[r, :] = act(a[r, :] + v[:]) ; a optional [R, D]; v optional broadcast row (step-indexed)
 int launch_rows_add_act(const float* a, const RowBcast& v, int R, int D, int act_silu, void* out,

@@ -29,10 +29,21 @@ template <> struct Pack4<bf16_t> {
 
 // One wave per row; every global load of the row (x, shift, scale) is issued before the first
 // reduction so the kernel pays one memory round trip, results leave as 8/16-byte vector stores.
+struct LnPair {
+  LnArgs a[2];
+  int blocks0;
+};
+
 template <typename OutT, int MAXV>
-__global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x, int M, int D, float eps,
-                                                     RowBcast shift, RowBcast scale, OutT* __restrict__ out) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+__global__ __launch_bounds__(256) void ln_mod_kernel(const LnPair pr, int D, float eps) {
+  const int sel = (int)blockIdx.x >= pr.blocks0 ? 1 : 0;
+  const LnArgs& A = pr.a[sel];
+  const float* __restrict__ x = A.x;
+  const int M = A.M;
+  const RowBcast& shift = A.shift;
+  const RowBcast& scale = A.scale;
+  OutT* __restrict__ out = (OutT*)A.out;
+  const int row = ((int)blockIdx.x - (sel ? pr.blocks0 : 0)) * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= M) return;
   const int nv = D >> 2;  // float4 per row
@@ -81,9 +92,16 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x
 // reference: rearrange "(K H D)", RMSNorm (norm_layers.py:36-52 / nn.RMSNorm), apply_rotary_emb
 // (attn_layers.py:112-146).  One wave per (row, head, operand); lane owns the rotation pair
 // (2*lane, 2*lane+1).
+struct QkvPair {
+  QkvSplitArgs a[2];
+  int blocks0;
+};
+
 template <typename OutT>
-__global__ __launch_bounds__(256) void qkv_split_kernel(const QkvSplitArgs a) {
-  const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+__global__ __launch_bounds__(256) void qkv_split_kernel(const QkvPair pr) {
+  const int sel = (int)blockIdx.x >= pr.blocks0 ? 1 : 0;
+  const QkvSplitArgs& a = pr.a[sel];
+  const long wid = (long)((int)blockIdx.x - (sel ? pr.blocks0 : 0)) * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const long total = (long)a.M * a.H * a.nK;
   if (wid >= total) return;
@@ -292,27 +310,45 @@ inline int grid1d(long n, int block) {
 
 }  // namespace
 
-int launch_ln_mod(const float* x, int M, int D, float eps, const RowBcast& shift, const RowBcast& scale,
-                  void* out, int out_dtype, hipStream_t st) {
+int launch_ln_mod_pair(const LnArgs& a0, const LnArgs& a1, int D, float eps, int out_dtype, hipStream_t st) {
   if (D % 4 || D > 8 * 256) return foley_set_err("ln_mod: D must be a multiple of 4 and <= 2048", __FILE__, __LINE__);
-  dim3 grid((M + 3) / 4), block(256);
-  if (out_dtype == FOLEY_F32)
-    hipLaunchKernelGGL((ln_mod_kernel<float, 8>), grid, block, 0, st, x, M, D, eps, shift, scale, (float*)out);
-  else if (out_dtype == FOLEY_BF16)
-    hipLaunchKernelGGL((ln_mod_kernel<bf16_t, 8>), grid, block, 0, st, x, M, D, eps, shift, scale, (bf16_t*)out);
+  LnPair pr;
+  pr.a[0] = a0;
+  pr.a[1] = a1;
+  pr.blocks0 = (a0.M + 3) / 4;
+  dim3 grid(pr.blocks0 + (a1.M + 3) / 4), block(256);
+  if (out_dtype == FOLEY_F32) hipLaunchKernelGGL((ln_mod_kernel<float, 8>), grid, block, 0, st, pr, D, eps);
+  else if (out_dtype == FOLEY_BF16) hipLaunchKernelGGL((ln_mod_kernel<bf16_t, 8>), grid, block, 0, st, pr, D, eps);
   else return foley_set_err("ln_mod: bad dtype", __FILE__, __LINE__);
   FOLEY_LAUNCH_CHECK();
   return 0;
 }
 
-int launch_qkv_split(const QkvSplitArgs& a, hipStream_t st) {
-  const long waves = (long)a.M * a.H * a.nK;
-  if (a.out_dtype == FOLEY_BF16)
-    hipLaunchKernelGGL(qkv_split_kernel<bf16_t>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL(qkv_split_kernel<float>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, a);
+int launch_ln_mod(const float* x, int M, int D, float eps, const RowBcast& shift, const RowBcast& scale,
+                  void* out, int out_dtype, hipStream_t st) {
+  LnArgs a0{x, M, shift, scale, out};
+  LnArgs a1{x, 0, shift, scale, out};
+  return launch_ln_mod_pair(a0, a1, D, eps, out_dtype, st);
+}
+
+int launch_qkv_split_pair(const QkvSplitArgs& a0, const QkvSplitArgs& a1, hipStream_t st) {
+  if (a0.out_dtype != a1.out_dtype) return foley_set_err("qkv_split pair: dtype mismatch", __FILE__, __LINE__);
+  QkvPair pr;
+  pr.a[0] = a0;
+  pr.a[1] = a1;
+  const long w0 = (long)a0.M * a0.H * a0.nK, w1 = (long)a1.M * a1.H * a1.nK;
+  pr.blocks0 = (int)((w0 + 3) / 4);
+  dim3 grid((unsigned)(pr.blocks0 + (w1 + 3) / 4)), block(256);
+  if (a0.out_dtype == FOLEY_BF16) hipLaunchKernelGGL(qkv_split_kernel<bf16_t>, grid, block, 0, st, pr);
+  else hipLaunchKernelGGL(qkv_split_kernel<float>, grid, block, 0, st, pr);
   FOLEY_LAUNCH_CHECK();
   return 0;
+}
+
+int launch_qkv_split(const QkvSplitArgs& a, hipStream_t st) {
+  QkvSplitArgs none = a;
+  none.M = 0;
+  return launch_qkv_split_pair(a, none, st);
 }
 
 int launch_rows_add_act(const float* a, const RowBcast& v, int R, int D, int act_silu, void* out, int out_dtype,
