@@ -233,6 +233,44 @@ def test_node_mappings_and_widgets():
     assert torch.equal(out["waveform"], batch["waveform"][2:3]) and out["sample_rate"] == 48000
 
 
+def test_example_workflow_loads_against_our_nodes():
+    """Drop-in check: every Hunyuan node of the reference's example workflow exists
+    here, its widget values validate against our INPUT_TYPES, and every link's socket type matches."""
+    import json
+    import foley_amd
+    wf = json.load(open(os.path.join(ROOT, "tests", "golden", "example_workflow_nodes.json")))
+    m = foley_amd.NODE_CLASS_MAPPINGS
+    by_id = {n["id"]: n for n in wf["nodes"]}
+    assert {n["type"] for n in wf["nodes"]} == {"HunyuanModelLoader", "HunyuanDependenciesLoader",
+                                                "HunyuanFoleySampler", "HunyuanFoleyTorchCompile",
+                                                "HunyuanBlockSwap", "SelectAudioFromBatch"}
+    for n in wf["nodes"]:
+        cls = m[n["type"]]
+        it = cls.INPUT_TYPES()
+        spec = {**it.get("required", {}), **it.get("optional", {})}
+        for i in n["inputs"]:                       # every socket / converted widget the workflow names exists
+            assert i["name"] in spec, (n["type"], i["name"])
+        widgets = [k for k, v in spec.items() if isinstance(v[0], list) or v[0] in ("INT", "FLOAT", "STRING", "BOOLEAN")]
+        vals = [v for v in (n["widgets_values"] or []) if v not in ("increment", "randomize", "fixed")]
+        assert len(vals) == len(widgets), (n["type"], vals, widgets)
+        for k, v in zip(widgets, vals):
+            t, opts = spec[k][0], (spec[k][1] if len(spec[k]) > 1 else {})
+            if isinstance(t, list):
+                assert (not t) or v in t or k in ("model_name", "vae_name", "synchformer_name"), (k, v)
+            elif t in ("INT", "FLOAT"):
+                assert opts.get("min", v) <= v <= opts.get("max", v), (k, v)
+    for l in wf["links"]:
+        if l["from"] in by_id:
+            src = m[by_id[l["from"]]["type"]]
+            assert src.RETURN_TYPES[l["from_slot"]] == l["type"], l
+        if l["to"] in by_id:
+            dst = by_id[l["to"]]
+            name = dst["inputs"][l["to_slot"]]["name"]
+            it = m[dst["type"]].INPUT_TYPES()
+            spec = {**it.get("required", {}), **it.get("optional", {})}
+            assert spec[name][0] == l["type"], (l, spec[name][0])
+
+
 def test_checkpoint_detection_helpers():
     from foley_amd import nodes
     sd = {"a": torch.zeros(4, 4, dtype=torch.bfloat16), "b": torch.zeros(2, dtype=torch.float32)}
