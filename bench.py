@@ -170,6 +170,13 @@ def main():
         f_loop = f_clip - 2.30933e9 * la
         peak = PEAK_TFLOPS[a.precision]
         ach = a.bs * f_loop / (loop_ms * 1e-3) / 1e12
+        traffic = None   # PMC counters cannot be read live; the committed rocprofv3 --pmc passes give it
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if a.bs == 1 and a.precision == "bf16" and a.model == "xxl":
+                traffic = tj["hbm_bytes_per_loop_iteration"] * STEPS_PER_CLIP
+        except Exception:
+            pass
         out = {
             "metric": "audio-sec/sec (5s clip, 50-step Euler, CFG 4.5)",
             "value": clips * DURATION_S / dt, "unit": "audio-sec/sec", "n_gpus": world, "steps": a.steps,
@@ -180,7 +187,7 @@ def main():
                                    f"DAC-VAE fp32 decode to 48 kHz",
                        "clips_per_gpu": a.bs, "parallelism": f"dp{world}", "hip_graph": not a.no_graph},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                         "traffic": None,
+                         "traffic": traffic, "traffic_unit": "bytes per foley_sample launch (rocprofv3 PMC, offline pass)",
                          "kernel": "gemm_kernel (MFMA GEMM/conv engine; >90% of the device-resident sampler loop)",
                          "launch": "one foley_sample call = 50 captured iterations, HIP-event timed on its stream",
                          "loop_ms": loop_ms, "dac_decode_ms": dac_ms,
