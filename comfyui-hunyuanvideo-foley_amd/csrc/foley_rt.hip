@@ -172,6 +172,21 @@ static int get_tensor(foley_ctx* c, const std::string& name, int dtype, std::ini
   return 0;
 }
 
+// --------------------------------------------------------------------------- zero page
+// 256 zero bytes per device: the direct-to-LDS GEMM loop reads masked rows from here.
+static const void* zero_page() {
+  static void* pages[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!pages[dev]) {
+    void* p = nullptr;
+    if (hipMalloc(&p, 256) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 256) != hipSuccess) return nullptr;
+    pages[dev] = p;
+  }
+  return pages[dev];
+}
+
 // --------------------------------------------------------------------------- launch helpers
 static RowBcast rb_none() { return RowBcast{nullptr, 0, 0, 1, 1, nullptr, 0}; }
 
@@ -205,6 +220,7 @@ static GemmArgs gemm_plain(const void* A, int M, const Lin& l, void* out, long l
   g.out0 = out; g.out1 = nullptr;
   g.osegV = g.segV; g.out_seg = 0; g.out_row = ldc; g.out_shift = 0; g.out_check = 0;
   g.rb = rb_none(); g.res = nullptr; g.alpha = nullptr; g.alphaC = 1;
+  g.zeros = zero_page();
   return g;
 }
 
@@ -809,6 +825,7 @@ extern "C" int foley_op_gemm(const foley_gemm_desc* d, void* stream) {
   g.out_shift = d->out_shift; g.out_check = d->out_check; g.rb = to_rb(&d->rb); g.res = d->res;
   g.alpha = d->alpha; g.alphaC = d->alphaC > 0 ? d->alphaC : 1;
   g.ksplit = d->ksplit;
+  g.zeros = zero_page();
   if (g.segV < 1 || g.segS < 1 || g.osegV < 1 || g.taps < 1) return FAIL(FOLEY_ERR_INVALID, "bad GEMM descriptor");
   return launch_gemm(g, d->dtype, d->epilogue, d->tile, (hipStream_t)stream);
 }

@@ -28,6 +28,82 @@ __device__ __forceinline__ float act_epi(float v, int epi) {
   return v;
 }
 
+// Fused epilogues shared by both mainloops.  C/D layout of the 32x32 MFMA: column = lane & 31,
+// row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
+template <typename T, int EPI, int FM, int FN, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[FM][FN], int m0, int n0, int wm,
+                                              int wn, int fi, int kh, int ks) {
+  const bool plain_out = g.osegV >= g.M;
+  float sn_a[FN], sn_ia[FN];
+  if constexpr (EPI == EPI_DAC) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int col = n0 + wn * TN + j * 32 + fi;
+      sn_a[j] = (g.out1 && col < g.N) ? g.alpha[col % g.alphaC] : 1.0f;
+      sn_ia[j] = 1.0f / (sn_a[j] + 1e-9f);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = m0 + wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+      if (row >= g.M) continue;
+      long obase, orel;
+      if (plain_out) {
+        obase = 0;
+        orel = (long)row * g.out_row + g.out_shift;
+      } else {
+        const int b = row / g.osegV, q = row - b * g.osegV;
+        obase = (long)b * g.out_seg;
+        orel = (long)q * g.out_row + g.out_shift;
+      }
+      const float* rbp = nullptr;
+      if constexpr (EPI == EPI_GATE_RES || EPI == EPI_STORE_F32) {
+        if (g.rb.p) rbp = rb_row(g.rb, row);
+      }
+      if constexpr (EPI == EPI_SILUGATE_T) {
+#pragma unroll
+        for (int j = 0; j < FN; j += 2) {
+          const int colp = n0 + wn * TN + j * 32;  // packed column of the 'a' group
+          const int col = (colp >> 1) + fi;
+          if (colp + 32 + fi >= g.N) continue;
+          float va = acc[i][j][e], vb = acc[i][j + 1][e];
+          if (g.bias) { va += g.bias[colp + fi]; vb += g.bias[colp + 32 + fi]; }
+          const long rel = orel + col;
+          if (g.out_check && (rel < 0 || rel >= g.out_seg)) continue;
+          ((T*)g.out0)[obase + rel] = Cvt<T>::to(silu_f(va) * vb);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int col = n0 + wn * TN + j * 32 + fi;
+          if (col >= g.N) continue;
+          const long rel = orel + col;
+          if (g.out_check && (rel < 0 || rel >= g.out_seg)) continue;
+          const long off = obase + rel;
+          float v = acc[i][j][e];
+          if (g.bias && ks == 0) v += g.bias[col];
+          if constexpr (EPI == EPI_STORE_F32) {
+            if (rbp) v += rbp[col];
+            ((float*)g.out0)[off] = v;
+          } else if constexpr (EPI == EPI_GATE_RES) {
+            float* x = (float*)g.out0;
+            if (g.ksplit > 1) unsafeAtomicAdd(x + off, v * rbp[col]);  // global_atomic_add_f32
+            else x[off] = x[off] + v * rbp[col];
+          } else if constexpr (EPI == EPI_DAC) {
+            if (g.res) v += g.res[off];
+            if (g.out0) ((float*)g.out0)[off] = v;
+            if (g.out1) ((float*)g.out1)[off] = snake_f(v, sn_a[j], sn_ia[j]);
+          } else {
+            ((T*)g.out0)[off] = Cvt<T>::to(act_epi(v, EPI));
+          }
+        }
+      }
+    }
+  }
+}
+
 struct GemmPair {
   GemmArgs g[2];
   int tiles0;  // workgroups belonging to g[0]; the rest run g[1]
@@ -219,80 +295,196 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmPair pr) {
   }
 #undef FOLEY_GLOAD
 
-  // ------------------------------------------------------------------ epilogue
-  // C/D layout of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
-  const bool plain_out = g.osegV >= g.M;
-  float sn_a[FN], sn_ia[FN];
-  if constexpr (EPI == EPI_DAC) {
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int col = n0 + wn * TN + j * 32 + fi;
-      sn_a[j] = (g.out1 && col < g.N) ? g.alpha[col % g.alphaC] : 1.0f;
-      sn_ia[j] = 1.0f / (sn_a[j] + 1e-9f);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = m0 + wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-      if (row >= g.M) continue;
-      long obase, orel;
-      if (plain_out) {
-        obase = 0;
-        orel = (long)row * g.out_row + g.out_shift;
-      } else {
-        const int b = row / g.osegV, q = row - b * g.osegV;
-        obase = (long)b * g.out_seg;
-        orel = (long)q * g.out_row + g.out_shift;
-      }
-      const float* rbp = nullptr;
-      if constexpr (EPI == EPI_GATE_RES || EPI == EPI_STORE_F32) {
-        if (g.rb.p) rbp = rb_row(g.rb, row);
-      }
-      if constexpr (EPI == EPI_SILUGATE_T) {
-#pragma unroll
-        for (int j = 0; j < FN; j += 2) {
-          const int colp = n0 + wn * TN + j * 32;  // packed column of the 'a' group
-          const int col = (colp >> 1) + fi;
-          if (colp + 32 + fi >= g.N) continue;
-          float va = acc[i][j][e], vb = acc[i][j + 1][e];
-          if (g.bias) { va += g.bias[colp + fi]; vb += g.bias[colp + 32 + fi]; }
-          const long rel = orel + col;
-          if (g.out_check && (rel < 0 || rel >= g.out_seg)) continue;
-          ((T*)g.out0)[obase + rel] = Cvt<T>::to(silu_f(va) * vb);
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          const int col = n0 + wn * TN + j * 32 + fi;
-          if (col >= g.N) continue;
-          const long rel = orel + col;
-          if (g.out_check && (rel < 0 || rel >= g.out_seg)) continue;
-          const long off = obase + rel;
-          float v = acc[i][j][e];
-          if (g.bias && ks == 0) v += g.bias[col];
-          if constexpr (EPI == EPI_STORE_F32) {
-            if (rbp) v += rbp[col];
-            ((float*)g.out0)[off] = v;
-          } else if constexpr (EPI == EPI_GATE_RES) {
-            float* x = (float*)g.out0;
-            if (g.ksplit > 1) unsafeAtomicAdd(x + off, v * rbp[col]);  // global_atomic_add_f32
-            else x[off] = x[off] + v * rbp[col];
-          } else if constexpr (EPI == EPI_DAC) {
-            if (g.res) v += g.res[off];
-            if (g.out0) ((float*)g.out0)[off] = v;
-            if (g.out1) ((float*)g.out1)[off] = snake_f(v, sn_a[j], sn_ia[j]);
-          } else {
-            ((T*)g.out0)[off] = Cvt<T>::to(act_epi(v, EPI));
-          }
-        }
-      }
-    }
-  }
+  gemm_epilogue<T, EPI, FM, FN, TM, TN>(g, acc, m0, n0, wm, wn, fi, kh, ks);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Direct-to-LDS mainloop: K-slices travel HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR
+// staging, no ds_write pass), NS LDS stages deep, one raw s_barrier + one counted vmcnt per slice.
+// The DMA writes lane l of a wave-instruction at (wave-uniform base + 16*l), i.e. 8 unpadded
+// 128-byte rows per instruction, so bank conflicts are avoided by permuting the SOURCE: LDS chunk
+// p of row r holds global chunk p ^ ((r >> 1) & 7); fragment reads apply the same XOR.  Rows
+// that must read as zero (M/N edge, conv padding) fetch from a zero page instead.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void glds16(const void* gptr, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NS, int EPI>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmPair pr) {
+  const int sel = (int)blockIdx.x >= pr.tiles0 ? 1 : 0;
+  const GemmArgs& g = pr.g[sel];
+  constexpr int NW = WM * WN;
+  constexpr int EPC = Frag<T>::EPC;
+  constexpr int BK = 8 * EPC;
+  constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
+  constexpr int AI = BM / 8 / NW, BI = BN / 8 / NW;  // wave-instructions per wave and K-slice
+  constexpr int STAGE = (BM + BN) * 128;
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "bad tile");
+  static_assert(EPI != EPI_SILUGATE_T || (FN % 2 == 0), "gated epilogue needs fragment pairs");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  const int tiles_m = (g.M + BM - 1) / BM;
+  const int tiles_n = (g.N + BN - 1) / BN;
+  int bid = (int)blockIdx.x - (sel ? pr.tiles0 : 0);
+  {
+    const int nwg = tiles_m * tiles_n * (EPI == EPI_GATE_RES ? g.ksplit : 1);
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  int ks = 0;
+  if constexpr (EPI == EPI_GATE_RES) {
+    ks = bid % g.ksplit;
+    bid /= g.ksplit;
+  }
+  const int tm = bid % tiles_m, tn = bid / tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lr = lane >> 3, lp = lane & 7;  // row within the 8-row group, LDS chunk position
+
+  const T* zp = (const T*)g.zeros + lp * EPC;
+  const T* ap[AI];
+  int a_q[AI];
+  bool a_ok[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int rl = (wave * AI + i) * 8 + lr;  // row inside the tile
+    const int r = m0 + rl;
+    a_ok[i] = r < g.M;
+    const int rr = a_ok[i] ? r : 0;
+    const int b = rr / g.segV, q = rr - b * g.segV;
+    ap[i] = (const T*)g.A + ((long)b * g.segS + q) * g.lda + (lp ^ ((rl >> 1) & 7)) * EPC;
+    a_q[i] = q;
+  }
+  const T* wp[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int rl = (wave * BI + i) * 8 + lr;
+    const int n = n0 + rl;
+    wp[i] = (n < g.N) ? (const T*)g.W + (long)n * g.K + (lp ^ ((rl >> 1) & 7)) * EPC : nullptr;
+  }
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int fi = lane & 31, kh = lane >> 5;
+  int kt_begin = 0, nk = g.K / BK;
+  if constexpr (EPI == EPI_GATE_RES) {
+    const int tot = nk;
+    kt_begin = (int)((long)tot * ks / g.ksplit);
+    nk = (int)((long)tot * (ks + 1) / g.ksplit) - kt_begin;
+  }
+  const long tap_step = (long)g.dil * g.lda;
+  int ld_k0 = kt_begin * BK;
+  int ld_c0 = ld_k0, ld_toff = g.tap0;
+  if (kt_begin > 0) {
+    const int tap = ld_k0 / g.tapC;
+    ld_c0 = ld_k0 - tap * g.tapC;
+    ld_toff = g.tap0 + tap * g.dil;
+  }
+  long ld_roff = (long)ld_toff * g.lda;
+
+  auto issue = [&](int stage) {
+    unsigned char* As = lds + stage * STAGE;
+    unsigned char* Bs = As + BM * 128;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const bool in = a_ok[i] && (unsigned)(a_q[i] + ld_toff) < (unsigned)g.segS;
+      const T* src = in ? ap[i] + ld_roff + ld_c0 : zp;
+      glds16(src, As + (wave * AI + i) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const T* src = wp[i] ? wp[i] + ld_k0 : zp;
+      glds16(src, Bs + (wave * BI + i) * 1024);
+    }
+    ld_k0 += BK;
+    ld_c0 += BK;
+    if (ld_c0 >= g.tapC) {
+      ld_c0 = 0;
+      ld_toff += g.dil;
+      ld_roff += tap_step;
+    }
+  };
+
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nk) issue(s);
+
+  // fragment-read swizzle terms (row-dependent, K-independent)
+  int a_row[FM], a_sw[FM], b_row[FN], b_sw[FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    a_row[i] = (wm * TM + i * 32 + fi) * 128;
+    a_sw[i] = ((wm * TM + i * 32 + fi) >> 1) & 7;
+  }
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    b_row[j] = (wn * TN + j * 32 + fi) * 128;
+    b_sw[j] = ((wn * TN + j * 32 + fi) >> 1) & 7;
+  }
+
+  int stage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // slice kt has landed once at most the NS-2 younger slices are still in flight
+    if (kt + NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (AI + BI)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // everyone's part of slice kt is in LDS; stage (kt-1)%NS is free again
+    if (kt + NS - 1 < nk) issue(stage == 0 ? NS - 1 : stage - 1);
+    const unsigned char* As = lds + stage * STAGE;
+    const unsigned char* Bs = As + BM * 128;
+    if constexpr (sizeof(T) == 4) {
+      float a[FM][16], b[FN][16];
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 v = *(const f32x4*)(As + a_row[i] + (((kh * 4 + c) ^ a_sw[i]) << 4));
+          a[i][c * 4 + 0] = v[0]; a[i][c * 4 + 1] = v[1]; a[i][c * 4 + 2] = v[2]; a[i][c * 4 + 3] = v[3];
+        }
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 v = *(const f32x4*)(Bs + b_row[j] + (((kh * 4 + c) ^ b_sw[j]) << 4));
+          b[j][c * 4 + 0] = v[0]; b[j][c * 4 + 1] = v[1]; b[j][c * 4 + 2] = v[2]; b[j][c * 4 + 3] = v[3];
+        }
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        bf16x8 a[FM], b[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) a[i] = *(const bf16x8*)(As + a_row[i] + (((s * 2 + kh) ^ a_sw[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < FN; ++j) b[j] = *(const bf16x8*)(Bs + b_row[j] + (((s * 2 + kh) ^ b_sw[j]) << 4));
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    stage = stage + 1 == NS ? 0 : stage + 1;
+  }
+  gemm_epilogue<T, EPI, FM, FN, TM, TN>(g, acc, m0, n0, wm, wn, fi, kh, ks);
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int NS, int EPI, bool GLDS = false>
 int launch_one(const GemmArgs& g, const GemmArgs* g1, hipStream_t st) {
   auto ntiles = [](const GemmArgs& q) {
     return ((q.M + BM - 1) / BM) * ((q.N + BN - 1) / BN) * (EPI == EPI_GATE_RES ? q.ksplit : 1);
@@ -302,8 +494,11 @@ int launch_one(const GemmArgs& g, const GemmArgs* g1, hipStream_t st) {
   pr.g[1] = g1 ? *g1 : g;
   pr.tiles0 = ntiles(g);
   const int tiles = pr.tiles0 + (g1 ? ntiles(*g1) : 0);
-  constexpr size_t lds = 2 * (size_t)(BM + BN) * LDS_PITCH;
-  auto k = gemm_kernel<T, BM, BN, WM, WN, NS, EPI>;
+  constexpr size_t lds = GLDS ? (size_t)NS * (BM + BN) * 128 : 2 * (size_t)(BM + BN) * LDS_PITCH;
+  void (*k)(const GemmPair);
+  if constexpr (GLDS) k = gemm_glds_kernel<T, BM, BN, WM, WN, NS, EPI>;
+  else k = gemm_kernel<T, BM, BN, WM, WN, NS, EPI>;
+  if (GLDS && (!g.zeros || (g1 && !g1->zeros))) return foley_set_err("GEMM: zero page missing", __FILE__, __LINE__);
   if (lds > 64 * 1024) {
     static bool raised = false;   // per instantiation
     if (!raised) {
@@ -318,19 +513,19 @@ int launch_one(const GemmArgs& g, const GemmArgs* g1, hipStream_t st) {
   return 0;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NS>
+template <typename T, int BM, int BN, int WM, int WN, int NS, bool GLDS = false>
 int launch_tile(const GemmArgs& g, const GemmArgs* g1, int epi, hipStream_t st) {
   switch (epi) {
-    case EPI_STORE_F32: return launch_one<T, BM, BN, WM, WN, NS, EPI_STORE_F32>(g, g1, st);
-    case EPI_STORE_T: return launch_one<T, BM, BN, WM, WN, NS, EPI_STORE_T>(g, g1, st);
-    case EPI_SILU_T: return launch_one<T, BM, BN, WM, WN, NS, EPI_SILU_T>(g, g1, st);
-    case EPI_GELU_T: return launch_one<T, BM, BN, WM, WN, NS, EPI_GELU_T>(g, g1, st);
-    case EPI_GATE_RES: return launch_one<T, BM, BN, WM, WN, NS, EPI_GATE_RES>(g, g1, st);
+    case EPI_STORE_F32: return launch_one<T, BM, BN, WM, WN, NS, EPI_STORE_F32, GLDS>(g, g1, st);
+    case EPI_STORE_T: return launch_one<T, BM, BN, WM, WN, NS, EPI_STORE_T, GLDS>(g, g1, st);
+    case EPI_SILU_T: return launch_one<T, BM, BN, WM, WN, NS, EPI_SILU_T, GLDS>(g, g1, st);
+    case EPI_GELU_T: return launch_one<T, BM, BN, WM, WN, NS, EPI_GELU_T, GLDS>(g, g1, st);
+    case EPI_GATE_RES: return launch_one<T, BM, BN, WM, WN, NS, EPI_GATE_RES, GLDS>(g, g1, st);
     case EPI_SILUGATE_T:
-      if constexpr ((BN / WN) % 64 == 0) return launch_one<T, BM, BN, WM, WN, NS, EPI_SILUGATE_T>(g, g1, st);
+      if constexpr ((BN / WN) % 64 == 0) return launch_one<T, BM, BN, WM, WN, NS, EPI_SILUGATE_T, GLDS>(g, g1, st);
       else return foley_set_err("gated epilogue needs a 64-wide wave tile", __FILE__, __LINE__);
     case EPI_DAC:
-      if constexpr (sizeof(T) == 4) return launch_one<T, BM, BN, WM, WN, NS, EPI_DAC>(g, g1, st);
+      if constexpr (sizeof(T) == 4) return launch_one<T, BM, BN, WM, WN, NS, EPI_DAC, GLDS>(g, g1, st);
       else return foley_set_err("DAC epilogue is fp32 only", __FILE__, __LINE__);
   }
   return foley_set_err("unknown GEMM epilogue", __FILE__, __LINE__);
@@ -377,7 +572,7 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     g.ksplit = 1;   // fp32 (parity) mode keeps a fixed summation order
   } else if (g.ksplit == 0) {
     // fill ~3 workgroups per CU, keep >= 12 K-slices per range
-    static const int bm[5] = {0, 128, 64, 64, 128}, bn[5] = {0, 128, 128, 64, 64};
+    static const int bm[9] = {0, 128, 64, 64, 128, 128, 64, 128, 64}, bn[9] = {0, 128, 128, 64, 64, 128, 64, 128, 128};
     const long blocks = (long)((g.M + bm[tile] - 1) / bm[tile]) * ((g.N + bn[tile] - 1) / bn[tile]);
     const int nk = g.K / BK;
     long want = (768 + blocks - 1) / blocks;
@@ -390,6 +585,13 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     case 2: return launch_tile<T, 64, 128, 2, 2, 3>(g, g1, epi, st);
     case 3: return launch_tile<T, 64, 64, 2, 2, 4>(g, g1, epi, st);
     case 4: return launch_tile<T, 128, 64, 4, 1, 3>(g, g1, epi, st);
+    // direct-to-LDS mainloop
+    case 5: return launch_tile<T, 128, 128, 4, 2, 4, true>(g, g1, epi, st);
+    case 6: return launch_tile<T, 64, 64, 2, 2, 4, true>(g, g1, epi, st);
+    case 7:
+      if constexpr (sizeof(T) == 2) return launch_tile<T, 128, 128, 2, 2, 4, true>(g, g1, epi, st);
+      else return foley_set_err("GEMM: tile 7 is bf16 only", __FILE__, __LINE__);
+    case 8: return launch_tile<T, 64, 128, 2, 2, 4, true>(g, g1, epi, st);
   }
   return foley_set_err("GEMM: bad tile id", __FILE__, __LINE__);
 }

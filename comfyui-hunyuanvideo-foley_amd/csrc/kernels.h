@@ -42,6 +42,7 @@ struct GemmArgs {
   const float* res;   // EPI_DAC residual (same mapping as out0) or null
   const float* alpha; // EPI_DAC snake alpha, indexed n % alphaC
   int alphaC;
+  const void* zeros;  // >= 128 zero bytes in global memory (source of masked rows for the direct-to-LDS loop)
   int ksplit;         // EPI_GATE_RES only: K is cut into `ksplit` ranges whose partial products are
                       // accumulated with hardware fp32 atomics (0 = auto; 1 = deterministic)
 };

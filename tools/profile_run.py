@@ -20,21 +20,23 @@ ap.add_argument("--precision", default="bf16")
 ap.add_argument("--model", default="xxl")
 ap.add_argument("--graph", action="store_true")
 ap.add_argument("--no-dac", action="store_true")
+ap.add_argument("--duration", type=float, default=5.0)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = C.dit_config(a.model)
 dtype = packers.torch_dtype(a.precision)
 sd = synth.synth_dit_state_dict(cfg, device=dev)
-cond = synth.synth_conditioning(cfg, 5.0, t2a=True, sd=sd, device=dev)
+cond = synth.synth_conditioning(cfg, a.duration, t2a=True, sd=sd, device=dev)
+LA = int(a.duration * 50)
 model = sampler.FoleyModel(cfg, sd, dtype, dev)
 del sd
 dac = sampler.FoleyDAC(synth.synth_dac_state_dict(C.DAC48K, device=dev), dev)
 model.attach_dac(dac)
 plan = sampler.build_plan(model, {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]},
-                          {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]}, 250, 4.5, a.iters,
+                          {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]}, LA, 4.5, a.iters,
                           a.bs, "euler")
 model.ctx.prepare(plan)
-lat = torch.randn(a.bs, 128, 250, device=dev)
+lat = torch.randn(a.bs, 128, LA, device=dev)
 model.ctx.sample(lat, use_graph=a.graph)
 torch.cuda.synchronize()
 print("loop ms/iter:", model.ctx.last_elapsed_ms() / a.iters)
