@@ -109,7 +109,7 @@ struct GemmPair {
   int tiles0;  // workgroups belonging to g[0]; the rest run g[1]
 };
 
-template <typename T, int BM, int BN, int WM, int WN, int NS, int EPI>
+template <typename T, int BM, int BN, int WM, int WN, int NS, int EPI, bool CONV>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmPair pr) {
   const int sel = (int)blockIdx.x >= pr.tiles0 ? 1 : 0;  // wave-uniform
   const GemmArgs& g = pr.g[sel];
@@ -156,7 +156,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmPair pr) {
     const int r = m0 + lrow + i * RPP;
     a_ok[i] = r < g.M;
     const int rr = a_ok[i] ? r : 0;
-    const int b = rr / g.segV, q = rr - b * g.segV;
+    int b = 0, q = rr;
+    if constexpr (CONV) {
+      b = rr / g.segV;
+      q = rr - b * g.segV;
+    }
     ap[i] = (const T*)g.A + ((long)b * g.segS + q) * g.lda + chunk * EPC;
     a_q[i] = q;
   }
@@ -171,6 +175,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmPair pr) {
 
   u32x4 ra[NS][RA], rw[NS][RB];  // register ring: NS-1 K-slices in flight
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  constexpr bool DUAL = (FM * FN == 1) && sizeof(T) == 2;
+  f32x16 acc2;
+  if constexpr (DUAL) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
+  }
   f32x16 acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
@@ -202,16 +212,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmPair pr) {
 #define FOLEY_GLOAD(slot)                                                                  \
   {                                                                                        \
     _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                       \
-      const bool in_ = (unsigned)(a_q[i] + ld_toff) < (unsigned)g.segS;                    \
-      ra[slot][i] = *(const u32x4*)(ap[i] + (in_ ? ld_roff : 0L) + ld_c0);                 \
+      if constexpr (CONV) {                                                                \
+        const bool in_ = (unsigned)(a_q[i] + ld_toff) < (unsigned)g.segS;                  \
+        ra[slot][i] = *(const u32x4*)(ap[i] + (in_ ? ld_roff : 0L) + ld_c0);               \
+      } else {                                                                             \
+        ra[slot][i] = *(const u32x4*)(ap[i] + ld_k0);                                      \
+      }                                                                                    \
     }                                                                                      \
     _Pragma("unroll") for (int i = 0; i < RB; ++i) rw[slot][i] = *(const u32x4*)(wp[i] + ld_k0); \
     ld_k0 += BK;                                                                           \
-    ld_c0 += BK;                                                                           \
-    if (ld_c0 >= g.tapC) {                                                                 \
-      ld_c0 = 0;                                                                           \
-      ld_toff += g.dil;                                                                    \
-      ld_roff += tap_step;                                                                 \
+    if constexpr (CONV) {                                                                  \
+      ld_c0 += BK;                                                                         \
+      if (ld_c0 >= g.tapC) {                                                               \
+        ld_c0 = 0;                                                                         \
+        ld_toff += g.dil;                                                                  \
+        ld_roff += tap_step;                                                               \
+      }                                                                                    \
     }                                                                                      \
   }
 
@@ -229,13 +245,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmPair pr) {
         unsigned char* Bs = As + BM * LDS_PITCH;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-          const bool v = a_ok[i] && (unsigned)(a_q[i] + wr_toff) < (unsigned)g.segS;
+          bool v = a_ok[i];
+          if constexpr (CONV) v = v && (unsigned)(a_q[i] + wr_toff) < (unsigned)g.segS;
           *(u32x4*)(As + (lrow + i * RPP) * LDS_PITCH + chunk * 16) = v ? ra[j][i] : zero4;
         }
-        wr_c0 += BK;
-        if (wr_c0 >= g.tapC) {
-          wr_c0 = 0;
-          wr_toff += g.dil;
+        if constexpr (CONV) {
+          wr_c0 += BK;
+          if (wr_c0 >= g.tapC) {
+            wr_c0 = 0;
+            wr_toff += g.dil;
+          }
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i)
@@ -283,17 +302,28 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmPair pr) {
 #pragma unroll
             for (int jj = 0; jj < FN; ++jj)
               b[jj] = *(const bf16x8*)(Bs + (wn * TN + jj * 32 + fi) * LDS_PITCH + s * 32 + kh * 16);
+            if constexpr (DUAL) {
+              // single-fragment wave tile: alternate two accumulators so consecutive MFMAs do not
+              // wait for each other's 16-pass latency
+              if (s & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc2, 0, 0, 0);
+              else acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc[0][0], 0, 0, 0);
+            } else {
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
+              for (int i = 0; i < FM; ++i)
 #pragma unroll
-              for (int jj = 0; jj < FN; ++jj)
-                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[jj], acc[i][jj], 0, 0, 0);
+                for (int jj = 0; jj < FN; ++jj)
+                  acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[jj], acc[i][jj], 0, 0, 0);
+            }
           }
         }
       }
     }
   }
 #undef FOLEY_GLOAD
+  if constexpr (DUAL) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[0][0][e] += acc2[e];
+  }
 
   gemm_epilogue<T, EPI, FM, FN, TM, TN>(g, acc, m0, n0, wm, wn, fi, kh, ks);
 }
@@ -465,19 +495,23 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmPair p
           for (int j = 0; j < FN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
     } else {
+      // all fragment reads of the slice are issued up front so the MFMAs run back to back behind
+      // counted lgkmcnt waits (LDS latency hidden behind the matrix pipe instead of serialised)
+      bf16x8 a[4][FM], b[4][FN];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        bf16x8 a[FM], b[FN];
 #pragma unroll
-        for (int i = 0; i < FM; ++i) a[i] = *(const bf16x8*)(As + a_row[i] + (((s * 2 + kh) ^ a_sw[i]) << 4));
+        for (int i = 0; i < FM; ++i) a[s][i] = *(const bf16x8*)(As + a_row[i] + (((s * 2 + kh) ^ a_sw[i]) << 4));
 #pragma unroll
-        for (int j = 0; j < FN; ++j) b[j] = *(const bf16x8*)(Bs + b_row[j] + (((s * 2 + kh) ^ b_sw[j]) << 4));
+        for (int j = 0; j < FN; ++j) b[s][j] = *(const bf16x8*)(Bs + b_row[j] + (((s * 2 + kh) ^ b_sw[j]) << 4));
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
           for (int j = 0; j < FN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-      }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
     }
     stage = stage + 1 == NS ? 0 : stage + 1;
   }
@@ -496,15 +530,17 @@ int launch_one(const GemmArgs& g, const GemmArgs* g1, hipStream_t st) {
   const int tiles = pr.tiles0 + (g1 ? ntiles(*g1) : 0);
   constexpr size_t lds = GLDS ? (size_t)NS * (BM + BN) * 128 : 2 * (size_t)(BM + BN) * LDS_PITCH;
   void (*k)(const GemmPair);
+  const bool conv = g.taps > 1 || (g1 && g1->taps > 1);
   if constexpr (GLDS) k = gemm_glds_kernel<T, BM, BN, WM, WN, NS, EPI>;
-  else k = gemm_kernel<T, BM, BN, WM, WN, NS, EPI>;
+  else k = conv ? gemm_kernel<T, BM, BN, WM, WN, NS, EPI, true> : gemm_kernel<T, BM, BN, WM, WN, NS, EPI, false>;
   if (GLDS && (!g.zeros || (g1 && !g1->zeros))) return foley_set_err("GEMM: zero page missing", __FILE__, __LINE__);
   if (lds > 64 * 1024) {
-    static bool raised = false;   // per instantiation
-    if (!raised) {
+    static bool raised[2] = {false, false};   // per instantiation (plain / conv kernel)
+    bool& r_ = raised[conv ? 1 : 0];
+    if (!r_) {
       hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);
-      raised = true;
+      r_ = true;
     }
   }
   hipLaunchKernelGGL(k, dim3(tiles), dim3(WM * WN * 64), lds, st, pr);
@@ -564,8 +600,8 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     const long b128 = nblk(128, 128);
     const long rem = b128 % 256;
     if (g.N <= 64 && epi != EPI_SILUGATE_T) tile = nblk(128, 64) >= 192 ? 4 : 3;
-    else if (b128 >= 100 && (b128 <= 256 || rem == 0 || rem >= 128 || b128 >= 2048)) tile = 1;
-    else if (epi == EPI_SILUGATE_T) tile = nblk(64, 128) >= 192 ? 2 : 1;
+    else if (b128 >= 100 && (b128 <= 256 || rem == 0 || rem >= 128 || b128 >= 2048)) tile = 5;
+    else if (epi == EPI_SILUGATE_T) tile = nblk(64, 128) >= 192 ? 2 : 5;
     else tile = 3;
   }
   if (epi != EPI_GATE_RES || g.ksplit == 1 || (g.ksplit == 0 && sizeof(T) == 4)) {

@@ -40,6 +40,8 @@ def _q(t, dtype):   # round a CPU reference operand through the compute dtype
 @pytest.mark.parametrize("M,N,K,tile", [
     (500, 1536, 1536, 0), (500, 1536, 1536, 1), (500, 1536, 1536, 2), (500, 1536, 1536, 3),
     (37, 200, 256, 0), (130, 128, 128, 0), (10, 13824, 1536, 0), (4000, 64, 128, 4), (77, 3072, 768, 0),
+    (500, 1536, 1536, 5), (500, 1536, 1536, 6), (500, 1536, 1536, 8), (37, 200, 256, 6), (130, 192, 128, 5),
+    (700, 640, 4608, 5),
 ])
 def test_gemm_linear(dev, dtype, M, N, K, tile):
     A, W, b = _rand((M, K), 1), _rand((N, K), 2, 1 / math.sqrt(K)), _rand((N,), 3, 0.1)
@@ -50,13 +52,15 @@ def test_gemm_linear(dev, dtype, M, N, K, tile):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_gemm_transpose_detecting(dev, dtype):
-    """A = I with an asymmetric W: catches a swapped C/D row/column mapping."""
+@pytest.mark.parametrize("tile", [0, 3, 5, 6])
+def test_gemm_transpose_detecting(dev, dtype, tile):
+    """A = I with an asymmetric W: catches a swapped C/D row/column mapping (and, for the
+    direct-to-LDS loop, any mismatch between the source swizzle and the fragment-read swizzle)."""
     K = 128
     A = torch.eye(K)
     W = torch.arange(192 * K, dtype=torch.float32).view(192, K) % 251 / 16.0
     out = torch.empty(K, 192, device=dev)
-    rt.op_gemm(A.to(dev, dtype), W.to(dev, dtype), None, out0=out)
+    rt.op_gemm(A.to(dev, dtype), W.to(dev, dtype), None, out0=out, tile=tile)
     assert torch.equal(out.cpu(), W.t().contiguous())
 
 
@@ -124,14 +128,16 @@ def test_gemm_split_k(dev, ksplit, conv):
 
 # ----------------------------------------------------------------------------- GEMM: conv addressing
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("tile", [0, 3, 5, 6])
 @pytest.mark.parametrize("B,L,Cin,Cout", [(2, 50, 256, 384), (3, 7, 128, 64), (1, 250, 1536, 256)])
-def test_conv3_channels_last(dev, dtype, B, L, Cin, Cout):
-    """ChannelLastConv1d k=3 pad=1 (mlp_layers.py:104-110) as a GEMM over overlapping rows."""
+def test_conv3_channels_last(dev, dtype, tile, B, L, Cin, Cout):
+    """ChannelLastConv1d k=3 pad=1 (mlp_layers.py:104-110) as a GEMM over overlapping rows
+    (register-staged and direct-to-LDS mainloops)."""
     x, w, b = _rand((B, L, Cin), 10), _rand((Cout, Cin, 3), 11, 1 / math.sqrt(3 * Cin)), _rand((Cout,), 12, 0.1)
     ref = O.conv1d_cl(_q(x, dtype), _q(w, dtype), b, 1).reshape(B * L, Cout)
     out = torch.empty(B * L, Cout, device=dev)
     rt.op_gemm(x.reshape(B * L, Cin).to(dev, dtype), packers.conv_to_gemm(w).to(dev, dtype), b.to(dev),
-               out0=out, conv=(L, Cin, 3, 1))
+               out0=out, conv=(L, Cin, 3, 1), tile=tile)
     assert rel_err(out, ref) < _tol(dtype)
 
 
