@@ -83,7 +83,7 @@ struct foley_ctx {
   void* hid_a = nullptr;            // T [M, max(mlp_hidden, conv_hidden)]
   void* hid_v = nullptr;            // T [Mv, mlp_hidden]
   void* svec = nullptr;             // T [ncfg*La, D]
-  float* smod = nullptr;            // [ncfg*La, 6D]
+  float* smod = nullptr;            // [n_single][ncfg*La, 6D]
   float* pred = nullptr;            // [M, C]
   float* x_saved = nullptr;         // [clips, C, La]
   float* d_acc = nullptr;
@@ -98,6 +98,11 @@ struct foley_ctx {
   // graph: one captured loop iteration; valid while the workspace and weights stay put
   hipGraphExec_t graph_exec = nullptr;
   float graph_guidance = 0.f;
+  // side stream: work that depends only on the iteration index (single-block AdaLN GEMMs) overlaps
+  // the latent-dependent chain; joined through events (also inside the captured graph)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr;
+  std::vector<hipEvent_t> ev_mod;
   // timing
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
@@ -253,6 +258,10 @@ extern "C" int foley_ctx_create(int device, const foley_config* cfg, foley_ctx**
   c->cfg = *cfg;
   (void)hipEventCreate(&c->ev0);
   (void)hipEventCreate(&c->ev1);
+  (void)hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+  (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+  c->ev_mod.resize(cfg->depth_single);
+  for (auto& e : c->ev_mod) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
   *out = c;
   return 0;
 }
@@ -265,6 +274,9 @@ extern "C" void foley_ctx_destroy(foley_ctx* c) {
     if (b->p) hipFree(b->p);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
+  if (c->side) hipStreamDestroy(c->side);
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
+  for (auto e : c->ev_mod) hipEventDestroy(e);
   delete c;
 }
 
@@ -341,7 +353,7 @@ extern "C" int foley_prepare(foley_ctx* c, const foley_plan* pl, void* stream_v)
     ALLOC(c->hid_a, (size_t)M * hidmax * es);
     ALLOC(c->hid_v, (size_t)Mv * f.mlp_hidden * es);
     ALLOC(c->svec, (size_t)ncfg * La * D * es);
-    ALLOC(c->smod, (size_t)ncfg * La * 6 * D * 4);
+    ALLOC(c->smod, (size_t)f.depth_single * ncfg * La * 6 * D * 4);
     ALLOC(c->pred, (size_t)M * C * 4);
     ALLOC(c->x_saved, (size_t)clips * C * La * 4);
     ALLOC(c->d_acc, (size_t)clips * C * La * 4);
@@ -473,6 +485,23 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
   const int Sp = (S + 31) & ~31, Lap = (La + 31) & ~31;  // V^T row pitches (bf16 attention)
   const int* sp = c->step_ctr;
 
+  // ---- side stream: per-token conditioning of the single-stream blocks, SiLU(add_sync + vec)
+  // (hifi_foley.py:866-867), and every single block's modulation GEMM (hifi_foley.py:366).  They
+  // depend on the iteration only, and are identical for every clip of a CFG half (M = ncfg*La).
+  {
+    hipStream_t sd = c->side;
+    HIPTRY(hipEventRecord(c->ev_fork, st));
+    HIPTRY(hipStreamWaitEvent(sd, c->ev_fork, 0));
+    TRY(launch_rows_add_act(c->add_sync, rb_vec(c->vec_table, D, sp), ncfg * La, D, 1, c->svec, T, sd));
+    for (int blk = 0; blk < f.depth_single; ++blk) {
+      Lin mod;
+      TRY(get_lin(c, "s" + std::to_string(blk) + ".mod", T, 6 * D, D, true, &mod));
+      float* dst = c->smod + (size_t)blk * ncfg * La * 6 * D;
+      TRY(launch_gemm(gemm_plain(c->svec, ncfg * La, mod, dst, 6 * D), T, EPI_STORE_F32, 0, sd));
+      HIPTRY(hipEventRecord(c->ev_mod[blk], sd));
+    }
+  }
+
   // audio_embedder (conv k=1 == linear over the transposed latents) + add_sync (hifi_foley.py:768, 838-839)
   {
     Lin ain;
@@ -577,23 +606,20 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
     }
   }
 
-  // per-token conditioning of the single-stream blocks: SiLU(add_sync + vec) (hifi_foley.py:866-867, modulate_layers.py:15-16)
-  TRY(launch_rows_add_act(c->add_sync, rb_vec(c->vec_table, D, sp), ncfg * La, D, 1, c->svec, T, st));
   const int Hc = f.conv_hidden;
   for (int blk = 0; blk < f.depth_single; ++blk) {
     const std::string p = "s" + std::to_string(blk) + ".";
-    Lin mod, qkv, lin1, w13, w2;
+    Lin qkv, lin1, w13, w2;
     const void *qn, *kn;
-    TRY(get_lin(c, p + "mod", T, 6 * D, D, true, &mod));
     TRY(get_lin(c, p + "qkv", T, 3 * D, D, true, &qkv));
     TRY(get_lin(c, p + "lin1", T, D, 3 * D, true, &lin1));
     TRY(get_lin(c, p + "w13", T, 2 * Hc, 3 * D, false, &w13));
     TRY(get_lin(c, p + "w2", T, D, 3 * Hc, false, &w2));
     TRY(get_tensor(c, p + "qn", FOLEY_F32, {128}, &qn));
     TRY(get_tensor(c, p + "kn", FOLEY_F32, {128}, &kn));
-    auto sm = [&](int chunk) { return rb_tok(c->smod + (size_t)chunk * D, 6L * D, clips * La, La); };
-    // modulation is identical for every clip of a CFG half => M = ncfg*La rows only
-    TRY(launch_gemm(gemm_plain(c->svec, ncfg * La, mod, c->smod, 6 * D), T, EPI_STORE_F32, 0, st));
+    const float* smod_b = c->smod + (size_t)blk * ncfg * La * 6 * D;
+    auto sm = [&](int chunk) { return rb_tok(smod_b + (size_t)chunk * D, 6L * D, clips * La, La); };
+    HIPTRY(hipStreamWaitEvent(st, c->ev_mod[blk], 0));   // join: this block's modulation table is ready
     TRY(launch_ln_mod(c->audio, M, D, 1e-5f, sm(0), sm(1), c->xn_a, T, st));
     TRY(launch_gemm(gemm_plain(c->xn_a, M, qkv, c->qkv_a, 3 * D), T, EPI_STORE_F32, 0, st));
     QkvSplitArgs q{};
