@@ -94,7 +94,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and os.environ.get("FOLEY_BENCH_FORCE_DIST"))
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
@@ -115,7 +116,7 @@ def main():
         dac_arena = packers.Arena.from_packed(packers.pack_dac(dsd, C.DAC48K), dev)
     else:
         cond = dit_arena = dac_arena = None
-    if world > 1:
+    if use_dist:
         dit_arena = D.broadcast_arena(dit_arena, dev)
         dac_arena = D.broadcast_arena(dac_arena, dev)
         cond = D.broadcast_tensors(cond, dev)
@@ -137,7 +138,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
@@ -158,7 +159,7 @@ def main():
     model.ctx.dac_decode(torch.zeros(a.bs, cfg.latent_dim, la, device=dev))
     torch.cuda.synchronize()
     dac_ms = model.ctx.last_elapsed_ms()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -196,7 +197,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline and a.model == "xxl":
             out["cpu_baseline"] = cpu_baseline(sd, dsd, cfg, cond, noise_all)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         torch.distributed.destroy_process_group()
 
 

@@ -81,15 +81,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_exp_kernel(const GemmArgs g)
     for (int j = 0; j < NS; ++j) {
       const int kt = kt0 + j;
       if (kt < nk) {
-        if (kt + NS - 1 < nk) GLOAD((j + NS - 1) % NS, kt + NS - 1);
+        if (ROT < 3) { if (kt + NS - 1 < nk) GLOAD((j + NS - 1) % NS, kt + NS - 1); }
         unsigned char* As = lds + (LB == 2 ? (kt & 1) * STAGE : 0);
         unsigned char* Bs = As + BM * PITCH;
         if (LB == 1) __syncthreads();
+        if (ROT < 4 || kt == 0) {
 #pragma unroll
-        for (int i = 0; i < RA; ++i) *(u32x4*)(As + (lrow + i * RPP) * PITCH + chunk * 16) = a_ok[i] ? ra[j][i] : zero4;
+        for (int i = 0; i < RA; ++i) *(u32x4*)(As + (lrow + i * RPP) * PITCH + chunk * 16) = a_ok[i] ? ra[ROT >= 3 ? 0 : j][i] : zero4;
 #pragma unroll
-        for (int i = 0; i < RB; ++i) *(u32x4*)(Bs + (lrow + i * RPP) * PITCH + chunk * 16) = w_ok[i] ? rw[j][i] : zero4;
+        for (int i = 0; i < RB; ++i) *(u32x4*)(Bs + (lrow + i * RPP) * PITCH + chunk * 16) = w_ok[i] ? rw[ROT >= 3 ? 0 : j][i] : zero4;
         __syncthreads();
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           bf16x8 a[FM], b[FN];
@@ -157,6 +159,10 @@ int launch_gemm_exp(const GemmArgs& g, int code, hipStream_t st) {
     case 231: return launch_exp<128, 128, 2, 2, 4, 2, 1>(g, st);
     case 301: return launch_exp<128, 128, 2, 2, 2, 1, 2>(g, st);   // rotation per workgroup
     case 321: return launch_exp<128, 128, 2, 2, 3, 2, 2>(g, st);
+    case 433: return launch_exp<64, 64, 2, 2, 4, 2, 3>(g, st);     // ablation: no global loads in the loop
+    case 533: return launch_exp<64, 64, 2, 2, 4, 2, 4>(g, st);     // ablation: + no LDS writes / barriers
+    case 437: return launch_exp<128, 128, 4, 2, 4, 2, 3>(g, st);
+    case 537: return launch_exp<128, 128, 4, 2, 4, 2, 4>(g, st);
     case 203: return launch_exp<64, 64, 2, 2, 2, 1, 1>(g, st);
     case 223: return launch_exp<64, 64, 2, 2, 3, 2, 1>(g, st);
     case 323: return launch_exp<64, 64, 2, 2, 3, 2, 2>(g, st);

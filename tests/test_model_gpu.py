@@ -186,3 +186,75 @@ def test_c1_xxl_golden(dev):
     print("waveform rel err: %.3e" % werr)
     assert max(errs) < 1e-4
     assert werr < 1e-3
+
+
+def test_xl_dimensions_forward(dev):
+    """The xl model family (D=1408, 11 heads: N/K not multiples of 128/256) at depth 1+1 against the
+    oracle - exercises the N-edge masking of every GEMM tile and the 11-head split."""
+    c = C.DiTConfig(name="xl-1-1", depth_triple=1, depth_single=1, hidden=1408, heads=11)
+    sd = synth.synth_dit_state_dict(c)
+    model = sampler.FoleyModel(c, sd, torch.float32, dev)
+    g = torch.Generator().manual_seed(17)
+    La, Lv, Ls = C.lengths(1.5, c)
+    x = torch.randn(1, 128, La, generator=g)
+    t = torch.tensor([500.0])
+    cond, clip, sync = torch.randn(1, 77, 768, generator=g), torch.randn(1, Lv, 768, generator=g), torch.randn(1, Ls, 768, generator=g)
+    y = _forward(model, x, t, cond, clip, sync)
+    with torch.inference_mode():
+        ref = O.dit_forward(sd, c.heads, x, t, cond, clip, sync)
+    assert rel_err(y, ref) < 2e-5
+    # and the bf16 throughput mode of the same model
+    model16 = sampler.FoleyModel(c, sd, torch.bfloat16, dev)
+    y16 = _forward(model16, x.to(torch.bfloat16).float(), t, cond, clip, sync)
+    assert rel_err(y16, ref) < 4e-2
+
+
+def test_fp8_weight_only_loader(dev):
+    """Config C5 semantics (reference utils.py:316-485): every >=2-D weight is rounded
+    through fp8 (plain cast, no scales), biases/gains untouched, compute in bf16.  Checked against
+    the oracle run on the same fp8-rounded weights."""
+    from foley_amd import nodes
+    c = C.TINY
+    sd = synth.synth_dit_state_dict(c)
+    for q in ("fp8_e4m3fn", "fp8_e5m2"):
+        model = nodes.HunyuanModelLoader.pack_state_dict(sd, "bf16", q, device=dev, cfg=c)
+        assert model.quantization == q and model.dtype == torch.bfloat16
+        qd = torch.float8_e4m3fn if q == "fp8_e4m3fn" else torch.float8_e5m2
+        sdq = {k: (v.to(qd).float() if v.dim() >= 2 else v) for k, v in sd.items()}
+        g = golden("g5_dit_tiny")
+        x, t, cond, clip, sync = (g["a_" + k] for k in ("x", "t", "cond", "clip", "sync"))
+        xq = x.to(torch.bfloat16).float()
+        y = _forward(model, xq, t, cond, clip, sync)
+        with torch.inference_mode():
+            ref = O.dit_forward(sdq, c.heads, xq, t, cond, clip, sync)
+        assert rel_err(y, ref) < 4e-2, q
+    # a checkpoint that already stores fp8 tensors is honoured by quantization="auto"
+    sd8 = {k: (v.to(torch.float8_e4m3fn) if v.dim() >= 2 else v) for k, v in sd.items()}
+    m = nodes.HunyuanModelLoader.pack_state_dict(sd8, "auto", "auto", device=dev, cfg=c)
+    assert m.quantization == "fp8_e4m3fn" and m.dtype == torch.bfloat16
+
+
+def test_sampler_node_end_to_end(dev):
+    """HunyuanFoleySampler.generate_audio with injected conditioning: AUDIO dict shapes / dtypes /
+    device of the reference node (nodes.py:420-427) and seed determinism."""
+    from foley_amd import nodes
+    c = C.TINY
+    sd = synth.synth_dit_state_dict(c)
+    model = sampler.FoleyModel(c, sd, torch.float32, dev, dac_cfg=C.DAC_TINY)
+    deps = nodes.AttributeDict(dac_model=sampler.FoleyDAC(synth.synth_dac_state_dict(C.DAC_TINY), dev, C.DAC_TINY))
+    cond = synth.synth_conditioning(c, 1.0, t2a=True, sd=sd)
+    feats = {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"], "text_feat": cond["text"],
+             "uncond_text_feat": cond["uncond_text"]}
+    node = nodes.HunyuanFoleySampler()
+    kw = dict(frame_rate=16, duration=1.0, prompt="x", negative_prompt="y", cfg_scale=4.5, steps=10, sampler="euler",
+              batch_size=2, seed=55574, force_offload=True, torch_compile_cfg={"backend": "inductor"},
+              block_swap_args={"blocks_to_swap": 30}, features=feats)
+    first, batch = node.generate_audio(model, deps, **kw)
+    assert first["sample_rate"] == 48000 and first["waveform"].shape == (1, 1, 48000)
+    assert batch["waveform"].shape == (2, 1, 48000) and batch["waveform"].dtype == torch.float32
+    assert batch["waveform"].device.type == "cpu" and torch.equal(first["waveform"][0], batch["waveform"][0])
+    _f2, batch2 = node.generate_audio(model, deps, **kw)
+    assert rel_err(batch2["waveform"], batch["waveform"]) < 1e-6
+    kw["seed"] = 1
+    _f3, batch3 = node.generate_audio(model, deps, **kw)
+    assert rel_err(batch3["waveform"], batch["waveform"]) > 1e-2
