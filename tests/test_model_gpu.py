@@ -230,8 +230,11 @@ def test_fp8_weight_only_loader(dev):
         assert rel_err(y, ref) < 4e-2, q
     # a checkpoint that already stores fp8 tensors is honoured by quantization="auto"
     sd8 = {k: (v.to(torch.float8_e4m3fn) if v.dim() >= 2 else v) for k, v in sd.items()}
-    m = nodes.HunyuanModelLoader.pack_state_dict(sd8, "auto", "auto", device=dev, cfg=c)
+    m = nodes.HunyuanModelLoader.pack_state_dict(sd8, "bf16", "auto", device=dev, cfg=c)
     assert m.quantization == "fp8_e4m3fn" and m.dtype == torch.bfloat16
+    # precision="auto" looks at bf16/fp16/fp32 tensors only (reference utils.py:507-515): here the
+    # fp32 biases dominate, exactly as the reference would decide
+    assert nodes.detect_ckpt_major_precision(sd8) == torch.float32
 
 
 def test_sampler_node_end_to_end(dev):
