@@ -83,7 +83,7 @@ struct foley_ctx {
   void* hid_a = nullptr;            // T [M, max(mlp_hidden, conv_hidden)]
   void* hid_v = nullptr;            // T [Mv, mlp_hidden]
   void* svec = nullptr;             // T [ncfg*La, D]
-  float* smod = nullptr;            // [n_single][ncfg*La, 6D]
+  float* smod = nullptr;            // [ncfg*La, n_single*6D]
   float* pred = nullptr;            // [M, C]
   float* x_saved = nullptr;         // [clips, C, La]
   float* d_acc = nullptr;
@@ -493,12 +493,12 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
     HIPTRY(hipEventRecord(c->ev_fork, st));
     HIPTRY(hipStreamWaitEvent(sd, c->ev_fork, 0));
     TRY(launch_rows_add_act(c->add_sync, rb_vec(c->vec_table, D, sp), ncfg * La, D, 1, c->svec, T, sd));
-    for (int blk = 0; blk < f.depth_single; ++blk) {
+    if (f.depth_single > 0) {
+      // one GEMM for all blocks: [ncfg*La, D] x [n_single*6D, D]^T -> smod [ncfg*La, n_single*6D]
       Lin mod;
-      TRY(get_lin(c, "s" + std::to_string(blk) + ".mod", T, 6 * D, D, true, &mod));
-      float* dst = c->smod + (size_t)blk * ncfg * La * 6 * D;
-      TRY(launch_gemm(gemm_plain(c->svec, ncfg * La, mod, dst, 6 * D), T, EPI_STORE_F32, 0, sd));
-      HIPTRY(hipEventRecord(c->ev_mod[blk], sd));
+      TRY(get_lin(c, "smod_all", T, f.depth_single * 6 * D, D, true, &mod));
+      TRY(launch_gemm(gemm_plain(c->svec, ncfg * La, mod, c->smod, (long)f.depth_single * 6 * D), T, EPI_STORE_F32, 0, sd));
+      HIPTRY(hipEventRecord(c->ev_mod[0], sd));
     }
   }
 
@@ -617,9 +617,9 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
     TRY(get_lin(c, p + "w2", T, D, 3 * Hc, false, &w2));
     TRY(get_tensor(c, p + "qn", FOLEY_F32, {128}, &qn));
     TRY(get_tensor(c, p + "kn", FOLEY_F32, {128}, &kn));
-    const float* smod_b = c->smod + (size_t)blk * ncfg * La * 6 * D;
-    auto sm = [&](int chunk) { return rb_tok(smod_b + (size_t)chunk * D, 6L * D, clips * La, La); };
-    HIPTRY(hipStreamWaitEvent(st, c->ev_mod[blk], 0));   // join: this block's modulation table is ready
+    const float* smod_b = c->smod + (size_t)blk * 6 * D;   // column block of the fused table
+    auto sm = [&](int chunk) { return rb_tok(smod_b + (size_t)chunk * D, 6L * D * f.depth_single, clips * La, La); };
+    if (blk == 0) HIPTRY(hipStreamWaitEvent(st, c->ev_mod[0], 0));   // join: the modulation table is ready
     TRY(launch_ln_mod(c->audio, M, D, 1e-5f, sm(0), sm(1), c->xn_a, T, st));
     TRY(launch_gemm(gemm_plain(c->xn_a, M, qkv, c->qkv_a, 3 * D), T, EPI_STORE_F32, 0, st));
     QkvSplitArgs q{};

@@ -93,9 +93,15 @@ def pack_dit(sd: Dict[str, Tensor], cfg: DiTConfig, dtype: torch.dtype) -> "Orde
             lin(p + n, r + m)
         for n, m in _TRIPLE_GAINS:
             out[p + n] = _f32(sd[r + m + ".weight"])
+    # All single-block AdaLN projections consume the same per-token conditioning, so they are
+    # packed as ONE [n_single*6D, D] matrix: a single large GEMM per loop iteration.
+    if cfg.depth_single:
+        mat("smod_all", torch.cat([sd[f"single_blocks.{b}.modulation.linear.weight"].float()
+                                   for b in range(cfg.depth_single)], dim=0))
+        out["smod_all.b"] = torch.cat([_f32(sd[f"single_blocks.{b}.modulation.linear.bias"])
+                                       for b in range(cfg.depth_single)], dim=0).contiguous()
     for b in range(cfg.depth_single):
         p, r = f"s{b}.", f"single_blocks.{b}."
-        lin(p + "mod", r + "modulation.linear")
         mat(p + "qkv", qkv_hdk_to_khd(sd[r + "linear_qkv.weight"].float(), H))
         out[p + "qkv.b"] = _f32(qkv_hdk_to_khd(sd[r + "linear_qkv.bias"].float(), H))
         out[p + "qn"] = _f32(sd[r + "q_norm.weight"])

@@ -105,6 +105,9 @@ def test_pack_dit_and_arena_roundtrip():
     D, Hc = cfg.hidden, cfg.conv_hidden
     assert packed["s0.w13.w"].shape == (2 * Hc, 3 * D) and packed["s0.w13.w"].dtype == torch.bfloat16
     assert packed["s0.w2.w"].shape == (D, 3 * Hc) and packed["t1.a_mod.w"].shape == (9 * D, D)
+    assert packed["smod_all.w"].shape == (cfg.depth_single * 6 * D, D)
+    assert torch.equal(packed["smod_all.w"][6 * D:12 * D].float(),
+                       sd["single_blocks.1.modulation.linear.weight"].to(torch.bfloat16).float())
     assert packed["t0.a_mod.b"].dtype == torch.float32 and "final_layer.adaLN_modulation.1.weight" not in packed
     arena = packers.Arena.from_packed(packed, "cpu")
     for k, v in packed.items():
