@@ -1,6 +1,10 @@
 // EXPERIMENTAL mainloop variants of the GEMM engine (bf16, plain store epilogue only), reachable
-// through foley_op_gemm with tile codes >= 100: tile = 100 + 10*variant + shape.  Used by
-// tools/gemm_bench.py to pick the production mainloop; not used by the runtime.
+// through foley_op_gemm with tile codes >= 100 and used ONLY by tools/gemm_bench.py (never by the
+// runtime): pipeline-depth / LDS-buffering sweeps (1xx), K-walk rotation (2xx/3xx: no effect - the
+// loop is not channel-camping) and phase ablations (4xx: no global loads in the loop, 5xx: also no
+// LDS writes / barriers).  Ablation result at M=500, 64x64 tiles: per K-slice the three phases
+// cost 0.21 us (global) + 0.13 us (LDS write + barrier) + 0.12 us (fragment reads + MFMA) and run
+// back to back; see DESIGN.md section 4.
 #include "kernels.h"
 
 namespace {
