@@ -599,7 +599,8 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     auto nblk = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn); };
     const long b128 = nblk(128, 128);
     const long rem = b128 % 256;
-    if (g.N <= 64 && epi != EPI_SILUGATE_T) tile = nblk(128, 64) >= 192 ? 4 : 3;
+    if (sizeof(T) == 2 && g.N > 64 && nblk(256, 128) >= 160) tile = 9;   // big grids: 64x64 per wave
+    else if (g.N <= 64 && epi != EPI_SILUGATE_T) tile = nblk(128, 64) >= 192 ? 4 : 3;
     else if (b128 >= 100 && (b128 <= 256 || rem == 0 || rem >= 128 || b128 >= 2048)) tile = 5;
     else if (epi == EPI_SILUGATE_T) tile = nblk(64, 128) >= 192 ? 2 : 5;
     else tile = 3;
@@ -608,10 +609,11 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     g.ksplit = 1;   // fp32 (parity) mode keeps a fixed summation order
   } else if (g.ksplit == 0) {
     // fill ~3 workgroups per CU, keep >= 12 K-slices per range
-    static const int bm[9] = {0, 128, 64, 64, 128, 128, 64, 128, 64}, bn[9] = {0, 128, 128, 64, 64, 128, 64, 128, 128};
+    static const int bm[10] = {0, 128, 64, 64, 128, 128, 64, 128, 64, 256}, bn[10] = {0, 128, 128, 64, 64, 128, 64, 128, 128, 128};
     const long blocks = (long)((g.M + bm[tile] - 1) / bm[tile]) * ((g.N + bn[tile] - 1) / bn[tile]);
     const int nk = g.K / BK;
-    long want = (768 + blocks - 1) / blocks;
+    const long target = tile == 9 ? 384 : 768;
+    long want = (target + blocks - 1) / blocks;
     if (want > nk / 12) want = nk / 12;
     g.ksplit = (int)(want < 1 ? 1 : (want > 16 ? 16 : want));
   }
@@ -628,6 +630,9 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
       if constexpr (sizeof(T) == 2) return launch_tile<T, 128, 128, 2, 2, 4, true>(g, g1, epi, st);
       else return foley_set_err("GEMM: tile 7 is bf16 only", __FILE__, __LINE__);
     case 8: return launch_tile<T, 64, 128, 2, 2, 4, true>(g, g1, epi, st);
+    case 9:  // 256x128, 8 waves of 64x64: fewest LDS bytes per MFMA; needs a large grid
+      if constexpr (sizeof(T) == 2) return launch_tile<T, 256, 128, 4, 2, 3, true>(g, g1, epi, st);
+      else return foley_set_err("GEMM: tile 9 is bf16 only", __FILE__, __LINE__);
   }
   return foley_set_err("GEMM: bad tile id", __FILE__, __LINE__);
 }

@@ -16,7 +16,7 @@ from foley_amd.host import runtime as rt  # noqa: E402
 
 SHAPES = {  # name: (N, K) ; M given by --m
     "qkv": (4608, 1536), "proj": (1536, 1536), "mod6": (9216, 1536), "fc1": (6144, 1536), "fc2": (1536, 6144),
-    "lin1": (1536, 4608), "w13": (8192, 4608), "w2": (1536, 12288),
+    "lin1": (1536, 4608), "w13": (8192, 4608), "w2": (1536, 12288), "smod": (36 * 9216, 1536),
 }
 ap = argparse.ArgumentParser()
 ap.add_argument("--m", type=int, default=500)
