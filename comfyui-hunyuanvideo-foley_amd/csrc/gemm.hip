@@ -612,7 +612,9 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     static const int bm[10] = {0, 128, 64, 64, 128, 128, 64, 128, 64, 256}, bn[10] = {0, 128, 128, 64, 64, 128, 64, 128, 128, 128};
     const long blocks = (long)((g.M + bm[tile] - 1) / bm[tile]) * ((g.N + bn[tile] - 1) / bn[tile]);
     const int nk = g.K / BK;
-    const long target = tile == 9 ? 384 : 768;
+    // small tiles want ~3 workgroups per CU; the large, efficient tiles only split when they
+    // cannot even cover the chip once (the fp32 atomics are not free)
+    const long target = (tile == 1 || tile == 5 || tile == 7 || tile == 9) ? 192 : 768;
     long want = (target + blocks - 1) / blocks;
     if (want > nk / 12) want = nk / 12;
     g.ksplit = (int)(want < 1 ? 1 : (want > 16 ? 16 : want));
