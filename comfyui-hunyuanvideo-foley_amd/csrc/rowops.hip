@@ -97,43 +97,62 @@ struct QkvPair {
   int blocks0;
 };
 
+// A workgroup handles one (clip, head, 32-token tile): its 4 waves walk the tile's rows and
+// operands (RMSNorm / RoPE are per (row, head), lane = rotation pair), and a transposed V operand
+// goes through a 32x128 LDS tile so that V^T leaves as 64-byte runs instead of 2-byte scatters.
 template <typename OutT>
 __global__ __launch_bounds__(256) void qkv_split_kernel(const QkvPair pr) {
+  __shared__ OutT vt[32][128 + 2];
   const int sel = (int)blockIdx.x >= pr.blocks0 ? 1 : 0;
   const QkvSplitArgs& a = pr.a[sel];
-  const long wid = (long)((int)blockIdx.x - (sel ? pr.blocks0 : 0)) * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const long total = (long)a.M * a.H * a.nK;
-  if (wid >= total) return;
-  const int w = (int)(wid % a.nK);
-  const int h = (int)((wid / a.nK) % a.H);
-  const int r = (int)(wid / ((long)a.nK * a.H));
-  const int b = r / a.L, l = r - b * a.L;
-  const float* src = a.qkv + (long)r * (a.nK * a.H * 128) + (long)w * a.H * 128 + h * 128 + 2 * lane;
-  float x0 = src[0], x1 = src[1];
-  if (a.gain[w]) {
-    const float ss = wave_sum(x0 * x0 + x1 * x1);
-    const float rinv = rsqrtf(ss * (1.0f / 128.0f) + a.eps);
-    x0 = x0 * rinv * a.gain[w][2 * lane];
-    x1 = x1 * rinv * a.gain[w][2 * lane + 1];
+  int bid = (int)blockIdx.x - (sel ? pr.blocks0 : 0);
+  const int tiles = (a.L + 31) >> 5;
+  const int tl = bid % tiles;
+  bid /= tiles;
+  const int h = bid % a.H;
+  const int b = bid / a.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l0 = tl * 32;
+  const int nrows = min(32, a.L - l0);
+  const bool vtrans = a.vt_pitch > 0;
+  for (int it = wave; it < nrows * a.nK; it += 4) {
+    const int w = it % a.nK;
+    const int lr = it / a.nK;
+    const int l = l0 + lr;
+    const long r = (long)b * a.L + l;
+    const float* src = a.qkv + r * (a.nK * a.H * 128) + (long)w * a.H * 128 + h * 128 + 2 * lane;
+    float x0 = src[0], x1 = src[1];
+    if (a.gain[w]) {
+      const float ss = wave_sum(x0 * x0 + x1 * x1);
+      const float rinv = rsqrtf(ss * (1.0f / 128.0f) + a.eps);
+      x0 = x0 * rinv * a.gain[w][2 * lane];
+      x1 = x1 * rinv * a.gain[w][2 * lane + 1];
+    }
+    if (a.pos[w]) {
+      const int p = a.pos[w][l];
+      const float c = a.cos_tab[(long)p * 64 + lane], s = a.sin_tab[(long)p * 64 + lane];
+      const float y0 = x0 * c - x1 * s;
+      const float y1 = x1 * c + x0 * s;
+      x0 = y0;
+      x1 = y1;
+    }
+    if (vtrans && w == a.nK - 1) {
+      vt[lr][2 * lane] = Cvt<OutT>::to(x0);
+      vt[lr][2 * lane + 1] = Cvt<OutT>::to(x1);
+    } else {
+      OutT* dst = (OutT*)a.dst[w] + (((long)b * a.H + h) * a.S_tot + a.tok_off + l) * 128 + 2 * lane;
+      dst[0] = Cvt<OutT>::to(x0);
+      dst[1] = Cvt<OutT>::to(x1);
+    }
   }
-  if (a.pos[w]) {
-    const int p = a.pos[w][l];
-    const float c = a.cos_tab[(long)p * 64 + lane], s = a.sin_tab[(long)p * 64 + lane];
-    const float y0 = x0 * c - x1 * s;
-    const float y1 = x1 * c + x0 * s;
-    x0 = y0;
-    x1 = y1;
-  }
-  if (a.vt_pitch > 0 && w == a.nK - 1) {
-    // V^T [clip, H, 128, vt_pitch]: the attention kernel wants key-contiguous rows per channel
-    OutT* dst = (OutT*)a.dst[w] + (((long)b * a.H + h) * 128 + 2 * lane) * a.vt_pitch + a.tok_off + l;
-    dst[0] = Cvt<OutT>::to(x0);
-    dst[a.vt_pitch] = Cvt<OutT>::to(x1);
-  } else {
-    OutT* dst = (OutT*)a.dst[w] + (((long)b * a.H + h) * a.S_tot + a.tok_off + l) * 128 + 2 * lane;
-    dst[0] = Cvt<OutT>::to(x0);
-    dst[1] = Cvt<OutT>::to(x1);
+  if (vtrans) {
+    __syncthreads();
+    // thread -> (channel d, half of the tile): 16 consecutive tokens of one V^T row
+    const int d = threadIdx.x >> 1, half = threadIdx.x & 1;
+    OutT* dst = (OutT*)a.dst[a.nK - 1] + (((long)b * a.H + h) * 128 + d) * a.vt_pitch + a.tok_off + l0 + half * 16;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+      if (half * 16 + t < nrows) dst[t] = vt[half * 16 + t][d];
   }
 }
 
@@ -336,9 +355,15 @@ int launch_qkv_split_pair(const QkvSplitArgs& a0, const QkvSplitArgs& a1, hipStr
   QkvPair pr;
   pr.a[0] = a0;
   pr.a[1] = a1;
-  const long w0 = (long)a0.M * a0.H * a0.nK, w1 = (long)a1.M * a1.H * a1.nK;
-  pr.blocks0 = (int)((w0 + 3) / 4);
-  dim3 grid((unsigned)(pr.blocks0 + (w1 + 3) / 4)), block(256);
+  auto nblk = [](const QkvSplitArgs& q) {
+    if (q.M <= 0) return 0;
+    return (q.M / q.L) * q.H * ((q.L + 31) / 32);   // rows are [clip][l]
+  };
+  if ((a0.M > 0 && a0.M % a0.L) || (a1.M > 0 && a1.M % a1.L))
+    return foley_set_err("qkv_split: M must be a multiple of L", __FILE__, __LINE__);
+  pr.blocks0 = nblk(a0);
+  dim3 grid((unsigned)(pr.blocks0 + nblk(a1))), block(256);
+  if (grid.x == 0) return 0;
   if (a0.out_dtype == FOLEY_BF16) hipLaunchKernelGGL(qkv_split_kernel<bf16_t>, grid, block, 0, st, pr);
   else hipLaunchKernelGGL(qkv_split_kernel<float>, grid, block, 0, st, pr);
   FOLEY_LAUNCH_CHECK();
