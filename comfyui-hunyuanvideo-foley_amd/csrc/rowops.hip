@@ -97,30 +97,28 @@ struct QkvPair {
   int blocks0;
 };
 
-// A workgroup handles one (clip, head, 32-token tile): its 4 waves walk the tile's rows and
-// operands (RMSNorm / RoPE are per (row, head), lane = rotation pair), and a transposed V operand
-// goes through a 32x128 LDS tile so that V^T leaves as 64-byte runs instead of 2-byte scatters.
+// Two workgroup roles in one launch: (1) one wave per (row, head, operand) for every operand that
+// keeps the [clip, H, S, 128] layout - RMSNorm / RoPE are per (row, head), lane = rotation pair;
+// (2) for a transposed V operand, one workgroup per (clip, head, 32-token tile) moves the tile
+// through LDS so that V^T leaves as 64-byte runs instead of 2-byte scatters.
 template <typename OutT>
 __global__ __launch_bounds__(256) void qkv_split_kernel(const QkvPair pr) {
   __shared__ OutT vt[32][128 + 2];
   const int sel = (int)blockIdx.x >= pr.blocks0 ? 1 : 0;
   const QkvSplitArgs& a = pr.a[sel];
   int bid = (int)blockIdx.x - (sel ? pr.blocks0 : 0);
-  const int tiles = (a.L + 31) >> 5;
-  const int tl = bid % tiles;
-  bid /= tiles;
-  const int h = bid % a.H;
-  const int b = bid / a.H;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int l0 = tl * 32;
-  const int nrows = min(32, a.L - l0);
   const bool vtrans = a.vt_pitch > 0;
-  for (int it = wave; it < nrows * a.nK; it += 4) {
-    const int w = it % a.nK;
-    const int lr = it / a.nK;
-    const int l = l0 + lr;
-    const long r = (long)b * a.L + l;
-    const float* src = a.qkv + r * (a.nK * a.H * 128) + (long)w * a.H * 128 + h * 128 + 2 * lane;
+  const int nQ = a.nK - (vtrans ? 1 : 0);  // operands handled by role (1)
+  const int lane = threadIdx.x & 63;
+  const int bqk = (int)(((long)a.M * a.H * nQ + 3) >> 2);
+  if (bid < bqk) {
+    const long wid = (long)bid * 4 + (threadIdx.x >> 6);
+    if (wid >= (long)a.M * a.H * nQ) return;
+    const int w = (int)(wid % nQ);
+    const int h = (int)((wid / nQ) % a.H);
+    const int r = (int)(wid / ((long)nQ * a.H));
+    const int b = r / a.L, l = r - b * a.L;
+    const float* src = a.qkv + (long)r * (a.nK * a.H * 128) + (long)w * a.H * 128 + h * 128 + 2 * lane;
     float x0 = src[0], x1 = src[1];
     if (a.gain[w]) {
       const float ss = wave_sum(x0 * x0 + x1 * x1);
@@ -136,24 +134,42 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const QkvPair pr) {
       x0 = y0;
       x1 = y1;
     }
-    if (vtrans && w == a.nK - 1) {
-      vt[lr][2 * lane] = Cvt<OutT>::to(x0);
-      vt[lr][2 * lane + 1] = Cvt<OutT>::to(x1);
-    } else {
-      OutT* dst = (OutT*)a.dst[w] + (((long)b * a.H + h) * a.S_tot + a.tok_off + l) * 128 + 2 * lane;
-      dst[0] = Cvt<OutT>::to(x0);
-      dst[1] = Cvt<OutT>::to(x1);
+    OutT* dst = (OutT*)a.dst[w] + (((long)b * a.H + h) * a.S_tot + a.tok_off + l) * 128 + 2 * lane;
+    dst[0] = Cvt<OutT>::to(x0);
+    dst[1] = Cvt<OutT>::to(x1);
+    return;
+  }
+  // ---- role (2): V tile -> V^T  (plain copy: V is neither normalised nor rotated)
+  bid -= bqk;
+  const int tiles = (a.L + 31) >> 5;
+  const int tl = bid % tiles;
+  bid /= tiles;
+  const int h = bid % a.H;
+  const int b = bid / a.H;
+  const int l0 = tl * 32;
+  const int nrows = min(32, a.L - l0);
+  const int w = a.nK - 1;
+  {
+    // 32 rows x 128 fp32 = 1024 float4: 4 per thread, all in flight together
+    const int c4 = threadIdx.x & 31, r0 = threadIdx.x >> 5;  // float4 column, row group
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int lr = r0 + i * 8;
+      const int l = l0 + min(lr, nrows - 1);
+      const f32x4 v = *(const f32x4*)(a.qkv + ((long)b * a.L + l) * (a.nK * a.H * 128) + (long)w * a.H * 128 +
+                                      h * 128 + c4 * 4);
+      vt[lr][c4 * 4 + 0] = Cvt<OutT>::to(v[0]);
+      vt[lr][c4 * 4 + 1] = Cvt<OutT>::to(v[1]);
+      vt[lr][c4 * 4 + 2] = Cvt<OutT>::to(v[2]);
+      vt[lr][c4 * 4 + 3] = Cvt<OutT>::to(v[3]);
     }
   }
-  if (vtrans) {
-    __syncthreads();
-    // thread -> (channel d, half of the tile): 16 consecutive tokens of one V^T row
-    const int d = threadIdx.x >> 1, half = threadIdx.x & 1;
-    OutT* dst = (OutT*)a.dst[a.nK - 1] + (((long)b * a.H + h) * 128 + d) * a.vt_pitch + a.tok_off + l0 + half * 16;
+  __syncthreads();
+  const int d = threadIdx.x >> 1, half = threadIdx.x & 1;  // channel, half of the tile
+  OutT* dst = (OutT*)a.dst[w] + (((long)b * a.H + h) * 128 + d) * a.vt_pitch + a.tok_off + l0 + half * 16;
 #pragma unroll
-    for (int t = 0; t < 16; ++t)
-      if (half * 16 + t < nrows) dst[t] = vt[half * 16 + t][d];
-  }
+  for (int t = 0; t < 16; ++t)
+    if (half * 16 + t < nrows) dst[t] = vt[half * 16 + t][d];
 }
 
 // ------------------------------------------------------------------ small elementwise helpers
@@ -357,7 +373,10 @@ int launch_qkv_split_pair(const QkvSplitArgs& a0, const QkvSplitArgs& a1, hipStr
   pr.a[1] = a1;
   auto nblk = [](const QkvSplitArgs& q) {
     if (q.M <= 0) return 0;
-    return (q.M / q.L) * q.H * ((q.L + 31) / 32);   // rows are [clip][l]
+    const int nQ = q.nK - (q.vt_pitch > 0 ? 1 : 0);
+    const int bqk = (int)(((long)q.M * q.H * nQ + 3) / 4);
+    const int bv = q.vt_pitch > 0 ? (q.M / q.L) * q.H * ((q.L + 31) / 32) : 0;   // rows are [clip][l]
+    return bqk + bv;
   };
   if ((a0.M > 0 && a0.M % a0.L) || (a1.M > 0 && a1.M % a1.L))
     return foley_set_err("qkv_split: M must be a multiple of L", __FILE__, __LINE__);
