@@ -110,33 +110,48 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const QkvPair pr) {
   const bool vtrans = a.vt_pitch > 0;
   const int nQ = a.nK - (vtrans ? 1 : 0);  // operands handled by role (1)
   const int lane = threadIdx.x & 63;
-  const int bqk = (int)(((long)a.M * a.H * nQ + 3) >> 2);
+  constexpr int IPW = 4;  // items per wave: their loads are issued together (memory-level parallelism)
+  const long n_items = (long)a.M * a.H * nQ;
+  const int bqk = (int)((n_items + 4 * IPW - 1) / (4 * IPW));
   if (bid < bqk) {
-    const long wid = (long)bid * 4 + (threadIdx.x >> 6);
-    if (wid >= (long)a.M * a.H * nQ) return;
-    const int w = (int)(wid % nQ);
-    const int h = (int)((wid / nQ) % a.H);
-    const int r = (int)(wid / ((long)nQ * a.H));
-    const int b = r / a.L, l = r - b * a.L;
-    const float* src = a.qkv + (long)r * (a.nK * a.H * 128) + (long)w * a.H * 128 + h * 128 + 2 * lane;
-    float x0 = src[0], x1 = src[1];
-    if (a.gain[w]) {
-      const float ss = wave_sum(x0 * x0 + x1 * x1);
-      const float rinv = rsqrtf(ss * (1.0f / 128.0f) + a.eps);
-      x0 = x0 * rinv * a.gain[w][2 * lane];
-      x1 = x1 * rinv * a.gain[w][2 * lane + 1];
+    const long it0 = ((long)bid * 4 + (threadIdx.x >> 6)) * IPW;
+    if (it0 >= n_items) return;
+    float x0[IPW], x1[IPW];
+    int wq[IPW], hq[IPW], rq[IPW];
+#pragma unroll
+    for (int u = 0; u < IPW; ++u) {
+      const long it = min(it0 + u, n_items - 1);
+      wq[u] = (int)(it % nQ);
+      hq[u] = (int)((it / nQ) % a.H);
+      rq[u] = (int)(it / ((long)nQ * a.H));
+      const float* src = a.qkv + (long)rq[u] * (a.nK * a.H * 128) + (long)wq[u] * a.H * 128 + hq[u] * 128 + 2 * lane;
+      x0[u] = src[0];
+      x1[u] = src[1];
     }
-    if (a.pos[w]) {
-      const int p = a.pos[w][l];
-      const float c = a.cos_tab[(long)p * 64 + lane], s = a.sin_tab[(long)p * 64 + lane];
-      const float y0 = x0 * c - x1 * s;
-      const float y1 = x1 * c + x0 * s;
-      x0 = y0;
-      x1 = y1;
+#pragma unroll
+    for (int u = 0; u < IPW; ++u) {
+      if (it0 + u >= n_items) break;
+      const int w = wq[u], h = hq[u], r = rq[u];
+      const int b = r / a.L, l = r - b * a.L;
+      float y0 = x0[u], y1 = x1[u];
+      if (a.gain[w]) {
+        const float ss = wave_sum(y0 * y0 + y1 * y1);
+        const float rinv = rsqrtf(ss * (1.0f / 128.0f) + a.eps);
+        y0 = y0 * rinv * a.gain[w][2 * lane];
+        y1 = y1 * rinv * a.gain[w][2 * lane + 1];
+      }
+      if (a.pos[w]) {
+        const int p = a.pos[w][l];
+        const float c = a.cos_tab[(long)p * 64 + lane], sn = a.sin_tab[(long)p * 64 + lane];
+        const float z0 = y0 * c - y1 * sn;
+        const float z1 = y1 * c + y0 * sn;
+        y0 = z0;
+        y1 = z1;
+      }
+      OutT* dst = (OutT*)a.dst[w] + (((long)b * a.H + h) * a.S_tot + a.tok_off + l) * 128 + 2 * lane;
+      dst[0] = Cvt<OutT>::to(y0);
+      dst[1] = Cvt<OutT>::to(y1);
     }
-    OutT* dst = (OutT*)a.dst[w] + (((long)b * a.H + h) * a.S_tot + a.tok_off + l) * 128 + 2 * lane;
-    dst[0] = Cvt<OutT>::to(x0);
-    dst[1] = Cvt<OutT>::to(x1);
     return;
   }
   // ---- role (2): V tile -> V^T  (plain copy: V is neither normalised nor rotated)
@@ -374,7 +389,7 @@ int launch_qkv_split_pair(const QkvSplitArgs& a0, const QkvSplitArgs& a1, hipStr
   auto nblk = [](const QkvSplitArgs& q) {
     if (q.M <= 0) return 0;
     const int nQ = q.nK - (q.vt_pitch > 0 ? 1 : 0);
-    const int bqk = (int)(((long)q.M * q.H * nQ + 3) / 4);
+    const int bqk = (int)(((long)q.M * q.H * nQ + 15) / 16);
     const int bv = q.vt_pitch > 0 ? (q.M / q.L) * q.H * ((q.L + 31) / 32) : 0;   // rows are [clip][l]
     return bqk + bv;
   };
