@@ -8,106 +8,9 @@
 // LDS table).  A ring of NS register stages keeps NS-1 K-slices of global loads in flight behind
 // the MFMA block (one barrier per slice).  Workgroup ids are remapped so tiles that share a
 // weight panel run on one XCD (L2).
-#include "kernels.h"
+#include "gemm_common.h"
 
 namespace {
-
-constexpr int LDS_PITCH = 144;  // bytes per staged row: 128 data + 16 pad
-
-template <typename T> struct Frag;
-template <> struct Frag<float> {
-  static constexpr int EPC = 4;   // elements per 16-byte chunk
-};
-template <> struct Frag<bf16_t> {
-  static constexpr int EPC = 8;
-};
-
-__device__ __forceinline__ float act_epi(float v, int epi) {
-  if (epi == EPI_SILU_T) return silu_f(v);
-  if (epi == EPI_GELU_T) return gelu_tanh_f(v);
-  return v;
-}
-
-// Fused epilogues shared by both mainloops.  C/D layout of the 32x32 MFMA: column = lane & 31,
-// row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
-template <typename T, int EPI, int FM, int FN, int TM, int TN>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[FM][FN], int m0, int n0, int wm,
-                                              int wn, int fi, int kh, int ks) {
-  const bool plain_out = g.osegV >= g.M;
-  float sn_a[FN], sn_ia[FN];
-  if constexpr (EPI == EPI_DAC) {
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int col = n0 + wn * TN + j * 32 + fi;
-      sn_a[j] = (g.out1 && col < g.N) ? g.alpha[col % g.alphaC] : 1.0f;
-      sn_ia[j] = 1.0f / (sn_a[j] + 1e-9f);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = m0 + wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-      if (row >= g.M) continue;
-      long obase, orel;
-      if (plain_out) {
-        obase = 0;
-        orel = (long)row * g.out_row + g.out_shift;
-      } else {
-        const int b = row / g.osegV, q = row - b * g.osegV;
-        obase = (long)b * g.out_seg;
-        orel = (long)q * g.out_row + g.out_shift;
-      }
-      const float* rbp = nullptr;
-      if constexpr (EPI == EPI_GATE_RES || EPI == EPI_STORE_F32) {
-        if (g.rb.p) rbp = rb_row(g.rb, row);
-      }
-      if constexpr (EPI == EPI_SILUGATE_T) {
-#pragma unroll
-        for (int j = 0; j < FN; j += 2) {
-          const int colp = n0 + wn * TN + j * 32;  // packed column of the 'a' group
-          const int col = (colp >> 1) + fi;
-          if (colp + 32 + fi >= g.N) continue;
-          float va = acc[i][j][e], vb = acc[i][j + 1][e];
-          if (g.bias) { va += g.bias[colp + fi]; vb += g.bias[colp + 32 + fi]; }
-          const long rel = orel + col;
-          if (g.out_check && (rel < 0 || rel >= g.out_seg)) continue;
-          ((T*)g.out0)[obase + rel] = Cvt<T>::to(silu_f(va) * vb);
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          const int col = n0 + wn * TN + j * 32 + fi;
-          if (col >= g.N) continue;
-          const long rel = orel + col;
-          if (g.out_check && (rel < 0 || rel >= g.out_seg)) continue;
-          const long off = obase + rel;
-          float v = acc[i][j][e];
-          if (g.bias && ks == 0) v += g.bias[col];
-          if constexpr (EPI == EPI_STORE_F32) {
-            if (rbp) v += rbp[col];
-            ((float*)g.out0)[off] = v;
-          } else if constexpr (EPI == EPI_GATE_RES) {
-            float* x = (float*)g.out0;
-            if (g.ksplit > 1) unsafeAtomicAdd(x + off, v * rbp[col]);  // global_atomic_add_f32
-            else x[off] = x[off] + v * rbp[col];
-          } else if constexpr (EPI == EPI_DAC) {
-            if (g.res) v += g.res[off];
-            if (g.out0) ((float*)g.out0)[off] = v;
-            if (g.out1) ((float*)g.out1)[off] = snake_f(v, sn_a[j], sn_ia[j]);
-          } else {
-            ((T*)g.out0)[off] = Cvt<T>::to(act_epi(v, EPI));
-          }
-        }
-      }
-    }
-  }
-}
-
-struct GemmPair {
-  GemmArgs g[2];
-  int tiles0;  // workgroups belonging to g[0]; the rest run g[1]
-};
 
 template <typename T, int BM, int BN, int WM, int WN, int NS, int EPI, bool CONV>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmPair pr) {
@@ -592,6 +495,12 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     return foley_set_err("GEMM: K / tap width / lda must be multiples of the 128-byte K-slice", __FILE__, __LINE__);
   if (((uintptr_t)g.A | (uintptr_t)g.W) & 15)
     return foley_set_err("GEMM: operands must be 16-byte aligned", __FILE__, __LINE__);
+  const bool conv3_ok = !g1 && g.taps == 3 && g.dil == 1 && g.tap0 == -1 && g.segV == g.segS && g.lda == g.tapC &&
+                        g.osegV >= g.M && (epi == EPI_STORE_F32 || epi == EPI_GATE_RES || epi == EPI_SILUGATE_T);
+  if (tile == 0 && conv3_ok) {
+    const long b128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+    tile = (b128 >= 100) ? 11 : 13;
+  }
   if (tile == 0) {
     // Tile choice for 256 CUs (measured on the M=500 / M=4000 shapes of the xxl DiT,
     // tools/gemm_bench.py): the 128x128 / 8-wave tile wins whenever it fills the chip without a
@@ -609,17 +518,22 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     g.ksplit = 1;   // fp32 (parity) mode keeps a fixed summation order
   } else if (g.ksplit == 0) {
     // fill ~3 workgroups per CU, keep >= 12 K-slices per range
-    static const int bm[10] = {0, 128, 64, 64, 128, 128, 64, 128, 64, 256}, bn[10] = {0, 128, 128, 64, 64, 128, 64, 128, 128, 128};
+    static const int bm[14] = {0, 128, 64, 64, 128, 128, 64, 128, 64, 256, 0, 128, 0, 64};
+    static const int bn[14] = {0, 128, 128, 64, 64, 128, 64, 128, 128, 128, 0, 128, 0, 64};
     const long blocks = (long)((g.M + bm[tile] - 1) / bm[tile]) * ((g.N + bn[tile] - 1) / bn[tile]);
-    const int nk = g.K / BK;
+    const int nk = (tile == 11 || tile == 13) ? 3 * (g.tapC / BK) / 3 : g.K / BK;   // conv3 splits over channel chunks
     // small tiles want ~3 workgroups per CU; the large, efficient tiles only split when they
     // cannot even cover the chip once (the fp32 atomics are not free)
-    const long target = (tile == 1 || tile == 5 || tile == 7 || tile == 9) ? 192 : 768;
+    const long target = (tile == 1 || tile == 5 || tile == 7 || tile == 9 || tile == 11) ? 192 : (tile == 13 ? 512 : 768);
     long want = (target + blocks - 1) / blocks;
     if (want > nk / 12) want = nk / 12;
     g.ksplit = (int)(want < 1 ? 1 : (want > 16 ? 16 : want));
   }
   if (g1) g1s.ksplit = g.ksplit;
+  if (tile == 11 || tile == 13) {
+    if (g1) return foley_set_err("conv3 kernel has no two-problem form", __FILE__, __LINE__);
+    return launch_gemm_conv3(g, sizeof(T) == 2 ? FOLEY_BF16 : FOLEY_F32, epi, tile == 11 ? 1 : 3, st);
+  }
   switch (tile) {
     case 1: return launch_tile<T, 128, 128, 4, 2, 4>(g, g1, epi, st);
     case 2: return launch_tile<T, 64, 128, 2, 2, 3>(g, g1, epi, st);

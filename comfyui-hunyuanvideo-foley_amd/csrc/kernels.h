@@ -53,6 +53,8 @@ int launch_gemm(const GemmArgs& g, int dtype, int epi, int tile, hipStream_t st)
 // stream of a two-stream block): the small problem's workgroups hide in the large one's shadow.
 // Tile shape and K split are chosen for g0.
 int launch_gemm_pair(const GemmArgs& g0, const GemmArgs& g1, int dtype, int epi, hipStream_t st);
+// tap-fused channels-last conv k=3 (gemm_conv3.hip); tile 1 = 128x128, 3 = 64x64; g.ksplit resolved
+int launch_gemm_conv3(const GemmArgs& g, int dtype, int epi, int tile, hipStream_t st);
 // experimental mainloop variants (bf16, plain fp32 store), tile codes >= 100 - see gemm_exp.hip
 int launch_gemm_exp(const GemmArgs& g, int code, hipStream_t st);
 

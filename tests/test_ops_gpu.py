@@ -106,7 +106,7 @@ def test_gemm_epilogues(dev, dtype, epi):
 
 
 @pytest.mark.parametrize("ksplit", [0, 1, 2, 5])
-@pytest.mark.parametrize("conv", [False, True])
+@pytest.mark.parametrize("conv", [False, True, 11, 13])
 def test_gemm_split_k(dev, ksplit, conv):
     """Gated-residual epilogue with K ranges accumulated by fp32 atomics (bf16 mode), incl. the
     conv addressing whose tap cursor must start mid-way for the later ranges."""
@@ -117,6 +117,8 @@ def test_gemm_split_k(dev, ksplit, conv):
     if conv:
         y = O.conv1d_cl(_q(x, dt), _q(w, dt), b, 1).reshape(B * L, N)
         Wp, kw = packers.conv_to_gemm(w), dict(conv=(L, C, 3, 1))
+        if conv in (11, 13):
+            kw["tile"] = conv    # tap-fused conv kernel
     else:
         y = F.linear(_q(x, dt).reshape(B * L, C), _q(w[:, :, 0], dt), b)
         Wp, kw = w[:, :, 0].contiguous(), {}
@@ -128,8 +130,8 @@ def test_gemm_split_k(dev, ksplit, conv):
 
 # ----------------------------------------------------------------------------- GEMM: conv addressing
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("tile", [0, 3, 5, 6])
-@pytest.mark.parametrize("B,L,Cin,Cout", [(2, 50, 256, 384), (3, 7, 128, 64), (1, 250, 1536, 256)])
+@pytest.mark.parametrize("tile", [0, 3, 5, 6, 11, 13])
+@pytest.mark.parametrize("B,L,Cin,Cout", [(2, 50, 256, 384), (3, 7, 128, 64), (1, 250, 1536, 256), (5, 33, 128, 200)])
 def test_conv3_channels_last(dev, dtype, tile, B, L, Cin, Cout):
     """ChannelLastConv1d k=3 pad=1 (mlp_layers.py:104-110) as a GEMM over overlapping rows
     (register-staged and direct-to-LDS mainloops)."""

@@ -25,6 +25,7 @@ ap.add_argument("--shapes", default=",".join(SHAPES))
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--check", action="store_true")
+ap.add_argument("--conv", action="store_true", help="treat K as 3*C of a channels-last conv k=3 over clips of 250 tokens")
 ap.add_argument("--ksplits", default="", help="comma list: benchmark the gated-residual epilogue with these K splits")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -35,23 +36,31 @@ for name in a.shapes.split(","):
     N, K = SHAPES[name]
     ncopy = max(2, int(600e6 // (N * K * (2 if dt == torch.bfloat16 else 4))) + 1)
     Ws = [(torch.randn(N, K, device=dev) / K ** 0.5).to(dt) for _ in range(ncopy)]
-    A = torch.randn(a.m, K, device=dev).to(dt)
+    A = torch.randn(a.m, K // 3 if a.conv else K, device=dev).to(dt)
+    ckw = dict(conv=(250, K // 3, 3, 1)) if a.conv else {}
     out = torch.empty(a.m, N, device=dev)
     ref = None
     if a.check:
-        ref = (A.float() @ Ws[0].float().t())
+        if a.conv:
+            Cc = K // 3
+            xr = A.float().view(-1, 250, Cc)
+            xp = torch.nn.functional.pad(xr, (0, 0, 1, 1))
+            im = torch.cat([xp[:, 0:250], xp[:, 1:251], xp[:, 2:252]], dim=2).reshape(a.m, K)
+            ref = im @ Ws[0].float().t()
+        else:
+            ref = (A.float() @ Ws[0].float().t())
     line = f"{name:5s} N={N:5d} K={K:5d} |"
     if a.ksplits:
         gate = torch.randn(N, device=dev)
         x = torch.zeros(a.m, N, device=dev)
         for t in tiles:
             for ksp in [int(v) for v in a.ksplits.split(",")]:
-                rt.op_gemm(A, Ws[0], None, out0=x, tile=t, epilogue=rt.EPI_GATE_RES, rb=rt.rowbcast(gate, 0), ksplit=ksp)
+                rt.op_gemm(A, Ws[0], None, out0=x, tile=t, epilogue=rt.EPI_GATE_RES, rb=rt.rowbcast(gate, 0), ksplit=ksp, **ckw)
                 torch.cuda.synchronize()
                 evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.reps)]
                 for i, (e0, e1) in enumerate(evs):
                     e0.record()
-                    rt.op_gemm(A, Ws[i % ncopy], None, out0=x, tile=t, epilogue=rt.EPI_GATE_RES, rb=rt.rowbcast(gate, 0), ksplit=ksp)
+                    rt.op_gemm(A, Ws[i % ncopy], None, out0=x, tile=t, epilogue=rt.EPI_GATE_RES, rb=rt.rowbcast(gate, 0), ksplit=ksp, **ckw)
                     e1.record()
                 torch.cuda.synchronize()
                 ts = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
@@ -61,7 +70,7 @@ for name in a.shapes.split(","):
         continue
     for t in tiles:
         try:
-            rt.op_gemm(A, Ws[0], None, out0=out, tile=t)
+            rt.op_gemm(A, Ws[0], None, out0=out, tile=t, **ckw)
             torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001
             line += f" t{t}: ERR({str(e)[-40:]})"
@@ -72,7 +81,7 @@ for name in a.shapes.split(","):
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.reps)]
         for i, (e0, e1) in enumerate(evs):
             e0.record()
-            rt.op_gemm(A, Ws[i % ncopy], None, out0=out, tile=t)
+            rt.op_gemm(A, Ws[i % ncopy], None, out0=out, tile=t, **ckw)
             e1.record()
         torch.cuda.synchronize()
         ts = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
