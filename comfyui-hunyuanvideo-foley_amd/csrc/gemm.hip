@@ -497,9 +497,12 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     return foley_set_err("GEMM: operands must be 16-byte aligned", __FILE__, __LINE__);
   const bool conv3_ok = !g1 && g.taps == 3 && g.dil == 1 && g.tap0 == -1 && g.segV == g.segS && g.lda == g.tapC &&
                         g.osegV >= g.M && (epi == EPI_STORE_F32 || epi == EPI_GATE_RES || epi == EPI_SILUGATE_T);
-  if (tile == 0 && conv3_ok) {
+  // Measured end to end (xxl, 5 s): the tap-fused kernel wins in fp32 (parity mode, -7 % loop time)
+  // and for the small-M gated w1/w3 GEMM; elsewhere the generic tiles (+ split-K / 256x128) are as
+  // fast or faster in bf16, so it is only auto-selected there.
+  if (tile == 0 && conv3_ok && (sizeof(T) == 4 || (epi == EPI_SILUGATE_T && g.M < 1024))) {
     const long b128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    tile = (b128 >= 100) ? 11 : 13;
+    tile = (b128 >= 100 || epi == EPI_SILUGATE_T) ? 11 : 13;   // the gated epilogue needs 64-wide wave tiles
   }
   if (tile == 0) {
     // Tile choice for 256 CUs (measured on the M=500 / M=4000 shapes of the xxl DiT,
