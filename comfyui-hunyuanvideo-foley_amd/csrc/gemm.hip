@@ -12,6 +12,21 @@
 
 namespace {
 
+// dbg_mode 0: 4 stamps per workgroup.  dbg_mode 1: workgroup 0 adds its prologue / K-loop / epilogue
+// ticks and a launch count to dbg[0..3] (totals over every GEMM of a forward pass).
+__device__ __forceinline__ void tl_stamp(const GemmArgs& g, int slot) {
+  if (!g.dbg || threadIdx.x != 0) return;
+  const long long t = wall_clock64();
+  if (g.dbg_mode == 0) {
+    g.dbg[(long)blockIdx.x * 4 + slot] = t;
+  } else if (blockIdx.x == 0) {
+    unsigned long long* d = (unsigned long long*)g.dbg;
+    if (slot > 0) atomicAdd(d + slot - 1, (unsigned long long)t);
+    if (slot < 3) atomicAdd(d + slot, 0ull - (unsigned long long)t);
+    if (slot == 3) atomicAdd(d + 3, 1ull);
+  }
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int NS, int EPI, bool CONV>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmPair pr) {
   const int sel = (int)blockIdx.x >= pr.tiles0 ? 1 : 0;  // wave-uniform
@@ -45,6 +60,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmPair pr) {
   const int tm = bid % tiles_m, tn = bid / tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  tl_stamp(g, 0);
   const int wm = wave / WN, wn = wave % WN;
   const int chunk = tid & 7, lrow = tid >> 3;
 
@@ -165,6 +181,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmPair pr) {
         // one barrier per K-slice: the stage written now was last read two slices ago, and every
         // wave has passed the previous barrier since
         __syncthreads();
+        if (kt == 0) tl_stamp(g, 1);
 
         if constexpr (sizeof(T) == 4) {
           // lane (fi, kh) owns k = kh*16 .. kh*16+15 of its row; MFMA step s contracts the k pair
@@ -228,7 +245,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmPair pr) {
     for (int e = 0; e < 16; ++e) acc[0][0][e] += acc2[e];
   }
 
-  gemm_epilogue<T, EPI, FM, FN, TM, TN>(g, acc, m0, n0, wm, wn, fi, kh, ks);
+  tl_stamp(g, 2);
+  if (g.vec_out) gemm_epilogue_lds<T, EPI, BM, BN, WM, WN>(g, acc, lds, m0, n0);
+  else gemm_epilogue<T, EPI, FM, FN, TM, TN>(g, acc, m0, n0, wm, wn, fi, kh, ks);
+  tl_stamp(g, 3);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -275,6 +295,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmPair p
   const int tm = bid % tiles_m, tn = bid / tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  tl_stamp(g, 0);
   const int wm = wave / WN, wn = wave % WN;
   const int lr = lane >> 3, lp = lane & 7;  // row within the 8-row group, LDS chunk position
 
@@ -371,6 +392,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmPair p
     if (kt + NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (AI + BI)) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // everyone's part of slice kt is in LDS; stage (kt-1)%NS is free again
+    if (kt == 0) tl_stamp(g, 1);
     if (kt + NS - 1 < nk) issue(stage == 0 ? NS - 1 : stage - 1);
     const unsigned char* As = lds + stage * STAGE;
     const unsigned char* Bs = As + BM * 128;
@@ -418,7 +440,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmPair p
     }
     stage = stage + 1 == NS ? 0 : stage + 1;
   }
-  gemm_epilogue<T, EPI, FM, FN, TM, TN>(g, acc, m0, n0, wm, wn, fi, kh, ks);
+  tl_stamp(g, 2);
+  if (g.vec_out) gemm_epilogue_lds<T, EPI, BM, BN, WM, WN>(g, acc, lds, m0, n0);
+  else gemm_epilogue<T, EPI, FM, FN, TM, TN>(g, acc, m0, n0, wm, wn, fi, kh, ks);
+  tl_stamp(g, 3);
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NS, int EPI, bool GLDS = false>
@@ -470,6 +495,9 @@ int launch_tile(const GemmArgs& g, const GemmArgs* g1, int epi, hipStream_t st) 
   return foley_set_err("unknown GEMM epilogue", __FILE__, __LINE__);
 }
 
+long long* g_gemm_dbg = nullptr;
+int g_gemm_dbg_mode = 0;
+
 template <typename T>
 int check_args(const GemmArgs& g) {
   constexpr int BK = 8 * Frag<T>::EPC;
@@ -483,11 +511,14 @@ int check_args(const GemmArgs& g) {
 template <typename T>
 int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile, hipStream_t st) {
   GemmArgs g = g_in;
+  g.dbg = g_gemm_dbg;
+  g.dbg_mode = g_gemm_dbg_mode;
   GemmArgs g1s;
   const GemmArgs* g1 = nullptr;
   if (g1_in) {
     if (int rc = check_args<T>(*g1_in)) return rc;
     g1s = *g1_in;
+    g1s.dbg = nullptr;
     g1 = &g1s;
   }
   constexpr int BK = 8 * Frag<T>::EPC;
@@ -533,6 +564,8 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     g.ksplit = (int)(want < 1 ? 1 : (want > 16 ? 16 : want));
   }
   if (g1) g1s.ksplit = g.ksplit;
+  g.vec_out = gemm_vec_out_ok<T>(g, epi) ? 1 : 0;
+  if (g1) g1s.vec_out = gemm_vec_out_ok<T>(g1s, epi) ? 1 : 0;
   if (tile == 11 || tile == 13) {
     if (g1) return foley_set_err("conv3 kernel has no two-problem form", __FILE__, __LINE__);
     return launch_gemm_conv3(g, sizeof(T) == 2 ? FOLEY_BF16 : FOLEY_F32, epi, tile == 11 ? 1 : 3, st);
@@ -576,4 +609,11 @@ int launch_gemm_pair(const GemmArgs& g0, const GemmArgs& g1, int dtype, int epi,
   if (dtype == FOLEY_F32) return launch_typed<float>(g0, &g1, epi, 0, st);
   if (dtype == FOLEY_BF16) return launch_typed<bf16_t>(g0, &g1, epi, 0, st);
   return foley_set_err("GEMM: unsupported operand dtype", __FILE__, __LINE__);
+}
+
+// Debug hook for tools/gemm_timeline.py (not part of include/foley_hip.h): every following GEMM
+// launch writes 4 wall-clock stamps per workgroup to `p` (device memory, 4 * grid * 8 bytes).
+extern "C" void foley_debug_gemm_timeline(void* p, int mode) {
+  g_gemm_dbg = (long long*)p;
+  g_gemm_dbg_mode = mode;
 }

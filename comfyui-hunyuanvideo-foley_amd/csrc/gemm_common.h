@@ -97,6 +97,178 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[F
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Vector epilogue: the accumulator tile goes through LDS once (the K-loop stages are dead by then)
+// so that every lane owns 16 contiguous output bytes of one row - global stores (and the residual
+// read-modify-write) become dwordx4 instead of 32 scalar dword accesses per fragment, which is what
+// the scalar epilogue is bound by (store issue, not bytes).  All global loads of a thread (residual,
+// gate rows) are issued before the first store.  Used when GemmArgs::vec_out is set by the launcher
+// (plain row-major output, 16-byte aligned operands); everything else takes gemm_epilogue above.
+struct RbCursor {   // rb_row() for rows that advance by a fixed stride, without per-row divisions
+  const float* p;
+  long ld;
+  int mode, rpc, L, cfg, rc, l;
+  __device__ __forceinline__ void init(const RowBcast& b, int row) {
+    p = b.p;
+    if (p && b.step_ptr) p += (long)(*b.step_ptr) * b.step_stride;
+    ld = b.ld; mode = p ? b.mode : 0; rpc = b.rows_per_cfg; L = b.L;
+    cfg = 0; rc = 0; l = 0;
+    if (mode == 1) { cfg = row / rpc; rc = row - cfg * rpc; l = row % L; }
+  }
+  __device__ __forceinline__ const float* row_ptr() const { return mode == 1 ? p + ((long)cfg * L + l) * ld : p; }
+  __device__ __forceinline__ void advance(int rows) {
+    if (mode != 1) return;
+    l += rows; while (l >= L) l -= L;
+    rc += rows; while (rc >= rpc) { rc -= rpc; ++cfg; }
+  }
+};
+
+template <typename OutT> struct VecStore;
+template <> struct VecStore<float> {
+  static constexpr int CP = 4;
+  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+    f32x4 w = {v[0], v[1], v[2], v[3]};
+    *(f32x4*)p = w;
+  }
+};
+template <> struct VecStore<bf16_t> {
+  static constexpr int CP = 8;
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+    u32x4 w;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) w[u] = (uint32_t)f32_to_bf16(v[2 * u]) | ((uint32_t)f32_to_bf16(v[2 * u + 1]) << 16);
+    *(u32x4*)p = w;
+  }
+};
+template <typename T, int EPI> struct EpiOutT { using type = T; };
+template <typename T> struct EpiOutT<T, EPI_STORE_F32> { using type = float; };
+template <typename T> struct EpiOutT<T, EPI_GATE_RES> { using type = float; };
+template <typename T> struct EpiOutT<T, EPI_DAC> { using type = float; };
+
+template <typename T, int EPI, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&acc)[BM / WM / 32][BN / WN / 32],
+                                                  unsigned char* lds_raw, int m0, int n0) {
+  constexpr int NT = WM * WN * 64, TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
+  using OutT = typename EpiOutT<T, EPI>::type;
+  constexpr int CP = VecStore<OutT>::CP;                    // output elements per lane and pass
+  constexpr int OBN = EPI == EPI_SILUGATE_T ? BN / 2 : BN;  // output columns of the tile
+  constexpr int TPR = OBN / CP, RP = NT / TPR, PASSES = BM / RP;
+  static_assert(NT % TPR == 0 && BM % RP == 0 && PASSES >= 1, "tile / epilogue mismatch");
+  float* tile = (float*)lds_raw;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN, fi = lane & 31, kh = lane >> 5;
+  __syncthreads();   // every wave is done reading the last K-slice
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        tile[(wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh) * BN + wn * TN + j * 32 + fi] = acc[i][j][e];
+  __syncthreads();
+
+  const int tr = tid / TPR, tc = (tid % TPR) * CP;   // row inside a pass, output column inside the tile
+  int ca, cb = 0, gcol, ncheck;                      // tile columns to read, global output column
+  if constexpr (EPI == EPI_SILUGATE_T) {
+    ca = (tc >> 5) * 64 + (tc & 31);
+    cb = ca + 32;
+    gcol = (n0 >> 1) + tc;
+    ncheck = n0 + (tc >> 5) * 64;
+  } else {
+    ca = tc;
+    gcol = n0 + tc;
+    ncheck = gcol;
+  }
+  const bool col_ok = ncheck < g.N;
+  float bias_a[CP], bias_b[CP];
+#pragma unroll
+  for (int u = 0; u < CP; ++u) bias_a[u] = bias_b[u] = 0.f;
+  if (g.bias && col_ok) {
+#pragma unroll
+    for (int u = 0; u < CP; u += 4) {
+      const f32x4 v = *(const f32x4*)(g.bias + n0 + ca + u);
+      bias_a[u] = v[0]; bias_a[u + 1] = v[1]; bias_a[u + 2] = v[2]; bias_a[u + 3] = v[3];
+      if constexpr (EPI == EPI_SILUGATE_T) {
+        const f32x4 w = *(const f32x4*)(g.bias + n0 + cb + u);
+        bias_b[u] = w[0]; bias_b[u + 1] = w[1]; bias_b[u + 2] = w[2]; bias_b[u + 3] = w[3];
+      }
+    }
+  }
+  OutT* out = (OutT*)g.out0 + g.out_shift + gcol;
+  const int row0 = m0 + tr;
+
+  if constexpr (EPI == EPI_GATE_RES || EPI == EPI_STORE_F32) {
+    RbCursor rc;
+    rc.init(g.rb, row0);
+    f32x4 xv[PASSES], gv[PASSES];
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {   // all global reads first
+      const int row = row0 + p * RP;
+      const bool ok = col_ok && row < g.M;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      xv[p] = z;
+      gv[p] = z;
+      if (ok) {
+        if constexpr (EPI == EPI_GATE_RES) xv[p] = *(const f32x4*)(out + (long)row * g.out_row);
+        if (rc.p) gv[p] = *(const f32x4*)(rc.row_ptr() + gcol);
+      }
+      rc.advance(RP);
+    }
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int row = row0 + p * RP;
+      if (!(col_ok && row < g.M)) continue;
+      const f32x4 a = *(const f32x4*)(tile + (p * RP + tr) * BN + ca);
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float t = a[u] + bias_a[u];
+        v[u] = EPI == EPI_GATE_RES ? xv[p][u] + t * gv[p][u] : t + gv[p][u];
+      }
+      VecStore<float>::store((float*)out + (long)row * g.out_row, v);
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int row = row0 + p * RP;
+      if (!(col_ok && row < g.M)) continue;
+      const float* src = tile + (p * RP + tr) * BN;
+      float v[CP];
+#pragma unroll
+      for (int u = 0; u < CP; u += 4) {
+        const f32x4 a = *(const f32x4*)(src + ca + u);
+        if constexpr (EPI == EPI_SILUGATE_T) {
+          const f32x4 b = *(const f32x4*)(src + cb + u);
+#pragma unroll
+          for (int w = 0; w < 4; ++w) v[u + w] = silu_f(a[w] + bias_a[u + w]) * (b[w] + bias_b[u + w]);
+        } else {
+#pragma unroll
+          for (int w = 0; w < 4; ++w) v[u + w] = act_epi(a[w] + bias_a[u + w], EPI);
+        }
+      }
+      VecStore<OutT>::store(out + (long)row * g.out_row, v);
+    }
+  }
+}
+
+// Launcher side: can this problem take the vector epilogue?
+template <typename T>
+inline bool gemm_vec_out_ok(const GemmArgs& g, int epi) {
+  if (epi == EPI_DAC || g.osegV < g.M || g.out_check) return false;
+  if (epi == EPI_GATE_RES && g.ksplit > 1) return false;   // split-K accumulates with scalar atomics
+  const bool f32 = epi == EPI_STORE_F32 || epi == EPI_GATE_RES || sizeof(T) == 4;
+  const int cp = f32 ? 4 : 8;
+  const long esz = f32 ? 4 : 2;
+  if (epi == EPI_SILUGATE_T) { if (g.N % 64) return false; }
+  else if (g.N % cp) return false;
+  if (g.out_row % cp || g.out_shift % cp || ((uintptr_t)g.out0 * 1) % 16 || (g.out_shift * esz) % 16) return false;
+  if (g.bias && ((uintptr_t)g.bias & 15)) return false;
+  if ((epi == EPI_GATE_RES || epi == EPI_STORE_F32) && g.rb.p) {
+    if (((uintptr_t)g.rb.p & 15) || g.rb.ld % 4 || g.rb.step_stride % 4) return false;
+  }
+  return true;
+}
+
 struct GemmPair {
   GemmArgs g[2];
   int tiles0;  // workgroups belonging to g[0]; the rest run g[1]

@@ -190,7 +190,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_conv3_kernel(const GemmPair 
     }
   }
 #undef FOLEY_GLOAD3
-  gemm_epilogue<T, EPI, FM, FN, TM, TN>(g, acc, m0, n0, wm, wn, fi, kh, ks);
+  if (g.vec_out) gemm_epilogue_lds<T, EPI, BM, BN, WM, WN>(g, acc, lds, m0, n0);
+  else gemm_epilogue<T, EPI, FM, FN, TM, TN>(g, acc, m0, n0, wm, wn, fi, kh, ks);
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NS, int EPI>

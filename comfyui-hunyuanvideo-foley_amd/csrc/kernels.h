@@ -45,6 +45,10 @@ struct GemmArgs {
   const void* zeros;  // >= 128 zero bytes in global memory (source of masked rows for the direct-to-LDS loop)
   int ksplit;         // EPI_GATE_RES only: K is cut into `ksplit` ranges whose partial products are
                       // accumulated with hardware fp32 atomics (0 = auto; 1 = deterministic)
+  int vec_out;        // set by the launcher: the problem qualifies for the LDS-transposed vector epilogue
+  int dbg_mode;
+  long long* dbg;     // tools/gemm_timeline.py: 4 wall-clock stamps per workgroup (entry, first slice
+                      // landed, K loop done, epilogue done); null in production
 };
 
 // dtype: FOLEY_F32 or FOLEY_BF16 operands (accumulation is always fp32). tile: 0 = auto.

@@ -1,0 +1,78 @@
+"""Per-workgroup timeline of one GEMM launch (debug stamps written by the kernels when
+foley_debug_gemm_timeline() is armed): entry, first K-slice landed, K loop done, epilogue done.
+Times are s_memrealtime ticks (100 MHz -> 10 ns) relative to the earliest workgroup entry.
+
+    python tools/gemm_timeline.py --shape w2 --tile 5 --ksplit 5 [--m 500] [--conv]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+load_package()
+from foley_amd.host import runtime as rt  # noqa: E402
+
+SHAPES = {"qkv": (4608, 1536), "proj": (1536, 1536), "fc1": (6144, 1536), "fc2": (1536, 6144),
+          "lin1": (1536, 4608), "w13": (8192, 4608), "w2": (1536, 12288)}
+ap = argparse.ArgumentParser()
+ap.add_argument("--m", type=int, default=500)
+ap.add_argument("--shape", default="w2")
+ap.add_argument("--tile", type=int, default=5)
+ap.add_argument("--ksplit", type=int, default=0, help="0 = plain fp32 store epilogue")
+ap.add_argument("--conv", action="store_true")
+ap.add_argument("--warm", action="store_true", help="measure with the weight matrix just used (L2 / Infinity-Cache warm)")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+N, K = SHAPES[a.shape]
+lib = rt.load_library()
+lib.foley_debug_gemm_timeline.argtypes = [C.c_void_p, C.c_int]
+lib.foley_debug_gemm_timeline.restype = None
+Ws = [(torch.randn(N, K, device=dev) / K ** 0.5).bfloat16() for _ in range(max(2, int(600e6 // (N * K * 2)) + 1))]
+A = torch.randn(a.m, K // 3 if a.conv else K, device=dev).bfloat16()
+ckw = dict(conv=(250, K // 3, 3, 1)) if a.conv else {}
+x = torch.zeros(a.m, N, device=dev)
+gate = torch.randn(N, device=dev)
+
+
+def run(W):
+    if a.ksplit:
+        rt.op_gemm(A, W, None, out0=x, tile=a.tile, epilogue=rt.EPI_GATE_RES, rb=rt.rowbcast(gate, 0), ksplit=a.ksplit, **ckw)
+    else:
+        rt.op_gemm(A, W, None, out0=x, tile=a.tile, **ckw)
+
+
+for W in Ws[:3]:
+    run(W)
+torch.cuda.synchronize()
+dbg = torch.zeros(8192 * 4, dtype=torch.int64, device=dev)
+lib.foley_debug_gemm_timeline(C.c_void_p(dbg.data_ptr()), 0)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+run(Ws[2] if a.warm else Ws[-1])
+e1.record()
+torch.cuda.synchronize()
+lib.foley_debug_gemm_timeline(None, 0)
+t = dbg.view(-1, 4).cpu()
+t = t[t[:, 0] > 0].double()
+t0 = t[:, 0].min()
+t = (t - t0) / 100.0  # us
+
+
+def q(v):
+    v = v.sort().values
+    n = len(v)
+    return f"min {v[0]:6.2f}  p50 {v[n // 2]:6.2f}  p90 {v[int(n * 0.9)]:6.2f}  max {v[-1]:6.2f}"
+
+
+print(f"{a.shape} M={a.m} N={N} K={K} tile={a.tile} ksplit={a.ksplit} conv={a.conv}: {len(t)} workgroups, event time {e0.elapsed_time(e1) * 1e3:.1f} us")
+print("entry            (us after first):", q(t[:, 0]))
+print("first slice landed - entry       :", q(t[:, 1] - t[:, 0]))
+print("K loop (after first slice)       :", q(t[:, 2] - t[:, 1]))
+print("epilogue                         :", q(t[:, 3] - t[:, 2]))
+print("exit             (us after first):", q(t[:, 3]))

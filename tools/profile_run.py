@@ -21,6 +21,7 @@ ap.add_argument("--model", default="xxl")
 ap.add_argument("--graph", action="store_true")
 ap.add_argument("--no-dac", action="store_true")
 ap.add_argument("--duration", type=float, default=5.0)
+ap.add_argument("--phases", action="store_true", help="sum workgroup-0 prologue / K-loop / epilogue time over all GEMM launches of the loop (eager)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = C.dit_config(a.model)
@@ -37,8 +38,24 @@ plan = sampler.build_plan(model, {"siglip2_feat": cond["clip"], "syncformer_feat
                           a.bs, "euler")
 model.ctx.prepare(plan)
 lat = torch.randn(a.bs, 128, LA, device=dev)
+if a.phases:
+    import ctypes as CT
+    from foley_amd.host import runtime as rt
+    lib = rt.load_library()
+    lib.foley_debug_gemm_timeline.argtypes = [CT.c_void_p, CT.c_int]
+    lib.foley_debug_gemm_timeline.restype = None
+    model.ctx.sample(lat.clone(), use_graph=False)
+    torch.cuda.synchronize()
+    dbg = torch.zeros(8, dtype=torch.int64, device=dev)
+    lib.foley_debug_gemm_timeline(CT.c_void_p(dbg.data_ptr()), 1)
 model.ctx.sample(lat, use_graph=a.graph)
 torch.cuda.synchronize()
+if a.phases:
+    lib.foley_debug_gemm_timeline(None, 0)
+    d = dbg.cpu().tolist()
+    n = max(d[3], 1)
+    print(f"GEMM launches {d[3]} ({d[3] / a.iters:.0f}/iter): per iteration prologue {d[0] / 100 / a.iters:.0f} us, "
+          f"K loop {d[1] / 100 / a.iters:.0f} us, epilogue {d[2] / 100 / a.iters:.0f} us (workgroup 0 of each launch)")
 print("loop ms/iter:", model.ctx.last_elapsed_ms() / a.iters)
 if not a.no_dac:
     model.ctx.dac_decode(lat)
