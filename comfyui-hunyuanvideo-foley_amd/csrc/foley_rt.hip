@@ -85,6 +85,7 @@ struct foley_ctx {
   void* svec = nullptr;             // T [ncfg*La, D]
   float* smod = nullptr;            // [ncfg*La, n_single*6D]
   float* pred = nullptr;            // [M, C]
+  float *part_a = nullptr, *part_v = nullptr;   // deferred split-K partial products [PART_CAP][M | Mv][D]
   float* x_saved = nullptr;         // [clips, C, La]
   float* d_acc = nullptr;
   int* step_ctr = nullptr;
@@ -194,6 +195,10 @@ static const void* zero_page() {
 
 // --------------------------------------------------------------------------- launch helpers
 static RowBcast rb_none() { return RowBcast{nullptr, 0, 0, 1, 1, nullptr, 0}; }
+
+// K ranges whose partial products a gated-residual GEMM may leave for the next LayerNorm to sum
+// (deferred split-K, kernels.h GemmArgs::partials)
+constexpr int PART_CAP = 8;
 
 struct Lin {  // a packed linear / conv-as-GEMM layer
   const void* w = nullptr;
@@ -355,6 +360,8 @@ extern "C" int foley_prepare(foley_ctx* c, const foley_plan* pl, void* stream_v)
     ALLOC(c->svec, (size_t)ncfg * La * D * es);
     ALLOC(c->smod, (size_t)f.depth_single * ncfg * La * 6 * D * 4);
     ALLOC(c->pred, (size_t)M * C * 4);
+    ALLOC(c->part_a, (size_t)PART_CAP * M * D * 4);
+    ALLOC(c->part_v, (size_t)PART_CAP * Mv * D * 4);
     ALLOC(c->x_saved, (size_t)clips * C * La * 4);
     ALLOC(c->d_acc, (size_t)clips * C * La * 4);
     ALLOC(c->x_cur, (size_t)clips * C * La * 4);
@@ -516,6 +523,14 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
       HIPTRY(hipMemcpyAsync(c->vcond + ((size_t)(g * clips + b) * Lv) * D, c->v_cond0 + (size_t)g * Lv * D,
                             (size_t)Lv * D * 4, hipMemcpyDeviceToDevice, st));
 
+  // residual updates left pending by deferred split-K GEMMs, per stream (audio, visual); the next
+  // LayerNorm of that stream applies them
+  LnPending pend[2] = {LnPending{}, LnPending{}};
+  auto with_partials = [&](GemmArgs& g, float* slabs) {
+    g.partials = slabs;
+    g.partial_stride = (long)g.M * g.N;
+    g.partial_cap = PART_CAP;
+  };
   for (int blk = 0; blk < f.depth_triple; ++blk) {
     const std::string p = "t" + std::to_string(blk) + ".";
     auto tb = [&](int s, int chunk) {
@@ -531,8 +546,9 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
       return get_lin(c, p + "v_" + name, T, N, K, true, lv);
     };
     auto ln2 = [&](int c_shift, int c_scale) -> int {
-      LnArgs a0{ss[0].x, ss[0].rows, tb(0, c_shift), tb(0, c_scale), ss[0].xn};
-      LnArgs a1{ss[1].x, ss[1].rows, tb(1, c_shift), tb(1, c_scale), ss[1].xn};
+      LnArgs a0{ss[0].x, ss[0].rows, tb(0, c_shift), tb(0, c_scale), ss[0].xn, pend[0]};
+      LnArgs a1{ss[1].x, ss[1].rows, tb(1, c_shift), tb(1, c_scale), ss[1].xn, pend[1]};
+      pend[0] = pend[1] = LnPending{};
       return launch_ln_mod_pair(a0, a1, D, 1e-6f, T, st);
     };
     auto gated2 = [&](const Lin& la, const Lin& lv, bool from_hid, int c_gate) -> int {
@@ -540,7 +556,15 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
       GemmArgs g1 = gemm_plain(from_hid ? ss[1].hid : ss[1].att, ss[1].rows, lv, ss[1].x, D);
       g0.rb = tb(0, c_gate);
       g1.rb = tb(1, c_gate);
-      return launch_gemm_pair(g0, g1, T, EPI_GATE_RES, st);
+      with_partials(g0, c->part_a);
+      with_partials(g1, c->part_v);
+      int ks = 1;
+      TRY(launch_gemm_pair(g0, g1, T, EPI_GATE_RES, st, &ks));
+      if (ks > 1) {
+        pend[0] = LnPending{c->part_a, ks, g0.partial_stride, la.b, g0.rb};
+        pend[1] = LnPending{c->part_v, ks, g1.partial_stride, lv.b, g1.rb};
+      }
+      return 0;
     };
     auto split_args = [&](int s, int nK, const void* gq, const void* gk, const int* pos) {
       Stream& z = ss[s];
@@ -620,7 +644,8 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
     const float* smod_b = c->smod + (size_t)blk * 6 * D;   // column block of the fused table
     auto sm = [&](int chunk) { return rb_tok(smod_b + (size_t)chunk * D, 6L * D * f.depth_single, clips * La, La); };
     if (blk == 0) HIPTRY(hipStreamWaitEvent(st, c->ev_mod[0], 0));   // join: the modulation table is ready
-    TRY(launch_ln_mod(c->audio, M, D, 1e-5f, sm(0), sm(1), c->xn_a, T, st));
+    TRY(launch_ln_mod_pending(c->audio, M, D, 1e-5f, sm(0), sm(1), c->xn_a, T, pend[0], st));
+    pend[0] = LnPending{};
     TRY(launch_gemm(gemm_plain(c->xn_a, M, qkv, c->qkv_a, 3 * D), T, EPI_STORE_F32, 0, st));
     QkvSplitArgs q{};
     q.qkv = c->qkv_a; q.M = M; q.L = La; q.H = H; q.nK = 3;
@@ -638,14 +663,21 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
     {
       GemmArgs g = gemm_conv(c->att_a, M, La, D, 3, 1, lin1, c->audio, D);
       g.rb = sm(2);
-      TRY(launch_gemm(g, T, EPI_GATE_RES, 0, st));
+      with_partials(g, c->part_a);
+      int ks = 1;
+      TRY(launch_gemm(g, T, EPI_GATE_RES, 0, st, &ks));
+      if (ks > 1) pend[0] = LnPending{c->part_a, ks, g.partial_stride, lin1.b, g.rb};
     }
-    TRY(launch_ln_mod(c->audio, M, D, 1e-5f, sm(3), sm(4), c->xn_a, T, st));
+    TRY(launch_ln_mod_pending(c->audio, M, D, 1e-5f, sm(3), sm(4), c->xn_a, T, pend[0], st));
+    pend[0] = LnPending{};
     TRY(launch_gemm(gemm_conv(c->xn_a, M, La, D, 3, 1, w13, c->hid_a, Hc), T, EPI_SILUGATE_T, 0, st));
     {
       GemmArgs g = gemm_conv(c->hid_a, M, La, Hc, 3, 1, w2, c->audio, D);
       g.rb = sm(5);
-      TRY(launch_gemm(g, T, EPI_GATE_RES, 0, st));
+      with_partials(g, c->part_a);
+      int ks = 1;
+      TRY(launch_gemm(g, T, EPI_GATE_RES, 0, st, &ks));
+      if (ks > 1) pend[0] = LnPending{c->part_a, ks, g.partial_stride, w2.b, g.rb};
     }
   }
 
@@ -653,7 +685,7 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
   {
     Lin fin;
     TRY(get_lin(c, "final", T, C, D, true, &fin));
-    TRY(launch_ln_mod(c->audio, M, D, 1e-6f, rb_none(), rb_none(), c->xn_a, T, st));
+    TRY(launch_ln_mod_pending(c->audio, M, D, 1e-6f, rb_none(), rb_none(), c->xn_a, T, pend[0], st));
     TRY(launch_gemm(gemm_plain(c->xn_a, M, fin, c->pred, C), T, EPI_STORE_F32, 0, st));
   }
   return 0;
@@ -851,9 +883,16 @@ extern "C" int foley_op_gemm(const foley_gemm_desc* d, void* stream) {
   g.out_shift = d->out_shift; g.out_check = d->out_check; g.rb = to_rb(&d->rb); g.res = d->res;
   g.alpha = d->alpha; g.alphaC = d->alphaC > 0 ? d->alphaC : 1;
   g.ksplit = d->ksplit;
+  if (d->partials) {
+    if (d->partial_slabs < 1) return FAIL(FOLEY_ERR_INVALID, "partials need partial_slabs >= 1");
+    g.partials = d->partials; g.partial_stride = (long)d->M * d->N; g.partial_cap = d->partial_slabs;
+  }
   g.zeros = zero_page();
   if (g.segV < 1 || g.segS < 1 || g.osegV < 1 || g.taps < 1) return FAIL(FOLEY_ERR_INVALID, "bad GEMM descriptor");
-  return launch_gemm(g, d->dtype, d->epilogue, d->tile, (hipStream_t)stream);
+  int ks = 1;
+  const int rc = launch_gemm(g, d->dtype, d->epilogue, d->tile, (hipStream_t)stream, &ks);
+  if (d->ksplit_used) *d->ksplit_used = ks;
+  return rc;
 }
 
 extern "C" int foley_op_attention(const void* q, const void* k, const void* v, int in_dtype, int vt_pitch, int Bq,
@@ -866,6 +905,14 @@ extern "C" int foley_op_attention(const void* q, const void* k, const void* v, i
 extern "C" int foley_op_ln_mod(const float* x, int M, int D, float eps, const foley_rowbcast* shift,
                                const foley_rowbcast* scale, void* out, int out_dtype, void* stream) {
   return launch_ln_mod(x, M, D, eps, to_rb(shift), to_rb(scale), out, out_dtype, (hipStream_t)stream);
+}
+
+extern "C" int foley_op_ln_mod_pending(float* x, int M, int D, float eps, const foley_rowbcast* shift,
+                                       const foley_rowbcast* scale, void* out, int out_dtype, const float* partials,
+                                       int k, const float* bias, const foley_rowbcast* gate, void* stream) {
+  if (!partials || k < 1 || !gate) return FAIL(FOLEY_ERR_INVALID, "pending split-K: partials, k >= 1 and a gate are required");
+  LnPending p{partials, k, (long)M * D, bias, to_rb(gate)};
+  return launch_ln_mod_pending(x, M, D, eps, to_rb(shift), to_rb(scale), out, out_dtype, p, (hipStream_t)stream);
 }
 
 extern "C" int foley_op_qkv_split(const float* qkv, int M, int L, int H, int nK, const float* const* gain,

@@ -12,21 +12,6 @@
 
 namespace {
 
-// dbg_mode 0: 4 stamps per workgroup.  dbg_mode 1: workgroup 0 adds its prologue / K-loop / epilogue
-// ticks and a launch count to dbg[0..3] (totals over every GEMM of a forward pass).
-__device__ __forceinline__ void tl_stamp(const GemmArgs& g, int slot) {
-  if (!g.dbg || threadIdx.x != 0) return;
-  const long long t = wall_clock64();
-  if (g.dbg_mode == 0) {
-    g.dbg[(long)blockIdx.x * 4 + slot] = t;
-  } else if (blockIdx.x == 0) {
-    unsigned long long* d = (unsigned long long*)g.dbg;
-    if (slot > 0) atomicAdd(d + slot - 1, (unsigned long long)t);
-    if (slot < 3) atomicAdd(d + slot, 0ull - (unsigned long long)t);
-    if (slot == 3) atomicAdd(d + 3, 1ull);
-  }
-}
-
 template <typename T, int BM, int BN, int WM, int WN, int NS, int EPI, bool CONV>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmPair pr) {
   const int sel = (int)blockIdx.x >= pr.tiles0 ? 1 : 0;  // wave-uniform
@@ -246,7 +231,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmPair pr) {
   }
 
   tl_stamp(g, 2);
-  if (g.vec_out) gemm_epilogue_lds<T, EPI, BM, BN, WM, WN>(g, acc, lds, m0, n0);
+  if (g.vec_out) gemm_epilogue_lds<T, EPI, BM, BN, WM, WN>(g, acc, lds, m0, n0, ks);
   else gemm_epilogue<T, EPI, FM, FN, TM, TN>(g, acc, m0, n0, wm, wn, fi, kh, ks);
   tl_stamp(g, 3);
 }
@@ -386,6 +371,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmPair p
     b_sw[j] = ((wn * TN + j * 32 + fi) >> 1) & 7;
   }
 
+  bf16x8 fa[4][FM], fb[4][FN];
+  auto mma_bf16 = [&]() {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
+  };
   int stage = 0;
   for (int kt = 0; kt < nk; ++kt) {
     // slice kt has landed once at most the NS-2 younger slices are still in flight
@@ -393,7 +388,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmPair p
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // everyone's part of slice kt is in LDS; stage (kt-1)%NS is free again
     if (kt == 0) tl_stamp(g, 1);
-    if (kt + NS - 1 < nk) issue(stage == 0 ? NS - 1 : stage - 1);
+    if (kt + NS - 1 < nk && !(g.dbg_mode & 0x400)) issue(stage == 0 ? NS - 1 : stage - 1);
     const unsigned char* As = lds + stage * STAGE;
     const unsigned char* Bs = As + BM * 128;
     if constexpr (sizeof(T) == 4) {
@@ -422,26 +417,21 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmPair p
     } else {
       // all fragment reads of the slice are issued up front so the MFMAs run back to back behind
       // counted lgkmcnt waits (LDS latency hidden behind the matrix pipe instead of serialised)
-      bf16x8 a[4][FM], b[4][FN];
+      if (!(g.dbg_mode & 0x200)) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
 #pragma unroll
-        for (int i = 0; i < FM; ++i) a[s][i] = *(const bf16x8*)(As + a_row[i] + (((s * 2 + kh) ^ a_sw[i]) << 4));
+        for (int i = 0; i < FM; ++i) fa[s][i] = *(const bf16x8*)(As + a_row[i] + (((s * 2 + kh) ^ a_sw[i]) << 4));
 #pragma unroll
-        for (int j = 0; j < FN; ++j) b[s][j] = *(const bf16x8*)(Bs + b_row[j] + (((s * 2 + kh) ^ b_sw[j]) << 4));
+        for (int j = 0; j < FN; ++j) fb[s][j] = *(const bf16x8*)(Bs + b_row[j] + (((s * 2 + kh) ^ b_sw[j]) << 4));
       }
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int j = 0; j < FN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+      }
+      if (!(g.dbg_mode & 0x100)) mma_bf16();
     }
     stage = stage + 1 == NS ? 0 : stage + 1;
   }
   tl_stamp(g, 2);
-  if (g.vec_out) gemm_epilogue_lds<T, EPI, BM, BN, WM, WN>(g, acc, lds, m0, n0);
+  if (g.vec_out) gemm_epilogue_lds<T, EPI, BM, BN, WM, WN>(g, acc, lds, m0, n0, ks);
   else gemm_epilogue<T, EPI, FM, FN, TM, TN>(g, acc, m0, n0, wm, wn, fi, kh, ks);
   tl_stamp(g, 3);
 }
@@ -509,7 +499,7 @@ int check_args(const GemmArgs& g) {
 }
 
 template <typename T>
-int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile, hipStream_t st) {
+int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile, hipStream_t st, int* ksplit_used) {
   GemmArgs g = g_in;
   g.dbg = g_gemm_dbg;
   g.dbg_mode = g_gemm_dbg_mode;
@@ -528,12 +518,17 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     return foley_set_err("GEMM: operands must be 16-byte aligned", __FILE__, __LINE__);
   const bool conv3_ok = !g1 && g.taps == 3 && g.dil == 1 && g.tap0 == -1 && g.segV == g.segS && g.lda == g.tapC &&
                         g.osegV >= g.M && (epi == EPI_STORE_F32 || epi == EPI_GATE_RES || epi == EPI_SILUGATE_T);
+  // deferred split-K available (bf16 mode, caller provided partial slabs): reductions are cheap
+  // vector stores + a few extra row reads in the next LayerNorm
+  const bool deferred = epi == EPI_GATE_RES && g.partials && g.partial_cap > 1 && sizeof(T) == 2 && g.ksplit != 1 &&
+                        (!g1 || g1->partials);
   // Measured end to end (xxl, 5 s): the tap-fused kernel wins in fp32 (parity mode, -7 % loop time)
   // and for the small-M gated w1/w3 GEMM; elsewhere the generic tiles (+ split-K / 256x128) are as
   // fast or faster in bf16, so it is only auto-selected there.
-  if (tile == 0 && conv3_ok && (sizeof(T) == 4 || (epi == EPI_SILUGATE_T && g.M < 1024))) {
+  const bool small_grid = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) <= 256;
+  if (tile == 0 && conv3_ok && (sizeof(T) == 4 || (epi == EPI_SILUGATE_T && g.M < 1024) || (deferred && small_grid))) {
     const long b128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    tile = (b128 >= 100 || epi == EPI_SILUGATE_T) ? 11 : 13;   // the gated epilogue needs 64-wide wave tiles
+    tile = (b128 >= 100 || epi == EPI_SILUGATE_T || deferred) ? 11 : 13;   // the gated epilogue needs 64-wide wave tiles
   }
   if (tile == 0) {
     // Tile choice for 256 CUs (measured on the M=500 / M=4000 shapes of the xxl DiT,
@@ -543,6 +538,7 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     const long b128 = nblk(128, 128);
     const long rem = b128 % 256;
     if (sizeof(T) == 2 && g.N > 64 && nblk(256, 128) >= 160) tile = 9;   // big grids: 64x64 per wave
+    else if (deferred && g.N > 64 && b128 <= 256) tile = 5;   // 128x128 tiles, K ranges fill the chip (tools/gemm_timeline.py)
     else if (g.N <= 64 && epi != EPI_SILUGATE_T) tile = nblk(128, 64) >= 192 ? 4 : 3;
     else if (b128 >= 100 && (b128 <= 256 || rem == 0 || rem >= 128 || b128 >= 2048)) tile = 5;
     else if (epi == EPI_SILUGATE_T) tile = nblk(64, 128) >= 192 ? 2 : 5;
@@ -554,6 +550,7 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     // fill ~3 workgroups per CU, keep >= 12 K-slices per range
     static const int bm[14] = {0, 128, 64, 64, 128, 128, 64, 128, 64, 256, 0, 128, 0, 64};
     static const int bn[14] = {0, 128, 128, 64, 64, 128, 64, 128, 128, 128, 0, 128, 0, 64};
+    if (tile < 0 || tile >= 14 || bm[tile] == 0) return foley_set_err("GEMM: unknown tile", __FILE__, __LINE__);
     const long blocks = (long)((g.M + bm[tile] - 1) / bm[tile]) * ((g.N + bn[tile] - 1) / bn[tile]);
     const int nk = (tile == 11 || tile == 13) ? 3 * (g.tapC / BK) / 3 : g.K / BK;   // conv3 splits over channel chunks
     // small tiles want ~3 workgroups per CU; the large, efficient tiles only split when they
@@ -561,9 +558,21 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     const long target = (tile == 1 || tile == 5 || tile == 7 || tile == 9 || tile == 11) ? 192 : (tile == 13 ? 512 : 768);
     long want = (target + blocks - 1) / blocks;
     if (want > nk / 12) want = nk / 12;
+    if (deferred) {   // one resident round of workgroups: as many K ranges as fit on 256 CUs (>= 4 slices each)
+      const int per_cu = (tile == 3 || tile == 6 || tile == 13) ? 3 : 1;
+      want = 256L * per_cu / blocks;
+      if (want > nk / 4) want = nk / 4;
+    }
     g.ksplit = (int)(want < 1 ? 1 : (want > 16 ? 16 : want));
   }
+  if (epi == EPI_GATE_RES && g.partials) {
+    int cap = g.partial_cap;
+    if (g1 && g1s.partial_cap < cap) cap = g1s.partial_cap;
+    if (g1 && !g1s.partials) cap = 1;
+    if (g.ksplit > cap) g.ksplit = cap < 1 ? 1 : cap;
+  }
   if (g1) g1s.ksplit = g.ksplit;
+  if (ksplit_used) *ksplit_used = g.ksplit;
   g.vec_out = gemm_vec_out_ok<T>(g, epi) ? 1 : 0;
   if (g1) g1s.vec_out = gemm_vec_out_ok<T>(g1s, epi) ? 1 : 0;
   if (tile == 11 || tile == 13) {
@@ -591,23 +600,24 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
 
 }  // namespace
 
-int launch_gemm(const GemmArgs& g, int dtype, int epi, int tile, hipStream_t st) {
+int launch_gemm(const GemmArgs& g, int dtype, int epi, int tile, hipStream_t st, int* ksplit_used) {
+  if (ksplit_used) *ksplit_used = 1;
   if (g.M <= 0 || g.N <= 0) return 0;
   if (tile >= 100) {
     if (dtype != FOLEY_BF16 || epi != EPI_STORE_F32 || g.taps != 1)
       return foley_set_err("experimental GEMM variants: bf16 plain store only", __FILE__, __LINE__);
     return launch_gemm_exp(g, tile, st);
   }
-  if (dtype == FOLEY_F32) return launch_typed<float>(g, nullptr, epi, tile, st);
-  if (dtype == FOLEY_BF16) return launch_typed<bf16_t>(g, nullptr, epi, tile, st);
+  if (dtype == FOLEY_F32) return launch_typed<float>(g, nullptr, epi, tile, st, ksplit_used);
+  if (dtype == FOLEY_BF16) return launch_typed<bf16_t>(g, nullptr, epi, tile, st, ksplit_used);
   return foley_set_err("GEMM: unsupported operand dtype", __FILE__, __LINE__);
 }
 
-int launch_gemm_pair(const GemmArgs& g0, const GemmArgs& g1, int dtype, int epi, hipStream_t st) {
-  if (g1.M <= 0 || g1.N <= 0) return launch_gemm(g0, dtype, epi, 0, st);
-  if (g0.M <= 0 || g0.N <= 0) return launch_gemm(g1, dtype, epi, 0, st);
-  if (dtype == FOLEY_F32) return launch_typed<float>(g0, &g1, epi, 0, st);
-  if (dtype == FOLEY_BF16) return launch_typed<bf16_t>(g0, &g1, epi, 0, st);
+int launch_gemm_pair(const GemmArgs& g0, const GemmArgs& g1, int dtype, int epi, hipStream_t st, int* ksplit_used) {
+  if (g1.M <= 0 || g1.N <= 0) return launch_gemm(g0, dtype, epi, 0, st, ksplit_used);
+  if (g0.M <= 0 || g0.N <= 0) return launch_gemm(g1, dtype, epi, 0, st, ksplit_used);
+  if (dtype == FOLEY_F32) return launch_typed<float>(g0, &g1, epi, 0, st, ksplit_used);
+  if (dtype == FOLEY_BF16) return launch_typed<bf16_t>(g0, &g1, epi, 0, st, ksplit_used);
   return foley_set_err("GEMM: unsupported operand dtype", __FILE__, __LINE__);
 }
 

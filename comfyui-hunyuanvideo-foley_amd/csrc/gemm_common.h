@@ -15,6 +15,22 @@ template <> struct Frag<bf16_t> {
   static constexpr int EPC = 8;
 };
 
+// dbg_mode 0: 4 stamps per workgroup.  dbg_mode 1: workgroup 0 adds its prologue / K-loop / epilogue
+// ticks and a launch count to dbg[0..3] (totals over every GEMM of a forward pass).
+__device__ __forceinline__ void tl_stamp(const GemmArgs& g, int slot) {
+  if (!g.dbg || threadIdx.x != 0) return;
+  const long long t = wall_clock64();
+  if ((g.dbg_mode & 0xff) == 0) {
+    g.dbg[(long)blockIdx.x * 4 + slot] = t;
+    if (blockIdx.x == 0 && (slot == 0 || slot == 3)) g.dbg[4 * 8000 + (slot ? 1 : 0)] = (long long)__builtin_readcyclecounter();
+  } else if (blockIdx.x == 0) {
+    unsigned long long* d = (unsigned long long*)g.dbg;
+    if (slot > 0) atomicAdd(d + slot - 1, (unsigned long long)t);
+    if (slot < 3) atomicAdd(d + slot, 0ull - (unsigned long long)t);
+    if (slot == 3) atomicAdd(d + 3, 1ull);
+  }
+}
+
 __device__ __forceinline__ float act_epi(float v, int epi) {
   if (epi == EPI_SILU_T) return silu_f(v);
   if (epi == EPI_GELU_T) return gelu_tanh_f(v);
@@ -76,13 +92,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[F
           if (g.out_check && (rel < 0 || rel >= g.out_seg)) continue;
           const long off = obase + rel;
           float v = acc[i][j][e];
-          if (g.bias && ks == 0) v += g.bias[col];
+          if (g.bias && ks == 0 && !(EPI == EPI_GATE_RES && g.partials && g.ksplit > 1)) v += g.bias[col];
           if constexpr (EPI == EPI_STORE_F32) {
             if (rbp) v += rbp[col];
             ((float*)g.out0)[off] = v;
           } else if constexpr (EPI == EPI_GATE_RES) {
             float* x = (float*)g.out0;
-            if (g.ksplit > 1) unsafeAtomicAdd(x + off, v * rbp[col]);  // global_atomic_add_f32
+            if (g.ksplit > 1 && g.partials) g.partials[ks * g.partial_stride + (long)row * g.N + col] = v;
+            else if (g.ksplit > 1) unsafeAtomicAdd(x + off, v * rbp[col]);  // global_atomic_add_f32
             else x[off] = x[off] + v * rbp[col];
           } else if constexpr (EPI == EPI_DAC) {
             if (g.res) v += g.res[off];
@@ -147,7 +164,7 @@ template <typename T> struct EpiOutT<T, EPI_DAC> { using type = float; };
 
 template <typename T, int EPI, int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&acc)[BM / WM / 32][BN / WN / 32],
-                                                  unsigned char* lds_raw, int m0, int n0) {
+                                                  unsigned char* lds_raw, int m0, int n0, int ks) {
   constexpr int NT = WM * WN * 64, TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
   using OutT = typename EpiOutT<T, EPI>::type;
   constexpr int CP = VecStore<OutT>::CP;                    // output elements per lane and pass
@@ -196,6 +213,19 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
   }
   OutT* out = (OutT*)g.out0 + g.out_shift + gcol;
   const int row0 = m0 + tr;
+
+  if constexpr (EPI == EPI_GATE_RES) {
+    if (g.ksplit > 1) {   // deferred split-K: raw partial product of this K range
+      float* ps = g.partials + ks * g.partial_stride + gcol;
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) {
+        const int row = row0 + p * RP;
+        if (!(col_ok && row < g.M)) continue;
+        *(f32x4*)(ps + (long)row * g.N) = *(const f32x4*)(tile + (p * RP + tr) * BN + ca);
+      }
+      return;
+    }
+  }
 
   if constexpr (EPI == EPI_GATE_RES || EPI == EPI_STORE_F32) {
     RbCursor rc;
@@ -255,7 +285,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
 template <typename T>
 inline bool gemm_vec_out_ok(const GemmArgs& g, int epi) {
   if (epi == EPI_DAC || g.osegV < g.M || g.out_check) return false;
-  if (epi == EPI_GATE_RES && g.ksplit > 1) return false;   // split-K accumulates with scalar atomics
+  if (epi == EPI_GATE_RES && g.ksplit > 1)   // split-K: atomics are scalar; deferred partials are vector stores
+    return g.partials && g.N % 4 == 0 && !((uintptr_t)g.partials & 15) && g.partial_stride % 4 == 0;
   const bool f32 = epi == EPI_STORE_F32 || epi == EPI_GATE_RES || sizeof(T) == 4;
   const int cp = f32 ? 4 : 8;
   const long esz = f32 ? 4 : 2;

@@ -47,6 +47,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_conv3_kernel(const GemmPair 
   const int tm = bid % tiles_m, tn = bid / tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  tl_stamp(g, 0);
   const int wm = wave / WN, wn = wave % WN;
   const int C = g.tapC;  // channels per tap; K = 3*C; activation rows are [row][C]
 
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_conv3_kernel(const GemmPair 
 #pragma unroll
         for (int i = 0; i < RB; ++i) *(u32x4*)(St + w_lds[i]) = w_ok[i] ? rw[j][i] : zero4;
         __syncthreads();
+        if (kt == 0) tl_stamp(g, 1);
         const unsigned char* As = St;
         const unsigned char* Ws = St + AROWS * LDS_PITCH;
 #pragma unroll
@@ -190,8 +192,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_conv3_kernel(const GemmPair 
     }
   }
 #undef FOLEY_GLOAD3
-  if (g.vec_out) gemm_epilogue_lds<T, EPI, BM, BN, WM, WN>(g, acc, lds, m0, n0);
+  tl_stamp(g, 2);
+  if (g.vec_out) gemm_epilogue_lds<T, EPI, BM, BN, WM, WN>(g, acc, lds, m0, n0, ks);
   else gemm_epilogue<T, EPI, FM, FN, TM, TN>(g, acc, m0, n0, wm, wn, fi, kh, ks);
+  tl_stamp(g, 3);
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NS, int EPI>

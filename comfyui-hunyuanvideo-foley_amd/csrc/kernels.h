@@ -45,6 +45,13 @@ struct GemmArgs {
   const void* zeros;  // >= 128 zero bytes in global memory (source of masked rows for the direct-to-LDS loop)
   int ksplit;         // EPI_GATE_RES only: K is cut into `ksplit` ranges whose partial products are
                       // accumulated with hardware fp32 atomics (0 = auto; 1 = deterministic)
+  // Deferred split-K (EPI_GATE_RES, ksplit > 1): with `partials` set, K range s stores its raw partial
+  // product to partials + s*partial_stride ([M, N] row-major fp32, vector stores) instead of using
+  // atomics; the LayerNorm that consumes the residual stream next finishes
+  // x += gate * (sum_s partial_s + bias) (LnPending).  partial_cap = slabs available (caps ksplit).
+  float* partials;
+  long partial_stride;
+  int partial_cap;
   int vec_out;        // set by the launcher: the problem qualifies for the LDS-transposed vector epilogue
   int dbg_mode;
   long long* dbg;     // tools/gemm_timeline.py: 4 wall-clock stamps per workgroup (entry, first slice
@@ -52,11 +59,12 @@ struct GemmArgs {
 };
 
 // dtype: FOLEY_F32 or FOLEY_BF16 operands (accumulation is always fp32). tile: 0 = auto.
-int launch_gemm(const GemmArgs& g, int dtype, int epi, int tile, hipStream_t st);
+// ksplit_used (optional): the K split the launcher chose (callers of the deferred split-K need it)
+int launch_gemm(const GemmArgs& g, int dtype, int epi, int tile, hipStream_t st, int* ksplit_used = nullptr);
 // Two independent problems of the same dtype / epilogue in ONE launch (the audio and the visual
 // stream of a two-stream block): the small problem's workgroups hide in the large one's shadow.
 // Tile shape and K split are chosen for g0.
-int launch_gemm_pair(const GemmArgs& g0, const GemmArgs& g1, int dtype, int epi, hipStream_t st);
+int launch_gemm_pair(const GemmArgs& g0, const GemmArgs& g1, int dtype, int epi, hipStream_t st, int* ksplit_used = nullptr);
 // tap-fused channels-last conv k=3 (gemm_conv3.hip); tile 1 = 128x128, 3 = 64x64; g.ksplit resolved
 int launch_gemm_conv3(const GemmArgs& g, int dtype, int epi, int tile, hipStream_t st);
 // experimental mainloop variants (bf16, plain fp32 store), tile codes >= 100 - see gemm_exp.hip
@@ -89,12 +97,24 @@ int launch_attention(const AttnArgs& a, int out_dtype, hipStream_t st);
 // out(T)[r, :] = LayerNorm(x[r, :]; eps) * (1 + scale) + shift   (scale/shift optional)
 int launch_ln_mod(const float* x, int M, int D, float eps, const RowBcast& shift, const RowBcast& scale,
                   void* out, int out_dtype, hipStream_t st);
+// Pending residual update left by a deferred split-K GEMM (GemmArgs::partials): before normalising,
+// x += gate * (sum_{s<k} partials[s] + bias) and the new x is written back.
+struct LnPending {
+  const float* partials;  // null => nothing pending
+  int k;
+  long stride;
+  const float* bias;      // [D] or null
+  RowBcast gate;
+};
 struct LnArgs {
-  const float* x;
+  float* x;
   int M;
   RowBcast shift, scale;
   void* out;
+  LnPending pend;
 };
+int launch_ln_mod_pending(float* x, int M, int D, float eps, const RowBcast& shift, const RowBcast& scale,
+                          void* out, int out_dtype, const LnPending& pend, hipStream_t st);
 // two row sets (same D / eps / dtype) in one launch
 int launch_ln_mod_pair(const LnArgs& a0, const LnArgs& a1, int D, float eps, int out_dtype, hipStream_t st);
 

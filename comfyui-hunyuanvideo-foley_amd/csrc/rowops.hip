@@ -35,19 +35,19 @@ struct LnPair {
 };
 
 template <typename OutT, int MAXV>
-__global__ __launch_bounds__(256) void ln_mod_kernel(const LnPair pr, int D, float eps) {
+__global__ __launch_bounds__(128) void ln_mod_kernel(const LnPair pr, int D, float eps) {
   const int sel = (int)blockIdx.x >= pr.blocks0 ? 1 : 0;
   const LnArgs& A = pr.a[sel];
-  const float* __restrict__ x = A.x;
+  float* __restrict__ x = A.x;
   const int M = A.M;
   const RowBcast& shift = A.shift;
   const RowBcast& scale = A.scale;
   OutT* __restrict__ out = (OutT*)A.out;
-  const int row = ((int)blockIdx.x - (sel ? pr.blocks0 : 0)) * 4 + (threadIdx.x >> 6);
+  const int row = ((int)blockIdx.x - (sel ? pr.blocks0 : 0)) * 2 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= M) return;
   const int nv = D >> 2;  // float4 per row
-  const f32x4* xr = (const f32x4*)(x + (long)row * D);
+  f32x4* xr = (f32x4*)(x + (long)row * D);
   const f32x4* sh = shift.p ? (const f32x4*)rb_row(shift, row) : nullptr;
   const f32x4* sc = scale.p ? (const f32x4*)rb_row(scale, row) : nullptr;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -58,6 +58,45 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const LnPair pr, int D, flo
     v[i] = xr[c];
     hv[i] = sh ? sh[c] : z4;
     cv[i] = sc ? sc[c] : z4;
+  }
+  if (A.pend.partials) {
+    // finish the deferred split-K GEMM: x += gate * (sum of partial products + bias), SB slabs in
+    // flight at a time (clamped slab index keeps the loads unconditional, weight 0 drops repeats)
+    constexpr int SB = 6;
+    const LnPending& P = A.pend;
+    const f32x4* gp = (const f32x4*)rb_row(P.gate, row);
+    const f32x4* bp = (const f32x4*)P.bias;
+    f32x4 acc[MAXV], gt[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = min(lane + i * 64, nv - 1);
+      gt[i] = gp[c];
+      acc[i] = bp ? bp[c] : z4;
+    }
+    for (int s0 = 0; s0 < P.k; s0 += SB) {
+      f32x4 t[SB][MAXV];
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        const int s = min(s0 + u, P.k - 1);
+        const f32x4* pr_ = (const f32x4*)(P.partials + s * P.stride + (long)row * D);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) t[u][i] = pr_[min(lane + i * 64, nv - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        const float w = (s0 + u < P.k) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][e] += w * t[u][i][e];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[i][e] += gt[i][e] * acc[i][e];
+      if (lane + i * 64 < nv) xr[lane + i * 64] = v[i];
+    }
   }
   float s = 0.f;
 #pragma unroll
@@ -362,22 +401,46 @@ inline int grid1d(long n, int block) {
 
 int launch_ln_mod_pair(const LnArgs& a0, const LnArgs& a1, int D, float eps, int out_dtype, hipStream_t st) {
   if (D % 4 || D > 8 * 256) return foley_set_err("ln_mod: D must be a multiple of 4 and <= 2048", __FILE__, __LINE__);
+  for (const LnArgs* a : {&a0, &a1})
+    if (a->M > 0 && a->pend.partials &&
+        (a->pend.k < 1 || a->pend.stride % 4 || ((uintptr_t)a->pend.partials & 15) || ((uintptr_t)a->pend.bias & 15) ||
+         !a->pend.gate.p || ((uintptr_t)a->pend.gate.p & 15) || a->pend.gate.ld % 4 || a->pend.gate.step_stride % 4))
+      return foley_set_err("ln_mod: bad pending split-K descriptor", __FILE__, __LINE__);
   LnPair pr;
   pr.a[0] = a0;
   pr.a[1] = a1;
-  pr.blocks0 = (a0.M + 3) / 4;
-  dim3 grid(pr.blocks0 + (a1.M + 3) / 4), block(256);
-  if (out_dtype == FOLEY_F32) hipLaunchKernelGGL((ln_mod_kernel<float, 8>), grid, block, 0, st, pr, D, eps);
-  else if (out_dtype == FOLEY_BF16) hipLaunchKernelGGL((ln_mod_kernel<bf16_t, 8>), grid, block, 0, st, pr, D, eps);
-  else return foley_set_err("ln_mod: bad dtype", __FILE__, __LINE__);
+  pr.blocks0 = (a0.M + 1) / 2;
+  dim3 grid(pr.blocks0 + (a1.M + 1) / 2), block(128);
+  const int need = (D / 4 + 63) / 64;   // float4 per lane
+  if (out_dtype != FOLEY_F32 && out_dtype != FOLEY_BF16) return foley_set_err("ln_mod: bad dtype", __FILE__, __LINE__);
+  const bool f32o = out_dtype == FOLEY_F32;
+#define FOLEY_LN(V)                                                                                        \
+  {                                                                                                        \
+    if (f32o) hipLaunchKernelGGL((ln_mod_kernel<float, V>), grid, block, 0, st, pr, D, eps);               \
+    else hipLaunchKernelGGL((ln_mod_kernel<bf16_t, V>), grid, block, 0, st, pr, D, eps);                   \
+  }
+  if (need <= 2) FOLEY_LN(2)
+  else if (need <= 4) FOLEY_LN(4)
+  else if (need <= 6) FOLEY_LN(6)
+  else FOLEY_LN(8)
+#undef FOLEY_LN
   FOLEY_LAUNCH_CHECK();
   return 0;
 }
 
 int launch_ln_mod(const float* x, int M, int D, float eps, const RowBcast& shift, const RowBcast& scale,
                   void* out, int out_dtype, hipStream_t st) {
-  LnArgs a0{x, M, shift, scale, out};
-  LnArgs a1{x, 0, shift, scale, out};
+  LnArgs a0{const_cast<float*>(x), M, shift, scale, out, LnPending{}};
+  LnArgs a1 = a0;
+  a1.M = 0;
+  return launch_ln_mod_pair(a0, a1, D, eps, out_dtype, st);
+}
+
+int launch_ln_mod_pending(float* x, int M, int D, float eps, const RowBcast& shift, const RowBcast& scale,
+                          void* out, int out_dtype, const LnPending& pend, hipStream_t st) {
+  LnArgs a0{x, M, shift, scale, out, pend};
+  LnArgs a1 = a0;
+  a1.M = 0;
   return launch_ln_mod_pair(a0, a1, D, eps, out_dtype, st);
 }
 

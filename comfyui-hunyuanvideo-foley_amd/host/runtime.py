@@ -59,6 +59,7 @@ class GemmDescC(C.Structure):
         ("out_check", C.c_int32),
         ("rb", RowBcastC), ("res", C.c_void_p), ("alpha", C.c_void_p), ("alphaC", C.c_int32),
         ("dtype", C.c_int32), ("epilogue", C.c_int32), ("tile", C.c_int32), ("ksplit", C.c_int32),
+        ("partials", C.c_void_p), ("partial_slabs", C.c_int32), ("ksplit_used", C.POINTER(C.c_int32)),
     ]
 
 
@@ -78,6 +79,9 @@ _SIGNATURES = {
     "foley_op_gemm": (C.c_int, [C.POINTER(GemmDescC), C.c_void_p]),
     "foley_op_attention": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                                                         C.c_void_p]),
+    "foley_op_ln_mod_pending": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.POINTER(RowBcastC),
+                                          C.POINTER(RowBcastC), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                          C.POINTER(RowBcastC), C.c_void_p]),
     "foley_op_ln_mod": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.POINTER(RowBcastC),
                                   C.POINTER(RowBcastC), C.c_void_p, C.c_int, C.c_void_p]),
     "foley_op_qkv_split": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
@@ -256,8 +260,11 @@ def rowbcast(t: Optional[torch.Tensor], mode: int = 0, rows_per_cfg: int = 1, L:
 
 
 def op_gemm(A, W, bias=None, *, M=None, epilogue=EPI_STORE_F32, out0=None, out1=None, ldc=None, conv=None,
-            convT=None, rb: Optional[RowBcastC] = None, res=None, alpha=None, alphaC=1, tile=0, ksplit=0):
-    """Thin wrapper over foley_op_gemm.  conv=(seg, C, taps, dil) ; convT=(Tin, Cin, stride, Cout)."""
+            convT=None, rb: Optional[RowBcastC] = None, res=None, alpha=None, alphaC=1, tile=0, ksplit=0,
+            partials=None) -> int:
+    """Thin wrapper over foley_op_gemm.  conv=(seg, C, taps, dil) ; convT=(Tin, Cin, stride, Cout).
+    partials: fp32 [slabs, M, N] workspace for the deferred split-K of the gated-residual epilogue.
+    Returns the K split the launcher used."""
     lib = load_library()
     d = GemmDescC()
     N, K = W.shape
@@ -290,7 +297,12 @@ def op_gemm(A, W, bias=None, *, M=None, epilogue=EPI_STORE_F32, out0=None, out1=
     d.res = _ptr(res) if res is not None else None
     d.alpha = _ptr(alpha) if alpha is not None else None
     d.alphaC = alphaC
+    used = C.c_int32(1)
+    d.ksplit_used = C.pointer(used)
+    if partials is not None:
+        d.partials, d.partial_slabs = _ptr(partials), partials.shape[0]
     _check(lib, lib.foley_op_gemm(C.byref(d), _stream()), "foley_op_gemm")
+    return int(used.value)
 
 
 def op_attention(q, k, v, outA, outB, split: int, kv_bdiv: int = 1):
@@ -309,6 +321,17 @@ def op_ln_mod(x, eps, shift: Optional[RowBcastC], scale: Optional[RowBcastC], ou
     _check(lib, lib.foley_op_ln_mod(_ptr(x), M, D, eps, C.byref(shift) if shift else None,
                                     C.byref(scale) if scale else None, _ptr(out), dt_of(out), _stream()),
            "foley_op_ln_mod")
+
+
+def op_ln_mod_pending(x, eps, shift: Optional[RowBcastC], scale: Optional[RowBcastC], out, partials, k: int, bias,
+                      gate: RowBcastC):
+    """LayerNorm of x after x += gate * (sum(partials[:k]) + bias), x updated in place."""
+    lib = load_library()
+    M, D = x.shape
+    _check(lib, lib.foley_op_ln_mod_pending(_ptr(x), M, D, eps, C.byref(shift) if shift else None,
+                                            C.byref(scale) if scale else None, _ptr(out), dt_of(out), _ptr(partials),
+                                            k, _ptr(bias) if bias is not None else None, C.byref(gate), _stream()),
+           "foley_op_ln_mod_pending")
 
 
 def op_qkv_split(qkv, L, H, gains: Sequence, poss: Sequence, dsts: Sequence, S_tot, tok_off, eps, cos, sin,

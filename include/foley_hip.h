@@ -132,7 +132,14 @@ typedef struct foley_gemm_desc {
   int32_t dtype;   /* operand dtype */
   int32_t epilogue;/* 0 store f32, 1 store T, 2 silu T, 3 gelu-tanh T, 4 silu-gate T, 5 gated residual, 6 DAC */
   int32_t tile;    /* 0 auto */
-  int32_t ksplit;  /* gated-residual epilogue: K ranges accumulated with fp32 atomics (0 auto, 1 deterministic) */
+  int32_t ksplit;  /* gated-residual epilogue: K ranges (0 auto, 1 deterministic); ranges are combined with
+                    * fp32 atomics, or - when `partials` is set - deferred to the next LayerNorm */
+  /* Deferred split-K: K range s stores its raw product to partials[s][M][N] (fp32, 16-byte aligned,
+   * room for partial_slabs ranges; caps ksplit) and out0 is NOT touched; the caller then runs
+   * foley_op_ln_mod_pending(out0, ..., partials, *ksplit_used, bias, gate), which performs
+   * x += gate * (sum_s partials[s] + bias) before normalising.  With *ksplit_used == 1 the GEMM
+   * has already updated out0 and nothing is pending. */
+  float* partials; int32_t partial_slabs; int32_t* ksplit_used;
 } foley_gemm_desc;
 
 int foley_op_gemm(const foley_gemm_desc* d, void* stream);
@@ -143,6 +150,11 @@ int foley_op_attention(const void* q, const void* k, const void* v, int in_dtype
                        void* stream);
 int foley_op_ln_mod(const float* x, int M, int D, float eps, const foley_rowbcast* shift,
                     const foley_rowbcast* scale, void* out, int out_dtype, void* stream);
+/* LayerNorm (+ modulation) of a residual stream that first receives the pending update of a deferred
+ * split-K gated-residual GEMM (see foley_gemm_desc.partials); x is updated in place. */
+int foley_op_ln_mod_pending(float* x, int M, int D, float eps, const foley_rowbcast* shift,
+                            const foley_rowbcast* scale, void* out, int out_dtype, const float* partials,
+                            int k, const float* bias, const foley_rowbcast* gate, void* stream);
 /* vt_pitch > 0: the last operand is written transposed [clips, H, 128, vt_pitch] (see above). */
 int foley_op_qkv_split(const float* qkv, int M, int L, int H, int nK, const float* const* gain,
                        const int32_t* const* pos, void* const* dst, int out_dtype, int vt_pitch, int S_tot,

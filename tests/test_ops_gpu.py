@@ -128,6 +128,53 @@ def test_gemm_split_k(dev, ksplit, conv):
     assert rel_err(out, res0 + y * gate) < 1e-5
 
 
+@pytest.mark.parametrize("ksplit", [0, 2, 3, 7])
+@pytest.mark.parametrize("conv", [False, True, 11, 13])
+@pytest.mark.parametrize("tok_gate", [False, True])
+def test_gemm_deferred_split_k(dev, ksplit, conv, tok_gate):
+    """Deferred split-K: the gated-residual GEMM leaves raw partial products per K range, the next
+    LayerNorm applies x += gate * (sum + bias) in place before normalising (no atomics)."""
+    ncfg, clips, L, C, N = 2, 1, 50, 256, 192
+    B = ncfg * clips
+    x, w, b = _rand((B, L, C), 24), _rand((N, C, 3), 25, 1 / math.sqrt(3 * C)), _rand((N,), 26, 0.1)
+    dt = torch.bfloat16
+    res0 = _rand((B * L, N), 27)
+    if tok_gate:   # per-(cfg, token) gate rows, as the single-stream blocks use
+        gate = _rand((ncfg * L, N), 28)
+        g_full = gate.view(ncfg, 1, L, N).expand(ncfg, clips, L, N).reshape(B * L, N)
+        rb = rt.rowbcast(gate.to(dev), 1, rows_per_cfg=clips * L, L=L)
+    else:
+        gate = _rand((N,), 28)
+        g_full = gate
+        rb = rt.rowbcast(gate.to(dev), 0)
+    if conv:
+        y = O.conv1d_cl(_q(x, dt), _q(w, dt), b, 1).reshape(B * L, N)
+        Wp, kw = packers.conv_to_gemm(w), dict(conv=(L, C, 3, 1))
+        if conv in (11, 13):
+            kw["tile"] = conv
+    else:
+        y = F.linear(_q(x, dt).reshape(B * L, C), _q(w[:, :, 0], dt), b)
+        Wp, kw = w[:, :, 0].contiguous(), {}
+    xres = res0.to(dev).clone()
+    slabs = torch.full((8, B * L, N), float("nan"), device=dev)
+    used = rt.op_gemm(x.reshape(B * L, C).to(dev, dt), Wp.to(dev, dt), b.to(dev), out0=xres, epilogue=rt.EPI_GATE_RES,
+                      rb=rb, ksplit=ksplit, partials=slabs, **kw)
+    assert 1 <= used <= 8 and (ksplit == 0 or used == ksplit)
+    want_x = res0 + y * g_full
+    shift, scale = _rand((N,), 29), _rand((N,), 30)
+    out = torch.empty(B * L, N, device=dev)
+    if used > 1:
+        assert torch.equal(xres.cpu(), res0)                       # residual untouched by the GEMM
+        assert rel_err(slabs[:used].sum(0), y - b) < 1e-5          # raw products, bias not included
+        rt.op_ln_mod_pending(xres, 1e-6, rt.rowbcast(shift.to(dev), 0), rt.rowbcast(scale.to(dev), 0), out, slabs, used,
+                             b.to(dev), rb)
+    else:
+        rt.op_ln_mod(xres, 1e-6, rt.rowbcast(shift.to(dev), 0), rt.rowbcast(scale.to(dev), 0), out)
+    assert rel_err(xres, want_x) < 1e-5
+    ref = F.layer_norm(want_x, (N,), eps=1e-6) * (1 + scale) + shift
+    assert rel_err(out, ref) < 1e-4
+
+
 # ----------------------------------------------------------------------------- GEMM: conv addressing
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("tile", [0, 3, 5, 6, 11, 13])

@@ -23,8 +23,11 @@ SHAPES = {"qkv": (4608, 1536), "proj": (1536, 1536), "fc1": (6144, 1536), "fc2":
 ap = argparse.ArgumentParser()
 ap.add_argument("--m", type=int, default=500)
 ap.add_argument("--shape", default="w2")
-ap.add_argument("--tile", type=int, default=5)
-ap.add_argument("--ksplit", type=int, default=0, help="0 = plain fp32 store epilogue")
+ap.add_argument("--tile", default="5", help="comma list")
+ap.add_argument("--ksplit", default="0", help="comma list; 0 = plain fp32 store epilogue")
+ap.add_argument("--partials", action="store_true", help="deferred split-K (partial slabs) instead of atomics")
+ap.add_argument("--brief", action="store_true")
+ap.add_argument("--ablate", type=int, default=0, help="debug bits: 1 no MFMA, 2 no fragment reads, 4 no global->LDS loads (glds kernels)")
 ap.add_argument("--conv", action="store_true")
 ap.add_argument("--warm", action="store_true", help="measure with the weight matrix just used (L2 / Infinity-Cache warm)")
 a = ap.parse_args()
@@ -40,28 +43,15 @@ x = torch.zeros(a.m, N, device=dev)
 gate = torch.randn(N, device=dev)
 
 
-def run(W):
-    if a.ksplit:
-        rt.op_gemm(A, W, None, out0=x, tile=a.tile, epilogue=rt.EPI_GATE_RES, rb=rt.rowbcast(gate, 0), ksplit=a.ksplit, **ckw)
+slabs = torch.empty(16, a.m, N, device=dev) if a.partials else None
+
+
+def run(W, tile, ksplit):
+    if ksplit:
+        rt.op_gemm(A, W, None, out0=x, tile=tile, epilogue=rt.EPI_GATE_RES, rb=rt.rowbcast(gate, 0), ksplit=ksplit,
+                   partials=slabs, **ckw)
     else:
-        rt.op_gemm(A, W, None, out0=x, tile=a.tile, **ckw)
-
-
-for W in Ws[:3]:
-    run(W)
-torch.cuda.synchronize()
-dbg = torch.zeros(8192 * 4, dtype=torch.int64, device=dev)
-lib.foley_debug_gemm_timeline(C.c_void_p(dbg.data_ptr()), 0)
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-run(Ws[2] if a.warm else Ws[-1])
-e1.record()
-torch.cuda.synchronize()
-lib.foley_debug_gemm_timeline(None, 0)
-t = dbg.view(-1, 4).cpu()
-t = t[t[:, 0] > 0].double()
-t0 = t[:, 0].min()
-t = (t - t0) / 100.0  # us
+        rt.op_gemm(A, W, None, out0=x, tile=tile, **ckw)
 
 
 def q(v):
@@ -70,9 +60,34 @@ def q(v):
     return f"min {v[0]:6.2f}  p50 {v[n // 2]:6.2f}  p90 {v[int(n * 0.9)]:6.2f}  max {v[-1]:6.2f}"
 
 
-print(f"{a.shape} M={a.m} N={N} K={K} tile={a.tile} ksplit={a.ksplit} conv={a.conv}: {len(t)} workgroups, event time {e0.elapsed_time(e1) * 1e3:.1f} us")
-print("entry            (us after first):", q(t[:, 0]))
-print("first slice landed - entry       :", q(t[:, 1] - t[:, 0]))
-print("K loop (after first slice)       :", q(t[:, 2] - t[:, 1]))
-print("epilogue                         :", q(t[:, 3] - t[:, 2]))
-print("exit             (us after first):", q(t[:, 3]))
+for tile in [int(v) for v in a.tile.split(",")]:
+    for ksplit in [int(v) for v in a.ksplit.split(",")]:
+        for W in Ws[:3]:
+            run(W, tile, ksplit)
+        torch.cuda.synchronize()
+        spans = []
+        for rep in range(5):
+            dbg = torch.zeros(8192 * 4, dtype=torch.int64, device=dev)
+            lib.foley_debug_gemm_timeline(C.c_void_p(dbg.data_ptr()), a.ablate << 8)
+            run(Ws[2] if a.warm else Ws[(3 + rep) % len(Ws)], tile, ksplit)
+            torch.cuda.synchronize()
+            lib.foley_debug_gemm_timeline(None, 0)
+            t = dbg.view(-1, 4).cpu()
+            cyc = t[8000, 1] - t[8000, 0]
+            wall0 = (t[0, 3] - t[0, 0]) / 100.0
+            t = t[:8000]
+            t = t[t[:, 0] > 0].double()
+            t = (t - t[:, 0].min()) / 100.0  # us
+            spans.append((float(t[:, 3].max()), t, float(cyc) / max(float(wall0), 1e-3) / 1e3))
+        spans.sort(key=lambda z: z[0])
+        span, t, ghz = spans[len(spans) // 2]
+        if a.brief:
+            print(f"{a.shape:5s} t{tile}k{ksplit}{'p' if a.partials and ksplit else ''}: wgs {len(t):4d} span {span:6.1f} us | pro p50 {float((t[:, 1] - t[:, 0]).median()):5.2f} "
+                  f"loop p50 {float((t[:, 2] - t[:, 1]).median()):6.2f} max {float((t[:, 2] - t[:, 1]).max()):6.2f} epi p50 {float((t[:, 3] - t[:, 2]).median()):5.2f} | {ghz:.2f} GHz", flush=True)
+            continue
+        print(f"{a.shape} M={a.m} N={N} K={K} tile={tile} ksplit={ksplit} conv={a.conv}: {len(t)} workgroups, span {span:.1f} us")
+        print("entry            (us after first):", q(t[:, 0]))
+        print("first slice landed - entry       :", q(t[:, 1] - t[:, 0]))
+        print("K loop (after first slice)       :", q(t[:, 2] - t[:, 1]))
+        print("epilogue                         :", q(t[:, 3] - t[:, 2]))
+        print("exit             (us after first):", q(t[:, 3]))
