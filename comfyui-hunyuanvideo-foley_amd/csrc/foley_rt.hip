@@ -587,9 +587,11 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
       TRY(get_tensor(c, p + "v_qn", FOLEY_F32, {128}, &vqn));
       TRY(get_tensor(c, p + "v_kn", FOLEY_F32, {128}, &vkn));
       TRY(ln2(0, 1));
-      TRY(launch_gemm_pair(gemm_plain(ss[0].xn, ss[0].rows, qa, ss[0].qkv, 3 * D),
-                           gemm_plain(ss[1].xn, ss[1].rows, qv, ss[1].qkv, 3 * D), T, EPI_STORE_F32, st));
-      TRY(launch_qkv_split_pair(split_args(0, 3, aqn, akn, ss[0].pos), split_args(1, 3, vqn, vkn, ss[1].pos), st));
+      GemmArgs g0 = gemm_plain(ss[0].xn, ss[0].rows, qa, ss[0].qkv, 3 * D);
+      GemmArgs g1 = gemm_plain(ss[1].xn, ss[1].rows, qv, ss[1].qkv, 3 * D);
+      g0.qs = split_args(0, 3, aqn, akn, ss[0].pos);
+      g1.qs = split_args(1, 3, vqn, vkn, ss[1].pos);
+      TRY(launch_gemm_pair(g0, g1, T, EPI_QKV_SPLIT, st));   // head split fused into the projection
       AttnArgs a{c->Q, c->K, c->V, Bc, H, S, S, 1, c->att_v, c->att_a, Lv, T, bf ? Sp : 0};
       TRY(launch_attention(a, T, st));
       Lin pa, pv;
@@ -604,10 +606,11 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
       TRY(get_tensor(c, p + "a_cqn", FOLEY_F32, {128}, &aqn));
       TRY(get_tensor(c, p + "v_cqn", FOLEY_F32, {128}, &vqn));
       TRY(ln2(3, 4));
-      TRY(launch_gemm_pair(gemm_plain(ss[0].xn, ss[0].rows, qa, ss[0].qkv, D),
-                           gemm_plain(ss[1].xn, ss[1].rows, qv, ss[1].qkv, D), T, EPI_STORE_F32, st));
-      TRY(launch_qkv_split_pair(split_args(0, 1, aqn, nullptr, pl.pos_linear),
-                                split_args(1, 1, vqn, nullptr, pl.pos_linear), st));
+      GemmArgs g0 = gemm_plain(ss[0].xn, ss[0].rows, qa, ss[0].qkv, D);
+      GemmArgs g1 = gemm_plain(ss[1].xn, ss[1].rows, qv, ss[1].qkv, D);
+      g0.qs = split_args(0, 1, aqn, nullptr, pl.pos_linear);
+      g1.qs = split_args(1, 1, vqn, nullptr, pl.pos_linear);
+      TRY(launch_gemm_pair(g0, g1, T, EPI_QKV_SPLIT, st));
       const int Ltp = (Lt + 31) & ~31;
       const size_t offk = (size_t)blk * ncfg * H * Lt * 128 * es;
       const size_t offv = (size_t)blk * ncfg * H * (bf ? Ltp : Lt) * 128 * es;
@@ -646,7 +649,7 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
     if (blk == 0) HIPTRY(hipStreamWaitEvent(st, c->ev_mod[0], 0));   // join: the modulation table is ready
     TRY(launch_ln_mod_pending(c->audio, M, D, 1e-5f, sm(0), sm(1), c->xn_a, T, pend[0], st));
     pend[0] = LnPending{};
-    TRY(launch_gemm(gemm_plain(c->xn_a, M, qkv, c->qkv_a, 3 * D), T, EPI_STORE_F32, 0, st));
+    GemmArgs gq = gemm_plain(c->xn_a, M, qkv, c->qkv_a, 3 * D);
     QkvSplitArgs q{};
     q.qkv = c->qkv_a; q.M = M; q.L = La; q.H = H; q.nK = 3;
     q.gain[0] = (const float*)qn; q.gain[1] = (const float*)kn;
@@ -655,7 +658,8 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
     q.out_dtype = T; q.vt_pitch = bf ? Lap : 0;
     q.S_tot = La; q.tok_off = 0; q.eps = 1.1920928955078125e-07f;  // nn.RMSNorm(eps=None) -> finfo(fp32).eps
     q.cos_tab = pl.rope_cos; q.sin_tab = pl.rope_sin;
-    TRY(launch_qkv_split(q, st));
+    gq.qs = q;
+    TRY(launch_gemm(gq, T, EPI_QKV_SPLIT, 0, st));
     {
       AttnArgs a{c->Q, c->K, c->V, Bc, H, La, La, 1, c->att_a, c->att_a, 0, T, bf ? Lap : 0};
       TRY(launch_attention(a, T, st));
@@ -889,6 +893,15 @@ extern "C" int foley_op_gemm(const foley_gemm_desc* d, void* stream) {
   }
   g.zeros = zero_page();
   if (g.segV < 1 || g.segS < 1 || g.osegV < 1 || g.taps < 1) return FAIL(FOLEY_ERR_INVALID, "bad GEMM descriptor");
+  if (d->epilogue == EPI_QKV_SPLIT) {
+    const foley_qkv_split_desc* q = d->qkv;
+    if (!q) return FAIL(FOLEY_ERR_INVALID, "epilogue 7 needs a head-split descriptor");
+    QkvSplitArgs& a = g.qs;
+    a.qkv = nullptr; a.M = d->M; a.L = q->L; a.H = q->H; a.nK = q->nK;
+    for (int i = 0; i < 3; ++i) { a.gain[i] = q->gain[i]; a.pos[i] = q->pos[i]; a.dst[i] = q->dst[i]; }
+    a.S_tot = q->S_tot; a.tok_off = q->tok_off; a.out_dtype = q->out_dtype; a.vt_pitch = q->vt_pitch;
+    a.eps = q->eps; a.cos_tab = q->cos_tab; a.sin_tab = q->sin_tab;
+  }
   int ks = 1;
   const int rc = launch_gemm(g, d->dtype, d->epilogue, d->tile, (hipStream_t)stream, &ks);
   if (d->ksplit_used) *d->ksplit_used = ks;

@@ -231,8 +231,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmPair pr) {
   }
 
   tl_stamp(g, 2);
-  if (g.vec_out) gemm_epilogue_lds<T, EPI, BM, BN, WM, WN>(g, acc, lds, m0, n0, ks);
-  else gemm_epilogue<T, EPI, FM, FN, TM, TN>(g, acc, m0, n0, wm, wn, fi, kh, ks);
+  if constexpr (EPI == EPI_QKV_SPLIT) {
+    gemm_epilogue_qkv<T, BM, BN, WM, WN>(g, acc, lds, m0, n0);
+  } else {
+    if (g.vec_out) gemm_epilogue_lds<T, EPI, BM, BN, WM, WN>(g, acc, lds, m0, n0, ks);
+    else gemm_epilogue<T, EPI, FM, FN, TM, TN>(g, acc, m0, n0, wm, wn, fi, kh, ks);
+  }
   tl_stamp(g, 3);
 }
 
@@ -431,8 +435,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmPair p
     stage = stage + 1 == NS ? 0 : stage + 1;
   }
   tl_stamp(g, 2);
-  if (g.vec_out) gemm_epilogue_lds<T, EPI, BM, BN, WM, WN>(g, acc, lds, m0, n0, ks);
-  else gemm_epilogue<T, EPI, FM, FN, TM, TN>(g, acc, m0, n0, wm, wn, fi, kh, ks);
+  if constexpr (EPI == EPI_QKV_SPLIT) {
+    gemm_epilogue_qkv<T, BM, BN, WM, WN>(g, acc, lds, m0, n0);
+  } else {
+    if (g.vec_out) gemm_epilogue_lds<T, EPI, BM, BN, WM, WN>(g, acc, lds, m0, n0, ks);
+    else gemm_epilogue<T, EPI, FM, FN, TM, TN>(g, acc, m0, n0, wm, wn, fi, kh, ks);
+  }
   tl_stamp(g, 3);
 }
 
@@ -478,6 +486,9 @@ int launch_tile(const GemmArgs& g, const GemmArgs* g1, int epi, hipStream_t st) 
     case EPI_SILUGATE_T:
       if constexpr ((BN / WN) % 64 == 0) return launch_one<T, BM, BN, WM, WN, NS, EPI_SILUGATE_T, GLDS>(g, g1, st);
       else return foley_set_err("gated epilogue needs a 64-wide wave tile", __FILE__, __LINE__);
+    case EPI_QKV_SPLIT:
+      if constexpr (BN == 128) return launch_one<T, BM, BN, WM, WN, NS, EPI_QKV_SPLIT, GLDS>(g, g1, st);
+      else return foley_set_err("fused head-split epilogue needs a 128-column tile", __FILE__, __LINE__);
     case EPI_DAC:
       if constexpr (sizeof(T) == 4) return launch_one<T, BM, BN, WM, WN, NS, EPI_DAC, GLDS>(g, g1, st);
       else return foley_set_err("DAC epilogue is fp32 only", __FILE__, __LINE__);
@@ -543,6 +554,27 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     else if (b128 >= 100 && (b128 <= 256 || rem == 0 || rem >= 128 || b128 >= 2048)) tile = 5;
     else if (epi == EPI_SILUGATE_T) tile = nblk(64, 128) >= 192 ? 2 : 5;
     else tile = 3;
+  }
+  if (epi == EPI_QKV_SPLIT) {
+    for (const GemmArgs* q : {(const GemmArgs*)&g, g1}) {
+      if (!q) continue;
+      const QkvSplitArgs& s = q->qs;
+      if (s.nK < 1 || s.nK > 3 || s.H < 1 || q->N != s.nK * s.H * 128 || s.L < 1 || q->M % s.L)
+        return foley_set_err("fused head split: N must be nK*H*128 and M a multiple of L", __FILE__, __LINE__);
+      if (s.out_dtype != (sizeof(T) == 2 ? FOLEY_BF16 : FOLEY_F32))
+        return foley_set_err("fused head split: output dtype must equal the operand dtype", __FILE__, __LINE__);
+      if (s.vt_pitch && (sizeof(T) != 2 || s.vt_pitch % 8 || (s.tok_off + s.L) > s.vt_pitch))
+        return foley_set_err("fused head split: bad transposed-V pitch", __FILE__, __LINE__);
+      uintptr_t al = (uintptr_t)s.cos_tab | (uintptr_t)s.sin_tab | (uintptr_t)q->bias;
+      for (int i = 0; i < s.nK; ++i) {
+        if (!s.dst[i]) return foley_set_err("fused head split: null destination", __FILE__, __LINE__);
+        al |= (uintptr_t)s.dst[i] | (uintptr_t)s.gain[i];
+        if (s.pos[i] && (!s.cos_tab || !s.sin_tab)) return foley_set_err("fused head split: RoPE tables missing", __FILE__, __LINE__);
+      }
+      if (al & 15) return foley_set_err("fused head split: operands must be 16-byte aligned", __FILE__, __LINE__);
+    }
+    if (!(tile == 1 || tile == 2 || tile == 5 || tile == 7 || tile == 8 || tile == 9))
+      tile = (long)((g.M + 127) / 128) * (g.N / 128) >= 24 ? 5 : 2;
   }
   if (epi != EPI_GATE_RES || g.ksplit == 1 || (g.ksplit == 0 && sizeof(T) == 4)) {
     g.ksplit = 1;   // fp32 (parity) mode keeps a fixed summation order

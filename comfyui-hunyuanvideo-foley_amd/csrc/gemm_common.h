@@ -281,6 +281,130 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// EPI_QKV_SPLIT: the fused q/k/v (or cross-attention q) projection never materialises [M, nK*H*128].
+// A 128-column tile is exactly one head of one operand, so after the LDS transpose every output row
+// is a complete head vector: q/k get RMSNorm (norm_layers.py:36-52 / nn.RMSNorm) and interleaved
+// RoPE (attn_layers.py:112-146) and leave as 16-byte stores into [clip, H, S_tot, 128]; V leaves
+// transposed [clip, H, 128, pitch] for the bf16 attention kernel, 8 tokens (16 bytes) per store on
+// destination-aligned groups.  Same math as qkv_split_kernel (rowops.hip), which stays for callers
+// that have the projection in memory.
+template <typename T, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&acc)[BM / WM / 32][BN / WN / 32],
+                                                  unsigned char* lds_raw, int m0, int n0) {
+  static_assert(BN == 128, "one head per tile");
+  constexpr int NT = WM * WN * 64, TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
+  const QkvSplitArgs& q = g.qs;
+  float* tile = (float*)lds_raw;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN, fi = lane & 31, kh = lane >> 5;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        tile[(wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh) * BN + wn * TN + j * 32 + fi] = acc[i][j][e];
+  __syncthreads();
+  const int hidx = n0 >> 7;
+  const int o = hidx / q.H, h = hidx - o * q.H;   // operand (q, k, v), head
+  if (n0 >= g.N) return;
+  const bool vtrans = q.vt_pitch > 0 && o == q.nK - 1;
+  if (!vtrans) {
+    constexpr int CP = VecStore<T>::CP, TPR = 128 / CP, RP = NT / TPR, PASSES = BM / RP;
+    static_assert(NT % TPR == 0 && BM % RP == 0 && PASSES >= 1, "tile / epilogue mismatch");
+    const int tr = tid / TPR, tc = (tid % TPR) * CP;
+    float bias[CP], gain[CP];
+    const float* gp = q.gain[o];
+#pragma unroll
+    for (int u = 0; u < CP; u += 4) {
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f}, gv = {1.f, 1.f, 1.f, 1.f};
+      if (g.bias) bv = *(const f32x4*)(g.bias + n0 + tc + u);
+      if (gp) gv = *(const f32x4*)(gp + tc + u);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { bias[u + w] = bv[w]; gain[u + w] = gv[w]; }
+    }
+    const int* pos = q.pos[o];
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int rl = p * RP + tr;
+      const int row = m0 + rl;
+      const bool ok = row < g.M;
+      const int rr = ok ? row : g.M - 1;
+      const int b = rr / q.L, l = rr - b * q.L;
+      float v[CP];
+#pragma unroll
+      for (int u = 0; u < CP; u += 4) {
+        const f32x4 a = *(const f32x4*)(tile + rl * BN + tc + u);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v[u + w] = a[w] + bias[u + w];
+      }
+      if (gp) {
+        float ss = 0.f;
+#pragma unroll
+        for (int u = 0; u < CP; ++u) ss += v[u] * v[u];
+#pragma unroll
+        for (int off = 1; off < TPR; off <<= 1) ss += __shfl_xor(ss, off);
+        const float rinv = rsqrtf(ss * (1.0f / 128.0f) + q.eps);
+#pragma unroll
+        for (int u = 0; u < CP; ++u) v[u] = v[u] * rinv * gain[u];
+      }
+      if (pos) {
+        const long pp = (long)pos[l] * 64 + (tc >> 1);
+        float cs[CP / 2], sn[CP / 2];
+        if constexpr (CP == 8) {
+          const f32x4 c4 = *(const f32x4*)(q.cos_tab + pp), s4 = *(const f32x4*)(q.sin_tab + pp);
+#pragma unroll
+          for (int w = 0; w < 4; ++w) { cs[w] = c4[w]; sn[w] = s4[w]; }
+        } else {
+          cs[0] = q.cos_tab[pp]; cs[1] = q.cos_tab[pp + 1];
+          sn[0] = q.sin_tab[pp]; sn[1] = q.sin_tab[pp + 1];
+        }
+#pragma unroll
+        for (int w = 0; w < CP / 2; ++w) {
+          const float y0 = v[2 * w], y1 = v[2 * w + 1];
+          v[2 * w] = y0 * cs[w] - y1 * sn[w];
+          v[2 * w + 1] = y1 * cs[w] + y0 * sn[w];
+        }
+      }
+      if (ok) VecStore<T>::store((T*)q.dst[o] + (((long)b * q.H + h) * q.S_tot + q.tok_off + l) * 128 + tc, v);
+    }
+  } else {
+    // V^T: walk the clip segments of this row tile; an item = (channel d, 8 destination columns)
+    const int row_end = min(m0 + BM, g.M);
+    const int b_first = m0 / q.L, b_last = (row_end - 1) / q.L;
+    for (int b = b_first; b <= b_last; ++b) {
+      const int rs = max(m0, b * q.L), re = min(row_end, (b + 1) * q.L);
+      const int count = re - rs, c0 = q.tok_off + (rs - b * q.L);
+      const int G0 = c0 >> 3, ngroups = ((c0 + count - 1) >> 3) - G0 + 1;
+      for (int it = tid; it < 128 * ngroups; it += NT) {
+        const int d = it & 127, col0 = (G0 + (it >> 7)) * 8, j0 = col0 - c0;
+        const float bz = g.bias ? g.bias[n0 + d] : 0.f;
+        float v[8];
+        bool full = true;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + u;
+          const bool in = j >= 0 && j < count;
+          full = full && in;
+          v[u] = in ? tile[(rs - m0 + j) * BN + d] + bz : 0.f;
+        }
+        T* dst = (T*)q.dst[o] + (((long)b * q.H + h) * 128 + d) * q.vt_pitch + col0;
+        if constexpr (sizeof(T) == 2) {
+          if (full) {
+            VecStore<T>::store(dst, v);
+            continue;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (j0 + u >= 0 && j0 + u < count) dst[u] = Cvt<T>::to(v[u]);
+      }
+    }
+  }
+}
+
 // Launcher side: can this problem take the vector epilogue?
 template <typename T>
 inline bool gemm_vec_out_ok(const GemmArgs& g, int epi) {

@@ -20,9 +20,24 @@ enum GemmEpi {
   EPI_SILUGATE_T = 4, // out0(T)[.., N/2] = silu(a) * b, (a, b) = alternating 32-column groups
   EPI_GATE_RES = 5,   // out0(f32) += rb gate * (acc + bias)
   EPI_DAC = 6,        // v = acc + bias (+ res); out0(f32) = v; out1(f32) = snake(v)
+  EPI_QKV_SPLIT = 7,  // fused head split: per 128-column head tile RMSNorm + RoPE (q, k) or V^T, written
+                      // straight to the attention operands (GemmArgs::qs); needs a 128-wide tile
   EPI_COUNT
 };
 
+struct QkvSplitArgs {
+  const float* qkv;  // [M, nK * H * 128]
+  int M, L, H, nK;   // rows ordered [clip][l], L tokens per clip
+  const float* gain[3];  // RMSNorm gain per operand, null => copy only
+  const int* pos[3];     // RoPE position per token l, null => no rotation
+  void* dst[3];          // [clips, H, S_tot, 128] (out_dtype); see vt_pitch for the last operand
+  int S_tot, tok_off;
+  int out_dtype;         // FOLEY_F32 or FOLEY_BF16
+  int vt_pitch;          // > 0: the LAST operand (V) is stored transposed [clips, H, 128, vt_pitch]
+  float eps;
+  const float* cos_tab;  // [P, 64]
+  const float* sin_tab;
+};
 struct GemmArgs {
   const void* A;
   const void* W;      // [N, K] row-major, K contiguous
@@ -52,6 +67,7 @@ struct GemmArgs {
   float* partials;
   long partial_stride;
   int partial_cap;
+  QkvSplitArgs qs;    // EPI_QKV_SPLIT: destination / norm / rotation description (qs.qkv, qs.M unused)
   int vec_out;        // set by the launcher: the problem qualifies for the LDS-transposed vector epilogue
   int dbg_mode;
   long long* dbg;     // tools/gemm_timeline.py: 4 wall-clock stamps per workgroup (entry, first slice
@@ -118,19 +134,6 @@ int launch_ln_mod_pending(float* x, int M, int D, float eps, const RowBcast& shi
 // two row sets (same D / eps / dtype) in one launch
 int launch_ln_mod_pair(const LnArgs& a0, const LnArgs& a1, int D, float eps, int out_dtype, hipStream_t st);
 
-struct QkvSplitArgs {
-  const float* qkv;  // [M, nK * H * 128]
-  int M, L, H, nK;   // rows ordered [clip][l], L tokens per clip
-  const float* gain[3];  // RMSNorm gain per operand, null => copy only
-  const int* pos[3];     // RoPE position per token l, null => no rotation
-  void* dst[3];          // [clips, H, S_tot, 128] (out_dtype); see vt_pitch for the last operand
-  int S_tot, tok_off;
-  int out_dtype;         // FOLEY_F32 or FOLEY_BF16
-  int vt_pitch;          // > 0: the LAST operand (V) is stored transposed [clips, H, 128, vt_pitch]
-  float eps;
-  const float* cos_tab;  // [P, 64]
-  const float* sin_tab;
-};
 int launch_qkv_split(const QkvSplitArgs& a, hipStream_t st);
 int launch_qkv_split_pair(const QkvSplitArgs& a0, const QkvSplitArgs& a1, hipStream_t st);
 

@@ -48,6 +48,15 @@ class RowBcastC(C.Structure):
                 ("L", C.c_int32)]
 
 
+class QkvSplitDescC(C.Structure):
+    _fields_ = [
+        ("L", C.c_int32), ("H", C.c_int32), ("nK", C.c_int32),
+        ("gain", C.c_void_p * 3), ("pos", C.c_void_p * 3), ("dst", C.c_void_p * 3),
+        ("out_dtype", C.c_int32), ("vt_pitch", C.c_int32), ("S_tot", C.c_int32), ("tok_off", C.c_int32),
+        ("eps", C.c_float), ("cos_tab", C.c_void_p), ("sin_tab", C.c_void_p),
+    ]
+
+
 class GemmDescC(C.Structure):
     _fields_ = [
         ("A", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p),
@@ -60,6 +69,7 @@ class GemmDescC(C.Structure):
         ("rb", RowBcastC), ("res", C.c_void_p), ("alpha", C.c_void_p), ("alphaC", C.c_int32),
         ("dtype", C.c_int32), ("epilogue", C.c_int32), ("tile", C.c_int32), ("ksplit", C.c_int32),
         ("partials", C.c_void_p), ("partial_slabs", C.c_int32), ("ksplit_used", C.POINTER(C.c_int32)),
+        ("qkv", C.POINTER(QkvSplitDescC)),
     ]
 
 
@@ -261,7 +271,7 @@ def rowbcast(t: Optional[torch.Tensor], mode: int = 0, rows_per_cfg: int = 1, L:
 
 def op_gemm(A, W, bias=None, *, M=None, epilogue=EPI_STORE_F32, out0=None, out1=None, ldc=None, conv=None,
             convT=None, rb: Optional[RowBcastC] = None, res=None, alpha=None, alphaC=1, tile=0, ksplit=0,
-            partials=None) -> int:
+            partials=None, qkv: Optional["QkvSplitDescC"] = None) -> int:
     """Thin wrapper over foley_op_gemm.  conv=(seg, C, taps, dil) ; convT=(Tin, Cin, stride, Cout).
     partials: fp32 [slabs, M, N] workspace for the deferred split-K of the gated-residual epilogue.
     Returns the K split the launcher used."""
@@ -301,6 +311,8 @@ def op_gemm(A, W, bias=None, *, M=None, epilogue=EPI_STORE_F32, out0=None, out1=
     d.ksplit_used = C.pointer(used)
     if partials is not None:
         d.partials, d.partial_slabs = _ptr(partials), partials.shape[0]
+    if qkv is not None:
+        d.qkv = C.pointer(qkv)
     _check(lib, lib.foley_op_gemm(C.byref(d), _stream()), "foley_op_gemm")
     return int(used.value)
 
@@ -321,6 +333,24 @@ def op_ln_mod(x, eps, shift: Optional[RowBcastC], scale: Optional[RowBcastC], ou
     _check(lib, lib.foley_op_ln_mod(_ptr(x), M, D, eps, C.byref(shift) if shift else None,
                                     C.byref(scale) if scale else None, _ptr(out), dt_of(out), _stream()),
            "foley_op_ln_mod")
+
+
+EPI_QKV_SPLIT = 7
+
+
+def qkv_split_desc(L, H, gains: Sequence, poss: Sequence, dsts: Sequence, S_tot, tok_off, eps, cos, sin,
+                   vt_pitch: int = 0) -> QkvSplitDescC:
+    """Descriptor of the fused head-split epilogue (op_gemm(..., epilogue=EPI_QKV_SPLIT, qkv=desc))."""
+    q = QkvSplitDescC()
+    q.L, q.H, q.nK = L, H, len(dsts)
+    for i in range(len(dsts)):
+        q.gain[i] = _ptr(gains[i]) if gains[i] is not None else None
+        q.pos[i] = _ptr(poss[i]) if poss[i] is not None else None
+        q.dst[i] = _ptr(dsts[i])
+    q.out_dtype, q.vt_pitch, q.S_tot, q.tok_off, q.eps = dt_of(dsts[0]), vt_pitch, S_tot, tok_off, eps
+    q.cos_tab, q.sin_tab = _ptr(cos), _ptr(sin)
+    q._keepalive = (list(gains), list(poss), list(dsts), cos, sin)
+    return q
 
 
 def op_ln_mod_pending(x, eps, shift: Optional[RowBcastC], scale: Optional[RowBcastC], out, partials, k: int, bias,

@@ -122,6 +122,21 @@ typedef struct foley_rowbcast {  /* row-broadcast operand (AdaLN shift/scale/gat
   int32_t rows_per_cfg, L;
 } foley_rowbcast;
 
+/* Head split applied to a fused q/k/v (or cross-attention q) projection: per (row, head) RMSNorm
+ * (norm_layers.py:36-52), interleaved RoPE (attn_layers.py:112-146) and the [clip, H, S_tot, 128]
+ * layout of the attention operands; replaces `rearrange` + q_norm/k_norm + apply_rotary_emb of
+ * hifi_foley.py:226-262 / 376-382.  Used by foley_gemm_desc.qkv (epilogue 7). */
+typedef struct foley_qkv_split_desc {
+  int32_t L, H, nK;              /* rows are [clip][l] with L tokens per clip; nK operands of H heads */
+  const float* gain[3];          /* RMSNorm gain [128] per operand, null => copy only */
+  const int32_t* pos[3];         /* RoPE position per token l, null => no rotation */
+  void* dst[3];                  /* [clips, H, S_tot, 128] in out_dtype; see vt_pitch for the last one */
+  int32_t out_dtype, vt_pitch;   /* vt_pitch > 0: last operand stored transposed [clips, H, 128, vt_pitch] */
+  int32_t S_tot, tok_off;
+  float eps;
+  const float* cos_tab; const float* sin_tab;   /* [P, 64] */
+} foley_qkv_split_desc;
+
 typedef struct foley_gemm_desc {
   const void* A; const void* W; const float* bias;
   int32_t M, N, K; int64_t lda;
@@ -130,7 +145,7 @@ typedef struct foley_gemm_desc {
   int32_t osegV; int64_t out_seg, out_row, out_shift; int32_t out_check;
   foley_rowbcast rb; const float* res; const float* alpha; int32_t alphaC;
   int32_t dtype;   /* operand dtype */
-  int32_t epilogue;/* 0 store f32, 1 store T, 2 silu T, 3 gelu-tanh T, 4 silu-gate T, 5 gated residual, 6 DAC */
+  int32_t epilogue;/* 0 store f32, 1 store T, 2 silu T, 3 gelu-tanh T, 4 silu-gate T, 5 gated residual, 6 DAC, 7 head split */
   int32_t tile;    /* 0 auto */
   int32_t ksplit;  /* gated-residual epilogue: K ranges (0 auto, 1 deterministic); ranges are combined with
                     * fp32 atomics, or - when `partials` is set - deferred to the next LayerNorm */
@@ -140,6 +155,8 @@ typedef struct foley_gemm_desc {
    * x += gate * (sum_s partials[s] + bias) before normalising.  With *ksplit_used == 1 the GEMM
    * has already updated out0 and nothing is pending. */
   float* partials; int32_t partial_slabs; int32_t* ksplit_used;
+  /* epilogue 7 (fused head split): N = nK*H*128, out0 unused, results go to qkv->dst[] */
+  const foley_qkv_split_desc* qkv;
 } foley_gemm_desc;
 
 int foley_op_gemm(const foley_gemm_desc* d, void* stream);

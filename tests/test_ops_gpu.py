@@ -364,6 +364,42 @@ def test_qkv_split_bf16_transposed_v(dev):
     assert float(dv[..., :Lv].abs().max()) == 0.0 and float(dv[..., S:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,L,H,Lv,tile", [(2, 11, 3, 4, 0), (2, 250, 2, 40, 0), (3, 70, 2, 3, 5), (2, 250, 1, 40, 9),
+                                           (4, 37, 2, 8, 2)])
+def test_gemm_fused_head_split(dev, dtype, B, L, H, Lv, tile):
+    """q/k/v projection with the head split fused into the GEMM epilogue (RMSNorm + RoPE into
+    [B, H, S, 128]; bf16: V transposed [B, H, 128, pitch]) vs the unfused oracle math."""
+    if tile == 9 and dtype == torch.float32:
+        pytest.skip("256x128 tile is bf16 only")
+    K = 256
+    S = L + Lv
+    pitch = (S + 31) // 32 * 32
+    x, w, b = _rand((B * L, K), 90), _rand((3 * H * 128, K), 91, 1 / math.sqrt(K)), _rand((3 * H * 128,), 92, 0.1)
+    gq, gk = 1 + 0.1 * _rand((128,), 93), 1 + 0.1 * _rand((128,), 94)
+    pos = (2 * torch.arange(L)).to(torch.int32)
+    cos, sin = tables.rope_table(2 * L + 1)
+    qkv = F.linear(_q(x, dtype), _q(w, dtype), b)
+    q, k, v = qkv.view(B, L, 3, H, 128).unbind(2)
+    c2, s2 = cos[pos.long()].repeat_interleave(2, 1), sin[pos.long()].repeat_interleave(2, 1)
+    rq = O.apply_rope(O.rms_norm(q, gq, 1e-6), c2, s2).transpose(1, 2)
+    rk = O.apply_rope(O.rms_norm(k, gk, 1e-6), c2, s2).transpose(1, 2)
+    bf = dtype == torch.bfloat16
+    dq, dk = (torch.zeros(B, H, S, 128, device=dev, dtype=dtype) for _ in range(2))
+    dv = torch.zeros((B, H, 128, pitch) if bf else (B, H, S, 128), device=dev, dtype=dtype)
+    desc = rt.qkv_split_desc(L, H, [gq.to(dev), gk.to(dev), None], [pos.to(dev), pos.to(dev), None], [dq, dk, dv], S, Lv,
+                             1e-6, cos.to(dev), sin.to(dev), vt_pitch=pitch if bf else 0)
+    rt.op_gemm(x.to(dev, dtype), w.to(dev, dtype), b.to(dev), epilogue=rt.EPI_QKV_SPLIT, qkv=desc, tile=tile)
+    tol = 4e-3 if bf else 1e-5
+    assert rel_err(dq[:, :, Lv:].float(), rq) < tol and rel_err(dk[:, :, Lv:].float(), rk) < tol
+    assert float(dq[:, :, :Lv].float().abs().max()) == 0.0
+    if bf:
+        assert rel_err(dv[..., Lv:Lv + L].float(), v.transpose(1, 2).transpose(2, 3)) < tol
+        assert float(dv[..., :Lv].float().abs().max()) == 0.0 and float(dv[..., S:].float().abs().max()) == 0.0
+    else:
+        assert rel_err(dv[:, :, Lv:], v.transpose(1, 2)) < tol
+
+
 def test_latent_rows(dev):
     x = _rand((3, 128, 50), 60)
     out = torch.empty(2 * 3 * 50, 128, device=dev, dtype=torch.bfloat16)
