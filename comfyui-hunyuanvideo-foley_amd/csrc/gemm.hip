@@ -253,6 +253,13 @@ __device__ __forceinline__ void glds16(const void* gptr, unsigned char* lds_wave
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// buffer_load_dwordx4 ... lds: SGPR resource (base, extent) + per-lane byte offset + scalar byte
+// offset.  Kept out of the kernel template: the resource type only exists in the device pass.
+__device__ __forceinline__ void buf_lds16(const void* base, unsigned bytes, unsigned char* lds_wave_base, int voff, int soff) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int NS, int EPI>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmPair pr) {
   const int sel = (int)blockIdx.x >= pr.tiles0 ? 1 : 0;
@@ -288,27 +295,38 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmPair p
   const int wm = wave / WN, wn = wave % WN;
   const int lr = lane >> 3, lp = lane & 7;  // row within the 8-row group, LDS chunk position
 
-  const T* zp = (const T*)g.zeros + lp * EPC;
-  const T* ap[AI];
-  int a_q[AI];
-  bool a_ok[AI];
+  // Loader addressing without per-slice VALU work: both operands are buffer resources (SGPRs), every
+  // lane keeps ONE loop-invariant 32-bit byte offset per 1 KiB piece and the K position travels in a
+  // scalar offset.  (With per-lane 64-bit addresses each issue needs VALU adds, and those starve
+  // behind the MFMAs of the other waves: tools/ubench/ldsdma_interfere.hip, 118 vs 43 GB/s per CU.)
+  // Lanes that must read zeros (M / N edge, conv padding) carry an out-of-range offset: the buffer
+  // range check (voffset + soffset >= num_records) makes the DMA write zeros (tools/ubench/buf_oob.hip).
+  constexpr int ESZ = (int)sizeof(T);
+  constexpr int OOB = 0x7ffffff0;
+  int a_base[AI], a_q[AI], vA[AI];   // byte offset of the row at tap offset 0 (< 0: row beyond M)
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
     const int rl = (wave * AI + i) * 8 + lr;  // row inside the tile
     const int r = m0 + rl;
-    a_ok[i] = r < g.M;
-    const int rr = a_ok[i] ? r : 0;
+    const int rr = r < g.M ? r : 0;
     const int b = rr / g.segV, q = rr - b * g.segV;
-    ap[i] = (const T*)g.A + ((long)b * g.segS + q) * g.lda + (lp ^ ((rl >> 1) & 7)) * EPC;
+    a_base[i] = r < g.M ? (int)((((long)b * g.segS + q) * g.lda + (lp ^ ((rl >> 1) & 7)) * EPC) * ESZ) : -1;
     a_q[i] = q;
   }
-  const T* wp[BI];
+  int vW[BI];
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
     const int rl = (wave * BI + i) * 8 + lr;
     const int n = n0 + rl;
-    wp[i] = (n < g.N) ? (const T*)g.W + (long)n * g.K + (lp ^ ((rl >> 1) & 7)) * EPC : nullptr;
+    vW[i] = (n < g.N) ? (int)(((long)n * g.K + (lp ^ ((rl >> 1) & 7)) * EPC) * ESZ) : OOB;
   }
+  auto set_tap = [&](int toff) {   // per-lane offsets of the current tap (VALU, once per tap)
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const bool in = a_base[i] >= 0 && (unsigned)(a_q[i] + toff) < (unsigned)g.segS;
+      vA[i] = in ? a_base[i] + toff * (int)(g.lda * ESZ) : OOB;
+    }
+  };
 
   f32x16 acc[FM][FN];
 #pragma unroll
@@ -325,7 +343,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmPair p
     kt_begin = (int)((long)tot * ks / g.ksplit);
     nk = (int)((long)tot * (ks + 1) / g.ksplit) - kt_begin;
   }
-  const long tap_step = (long)g.dil * g.lda;
   int ld_k0 = kt_begin * BK;
   int ld_c0 = ld_k0, ld_toff = g.tap0;
   if (kt_begin > 0) {
@@ -333,28 +350,24 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmPair p
     ld_c0 = ld_k0 - tap * g.tapC;
     ld_toff = g.tap0 + tap * g.dil;
   }
-  long ld_roff = (long)ld_toff * g.lda;
+  set_tap(ld_toff);
 
   auto issue = [&](int stage) {
     unsigned char* As = lds + stage * STAGE;
     unsigned char* Bs = As + BM * 128;
+    const int sA = ld_c0 * ESZ, sW = ld_k0 * ESZ;   // scalar K offsets
 #pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      const bool in = a_ok[i] && (unsigned)(a_q[i] + ld_toff) < (unsigned)g.segS;
-      const T* src = in ? ap[i] + ld_roff + ld_c0 : zp;
-      glds16(src, As + (wave * AI + i) * 1024);
-    }
+    for (int i = 0; i < AI; ++i)
+      buf_lds16(g.A, g.a_bytes, As + (wave * AI + i) * 1024, vA[i], sA);
 #pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      const T* src = wp[i] ? wp[i] + ld_k0 : zp;
-      glds16(src, Bs + (wave * BI + i) * 1024);
-    }
+    for (int i = 0; i < BI; ++i)
+      buf_lds16(g.W, g.w_bytes, Bs + (wave * BI + i) * 1024, vW[i], sW);
     ld_k0 += BK;
     ld_c0 += BK;
     if (ld_c0 >= g.tapC) {
       ld_c0 = 0;
       ld_toff += g.dil;
-      ld_roff += tap_step;
+      set_tap(ld_toff);
     }
   };
 
@@ -459,7 +472,6 @@ int launch_one(const GemmArgs& g, const GemmArgs* g1, hipStream_t st) {
   const bool conv = g.taps > 1 || (g1 && g1->taps > 1);
   if constexpr (GLDS) k = gemm_glds_kernel<T, BM, BN, WM, WN, NS, EPI>;
   else k = conv ? gemm_kernel<T, BM, BN, WM, WN, NS, EPI, true> : gemm_kernel<T, BM, BN, WM, WN, NS, EPI, false>;
-  if (GLDS && (!g.zeros || (g1 && !g1->zeros))) return foley_set_err("GEMM: zero page missing", __FILE__, __LINE__);
   if (lds > 64 * 1024) {
     static bool raised[2] = {false, false};   // per instantiation (plain / conv kernel)
     bool& r_ = raised[conv ? 1 : 0];
@@ -529,6 +541,7 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     return foley_set_err("GEMM: operands must be 16-byte aligned", __FILE__, __LINE__);
   const bool conv3_ok = !g1 && g.taps == 3 && g.dil == 1 && g.tap0 == -1 && g.segV == g.segS && g.lda == g.tapC &&
                         g.osegV >= g.M && (epi == EPI_STORE_F32 || epi == EPI_GATE_RES || epi == EPI_SILUGATE_T);
+  const bool tile_auto = tile == 0;
   // deferred split-K available (bf16 mode, caller provided partial slabs): reductions are cheap
   // vector stores + a few extra row reads in the next LayerNorm
   const bool deferred = epi == EPI_GATE_RES && g.partials && g.partial_cap > 1 && sizeof(T) == 2 && g.ksplit != 1 &&
@@ -537,7 +550,8 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
   // and for the small-M gated w1/w3 GEMM; elsewhere the generic tiles (+ split-K / 256x128) are as
   // fast or faster in bf16, so it is only auto-selected there.
   const bool small_grid = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) <= 256;
-  if (tile == 0 && conv3_ok && (sizeof(T) == 4 || (epi == EPI_SILUGATE_T && g.M < 1024) || (deferred && small_grid))) {
+  (void)small_grid;
+  if (tile == 0 && conv3_ok && sizeof(T) == 4) {   // bf16: the wave-specialised generic tiles are faster (tools/gemm_timeline.py)
     const long b128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
     tile = (b128 >= 100 || epi == EPI_SILUGATE_T || deferred) ? 11 : 13;   // the gated epilogue needs 64-wide wave tiles
   }
@@ -554,6 +568,10 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     else if (b128 >= 100 && (b128 <= 256 || rem == 0 || rem >= 128 || b128 >= 2048)) tile = 5;
     else if (epi == EPI_SILUGATE_T) tile = nblk(64, 128) >= 192 ? 2 : 5;
     else tile = 3;
+  }
+  if (sizeof(T) == 2 && tile_auto) {   // bf16: loader / consumer wave specialisation of the same tiles
+    if (tile == 5) tile = 15;
+    else if (tile == 9) tile = 19;
   }
   if (epi == EPI_QKV_SPLIT) {
     for (const GemmArgs* q : {(const GemmArgs*)&g, g1}) {
@@ -573,25 +591,25 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
       }
       if (al & 15) return foley_set_err("fused head split: operands must be 16-byte aligned", __FILE__, __LINE__);
     }
-    if (!(tile == 1 || tile == 2 || tile == 5 || tile == 7 || tile == 8 || tile == 9))
+    if (!(tile == 1 || tile == 2 || tile == 5 || tile == 7 || tile == 8 || tile == 9 || tile == 15 || tile == 19))
       tile = (long)((g.M + 127) / 128) * (g.N / 128) >= 24 ? 5 : 2;
   }
   if (epi != EPI_GATE_RES || g.ksplit == 1 || (g.ksplit == 0 && sizeof(T) == 4)) {
     g.ksplit = 1;   // fp32 (parity) mode keeps a fixed summation order
   } else if (g.ksplit == 0) {
     // fill ~3 workgroups per CU, keep >= 12 K-slices per range
-    static const int bm[14] = {0, 128, 64, 64, 128, 128, 64, 128, 64, 256, 0, 128, 0, 64};
-    static const int bn[14] = {0, 128, 128, 64, 64, 128, 64, 128, 128, 128, 0, 128, 0, 64};
-    if (tile < 0 || tile >= 14 || bm[tile] == 0) return foley_set_err("GEMM: unknown tile", __FILE__, __LINE__);
+    static const int bm[20] = {0, 128, 64, 64, 128, 128, 64, 128, 64, 256, 0, 128, 0, 64, 0, 128, 0, 0, 0, 256};
+    static const int bn[20] = {0, 128, 128, 64, 64, 128, 64, 128, 128, 128, 0, 128, 0, 64, 0, 128, 0, 0, 0, 128};
+    if (tile < 0 || tile >= 20 || bm[tile] == 0) return foley_set_err("GEMM: unknown tile", __FILE__, __LINE__);
     const long blocks = (long)((g.M + bm[tile] - 1) / bm[tile]) * ((g.N + bn[tile] - 1) / bn[tile]);
     const int nk = (tile == 11 || tile == 13) ? 3 * (g.tapC / BK) / 3 : g.K / BK;   // conv3 splits over channel chunks
     // small tiles want ~3 workgroups per CU; the large, efficient tiles only split when they
     // cannot even cover the chip once (the fp32 atomics are not free)
-    const long target = (tile == 1 || tile == 5 || tile == 7 || tile == 9 || tile == 11) ? 192 : (tile == 13 ? 512 : 768);
+    const long target = (tile == 1 || tile == 5 || tile == 7 || tile == 9 || tile == 11 || tile == 15 || tile == 19) ? 192 : (tile == 13 ? 512 : 768);
     long want = (target + blocks - 1) / blocks;
     if (want > nk / 12) want = nk / 12;
     if (deferred) {   // one resident round of workgroups: as many K ranges as fit on 256 CUs (>= 4 slices each)
-      const int per_cu = (tile == 3 || tile == 6 || tile == 13) ? 3 : 1;
+      const int per_cu = (tile == 3 || tile == 6 || tile == 13) ? 3 : 1;   // resident workgroups per CU
       want = 256L * per_cu / blocks;
       if (want > nk / 4) want = nk / 4;
     }
@@ -605,11 +623,29 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
   }
   if (g1) g1s.ksplit = g.ksplit;
   if (ksplit_used) *ksplit_used = g.ksplit;
+  {
+    // the direct-to-LDS loop addresses its operands through 32-bit buffer offsets
+    auto extent = [&](GemmArgs& q) {
+      const long rows_src = (long)((q.M + q.segV - 1) / q.segV) * q.segS;
+      const long ab = rows_src * q.lda * (long)sizeof(T), wb = (long)q.N * q.K * (long)sizeof(T);
+      if (ab >= 0x7fff0000L || wb >= 0x7fff0000L) return false;
+      q.a_bytes = (unsigned)ab;
+      q.w_bytes = (unsigned)wb;
+      return true;
+    };
+    bool ok = extent(g);
+    if (g1) ok = extent(g1s) && ok;
+    if (!ok && ((tile >= 5 && tile <= 9) || tile == 15 || tile == 19)) tile = (tile == 6) ? 3 : (tile == 8 ? 2 : 1);   // register-staged twins
+  }
   g.vec_out = gemm_vec_out_ok<T>(g, epi) ? 1 : 0;
   if (g1) g1s.vec_out = gemm_vec_out_ok<T>(g1s, epi) ? 1 : 0;
   if (tile == 11 || tile == 13) {
     if (g1) return foley_set_err("conv3 kernel has no two-problem form", __FILE__, __LINE__);
     return launch_gemm_conv3(g, sizeof(T) == 2 ? FOLEY_BF16 : FOLEY_F32, epi, tile == 11 ? 1 : 3, st);
+  }
+  if (tile == 15 || tile == 19) {
+    if constexpr (sizeof(T) == 2) return launch_gemm_ws(g, g1, epi, tile, st);
+    else return foley_set_err("GEMM: wave-specialised tiles are bf16 only", __FILE__, __LINE__);
   }
   switch (tile) {
     case 1: return launch_tile<T, 128, 128, 4, 2, 4>(g, g1, epi, st);

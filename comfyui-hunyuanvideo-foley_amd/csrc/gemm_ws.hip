@@ -1,0 +1,247 @@
+// Wave-specialised GEMM mainloop for gfx950 (bf16 operands): LW loader waves do nothing but feed
+// the LDS ring with buffer_load_dwordx4 ... lds, WM*WN consumer waves do nothing but read fragments
+// and issue MFMAs; one s_barrier per K-slice couples them.
+//
+// Why (tools/gemm_timeline.py --ablate, tools/ubench/ldsdma_interfere.hip):
+//  * in the single-role loop of gemm.hip every wave runs barrier -> issue loads -> read fragments ->
+//    MFMA back to back, and the slice time is the SUM of the three (0.73 us per 128x128x64 slice vs
+//    0.52 us loads only and 0.46 us fragment reads + MFMA only);
+//  * a dedicated loader only keeps its rate next to MFMA-saturated SIMDs if issuing a load needs no
+//    VALU instruction: with per-lane 64-bit addresses (global_load_lds) a loader drops from 128 to
+//    43 GB/s per CU, with an SGPR buffer resource + loop-invariant lane offset + scalar K offset it
+//    stays at 118 GB/s.
+//
+//   loader wave   : wait(slice kt landed) ; barrier ; issue slice kt+NS-1 into the stage freed by kt-1
+//   consumer wave : barrier ; read fragments of slice kt ; MFMA
+//
+// Same operand addressing as gemm.hip (virtual rows / taps; zero fill through the buffer range
+// check), same source-side XOR swizzle, same epilogues (gemm_common.h).  reference ops: F.linear,
+// ChannelLastConv1d (mlp_layers.py:104-110), see include/foley_hip.h foley_op_gemm.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+#include "gemm_common.h"
+
+namespace {
+
+// buffer_load_dwordx4 ... lds: SGPR resource (base, extent) + per-lane byte offset + scalar byte
+// offset; out-of-range lanes write zeros.  Not inside the kernel template: the resource type only
+// exists in the device pass.
+__device__ __forceinline__ void buf_lds16(const void* base, unsigned bytes, unsigned char* lds_wave_base, int voff, int soff) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
+template <int BM, int BN, int WM, int WN, int NS, int LW, int EPI>
+__global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const GemmPair pr) {
+  using T = bf16_t;
+  const int sel = (int)blockIdx.x >= pr.tiles0 ? 1 : 0;
+  const GemmArgs& g = pr.g[sel];
+  constexpr int NW = WM * WN;
+  constexpr int EPC = 8, BK = 64, ESZ = 2, OOB = 0x7ffffff0;
+  constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
+  constexpr int AI = BM / 8 / LW, BI = BN / 8 / LW;  // 1 KiB pieces per loader wave and K-slice
+  constexpr int STAGE = (BM + BN) * 128;
+  static_assert(BM % (8 * LW) == 0 && BN % (8 * LW) == 0, "bad tile");
+  static_assert((NS - 1) * (AI + BI) < 64, "vmcnt is a 6-bit counter");
+  static_assert(EPI != EPI_SILUGATE_T || (FN % 2 == 0), "gated epilogue needs fragment pairs");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  const int tiles_m = (g.M + BM - 1) / BM;
+  const int tiles_n = (g.N + BN - 1) / BN;
+  int bid = (int)blockIdx.x - (sel ? pr.tiles0 : 0);
+  {  // bijective XCD remap: consecutive tile ids (same weight panel) share an XCD / L2
+    const int nwg = tiles_m * tiles_n * (EPI == EPI_GATE_RES ? g.ksplit : 1);
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  int ks = 0;
+  if constexpr (EPI == EPI_GATE_RES) {
+    ks = bid % g.ksplit;
+    bid /= g.ksplit;
+  }
+  const int tm = bid % tiles_m, tn = bid / tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  tl_stamp(g, 0);
+
+  int kt_begin = 0, nk = g.K / BK;
+  if constexpr (EPI == EPI_GATE_RES) {
+    const int tot = nk;
+    kt_begin = (int)((long)tot * ks / g.ksplit);
+    nk = (int)((long)tot * (ks + 1) / g.ksplit) - kt_begin;
+  }
+
+  if (wave >= NW) {
+    // ------------------------------------------------------------------ loader wave
+    const int lw = wave - NW;
+    const int lr = lane >> 3, lp = lane & 7;  // row within the 8-row piece, LDS chunk position
+    int a_base[AI], a_q[AI], vA[AI];   // byte offset of the row at tap offset 0 (< 0: row beyond M)
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int rl = (lw * AI + i) * 8 + lr;  // row inside the tile
+      const int r = m0 + rl;
+      const int rr = r < g.M ? r : 0;
+      const int b = rr / g.segV, q = rr - b * g.segV;
+      a_base[i] = r < g.M ? (int)((((long)b * g.segS + q) * g.lda + (lp ^ ((rl >> 1) & 7)) * EPC) * ESZ) : -1;
+      a_q[i] = q;
+    }
+    int vW[BI];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int rl = (lw * BI + i) * 8 + lr;
+      const int n = n0 + rl;
+      vW[i] = (n < g.N) ? (int)(((long)n * g.K + (lp ^ ((rl >> 1) & 7)) * EPC) * ESZ) : OOB;
+    }
+    auto set_tap = [&](int toff) {   // per-lane offsets of the current tap (VALU, once per tap)
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const bool in = a_base[i] >= 0 && (unsigned)(a_q[i] + toff) < (unsigned)g.segS;
+        vA[i] = in ? a_base[i] + toff * (int)(g.lda * ESZ) : OOB;
+      }
+    };
+    int ld_k0 = kt_begin * BK;
+    int ld_c0 = ld_k0, ld_toff = g.tap0;
+    if (kt_begin > 0) {
+      const int tap = ld_k0 / g.tapC;
+      ld_c0 = ld_k0 - tap * g.tapC;
+      ld_toff = g.tap0 + tap * g.dil;
+    }
+    set_tap(ld_toff);
+    auto issue = [&](int stage) {
+      unsigned char* As = lds + stage * STAGE;
+      unsigned char* Bs = As + BM * 128;
+      const int sA = ld_c0 * ESZ, sW = ld_k0 * ESZ;   // scalar K offsets: no VALU on the issue path
+#pragma unroll
+      for (int i = 0; i < AI; ++i) buf_lds16(g.A, g.a_bytes, As + (lw * AI + i) * 1024, vA[i], sA);
+#pragma unroll
+      for (int i = 0; i < BI; ++i) buf_lds16(g.W, g.w_bytes, Bs + (lw * BI + i) * 1024, vW[i], sW);
+      ld_k0 += BK;
+      ld_c0 += BK;
+      if (ld_c0 >= g.tapC) {
+        ld_c0 = 0;
+        ld_toff += g.dil;
+        set_tap(ld_toff);
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+      if (s < nk) issue(s);
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      // slice kt has landed once at most the NS-2 younger slices are still in flight
+      if (kt + NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (AI + BI)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // slice kt visible to the consumers; they are done with slice kt-1
+      if (kt + NS - 1 < nk) issue(stage == 0 ? NS - 1 : stage - 1);
+      stage = stage + 1 == NS ? 0 : stage + 1;
+    }
+    return;   // loaders take no part in the epilogue (a finished wave leaves the barrier count)
+  }
+
+  // -------------------------------------------------------------------- consumer wave
+  const int wm = wave / WN, wn = wave % WN;
+  const int fi = lane & 31, kh = lane >> 5;
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  int a_row[FM], a_sw[FM], b_row[FN], b_sw[FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    a_row[i] = (wm * TM + i * 32 + fi) * 128;
+    a_sw[i] = ((wm * TM + i * 32 + fi) >> 1) & 7;
+  }
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    b_row[j] = (wn * TN + j * 32 + fi) * 128;
+    b_sw[j] = ((wn * TN + j * 32 + fi) >> 1) & 7;
+  }
+  int stage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    __builtin_amdgcn_s_barrier();
+    if (kt == 0) tl_stamp(g, 1);
+    const unsigned char* As = lds + stage * STAGE;
+    const unsigned char* Bs = As + BM * 128;
+    bf16x8 fa[4][FM], fb[4][FN];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) fa[s][i] = *(const bf16x8*)(As + a_row[i] + (((s * 2 + kh) ^ a_sw[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < FN; ++j) fb[s][j] = *(const bf16x8*)(Bs + b_row[j] + (((s * 2 + kh) ^ b_sw[j]) << 4));
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
+    stage = stage + 1 == NS ? 0 : stage + 1;
+  }
+  tl_stamp(g, 2);
+  if constexpr (EPI == EPI_QKV_SPLIT) {
+    gemm_epilogue_qkv<T, BM, BN, WM, WN>(g, acc, lds, m0, n0);
+  } else {
+    if (g.vec_out) gemm_epilogue_lds<T, EPI, BM, BN, WM, WN>(g, acc, lds, m0, n0, ks);
+    else gemm_epilogue<T, EPI, FM, FN, TM, TN>(g, acc, m0, n0, wm, wn, fi, kh, ks);
+  }
+  tl_stamp(g, 3);
+}
+
+template <int BM, int BN, int WM, int WN, int NS, int LW, int EPI>
+int launch_ws_one(const GemmArgs& g, const GemmArgs* g1, hipStream_t st) {
+  auto ntiles = [](const GemmArgs& q) {
+    return ((q.M + BM - 1) / BM) * ((q.N + BN - 1) / BN) * (EPI == EPI_GATE_RES ? q.ksplit : 1);
+  };
+  GemmPair pr;
+  pr.g[0] = g;
+  pr.g[1] = g1 ? *g1 : g;
+  pr.tiles0 = ntiles(g);
+  const int tiles = pr.tiles0 + (g1 ? ntiles(*g1) : 0);
+  constexpr size_t lds = (size_t)NS * (BM + BN) * 128;
+  auto k = gemm_ws_kernel<BM, BN, WM, WN, NS, LW, EPI>;
+  static bool raised = false;
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);
+    raised = true;
+  }
+  hipLaunchKernelGGL(k, dim3(tiles), dim3((WM * WN + LW) * 64), lds, st, pr);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);
+  return 0;
+}
+
+template <int BM, int BN, int WM, int WN, int NS, int LW>
+int launch_ws_tile(const GemmArgs& g, const GemmArgs* g1, int epi, hipStream_t st) {
+  switch (epi) {
+    case EPI_STORE_F32: return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_STORE_F32>(g, g1, st);
+    case EPI_STORE_T: return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_STORE_T>(g, g1, st);
+    case EPI_SILU_T: return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_SILU_T>(g, g1, st);
+    case EPI_GELU_T: return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_GELU_T>(g, g1, st);
+    case EPI_GATE_RES: return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_GATE_RES>(g, g1, st);
+    case EPI_QKV_SPLIT: return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_QKV_SPLIT>(g, g1, st);
+    case EPI_SILUGATE_T:
+      if constexpr ((BN / WN) % 64 == 0) return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_SILUGATE_T>(g, g1, st);
+      else return foley_set_err("gated epilogue needs a 64-wide wave tile", __FILE__, __LINE__);
+  }
+  return foley_set_err("wave-specialised GEMM: unsupported epilogue", __FILE__, __LINE__);
+}
+
+}  // namespace
+
+// tile: 15 = 128x128 (8 consumer + 4 loader waves), 19 = 256x128 (8 + 4); g / g1 fully resolved
+// (ksplit, vec_out, operand extents) by gemm.hip's launcher
+int launch_gemm_ws(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hipStream_t st) {
+  switch (tile) {
+    case 15: return launch_ws_tile<128, 128, 4, 2, 4, 4>(g, g1, epi, st);
+    case 19: return launch_ws_tile<256, 128, 4, 2, 3, 4>(g, g1, epi, st);
+  }
+  return foley_set_err("wave-specialised GEMM: unknown tile", __FILE__, __LINE__);
+}

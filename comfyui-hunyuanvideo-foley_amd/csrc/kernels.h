@@ -57,6 +57,7 @@ struct GemmArgs {
   const float* res;   // EPI_DAC residual (same mapping as out0) or null
   const float* alpha; // EPI_DAC snake alpha, indexed n % alphaC
   int alphaC;
+  unsigned a_bytes, w_bytes;   // operand extents in bytes (buffer-resource range of the direct-to-LDS loop; set by the launcher)
   const void* zeros;  // >= 128 zero bytes in global memory (source of masked rows for the direct-to-LDS loop)
   int ksplit;         // EPI_GATE_RES only: K is cut into `ksplit` ranges whose partial products are
                       // accumulated with hardware fp32 atomics (0 = auto; 1 = deterministic)
@@ -83,6 +84,8 @@ int launch_gemm(const GemmArgs& g, int dtype, int epi, int tile, hipStream_t st,
 int launch_gemm_pair(const GemmArgs& g0, const GemmArgs& g1, int dtype, int epi, hipStream_t st, int* ksplit_used = nullptr);
 // tap-fused channels-last conv k=3 (gemm_conv3.hip); tile 1 = 128x128, 3 = 64x64; g.ksplit resolved
 int launch_gemm_conv3(const GemmArgs& g, int dtype, int epi, int tile, hipStream_t st);
+// wave-specialised mainloop (gemm_ws.hip, bf16): tile 15 = 128x128, 19 = 256x128; g / g1 resolved by launch_gemm
+int launch_gemm_ws(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hipStream_t st);
 // experimental mainloop variants (bf16, plain fp32 store), tile codes >= 100 - see gemm_exp.hip
 int launch_gemm_exp(const GemmArgs& g, int code, hipStream_t st);
 
