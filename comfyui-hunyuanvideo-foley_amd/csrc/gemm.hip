@@ -550,8 +550,7 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
   // and for the small-M gated w1/w3 GEMM; elsewhere the generic tiles (+ split-K / 256x128) are as
   // fast or faster in bf16, so it is only auto-selected there.
   const bool small_grid = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) <= 256;
-  (void)small_grid;
-  if (tile == 0 && conv3_ok && sizeof(T) == 4) {   // bf16: the wave-specialised generic tiles are faster (tools/gemm_timeline.py)
+  if (tile == 0 && conv3_ok && (sizeof(T) == 4 || (deferred && small_grid))) {   // other bf16 cases: the wave-specialised generic tiles win (tools/gemm_timeline.py)
     const long b128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
     tile = (b128 >= 100 || epi == EPI_SILUGATE_T || deferred) ? 11 : 13;   // the gated epilogue needs 64-wide wave tiles
   }
@@ -592,7 +591,7 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
       if (al & 15) return foley_set_err("fused head split: operands must be 16-byte aligned", __FILE__, __LINE__);
     }
     if (!(tile == 1 || tile == 2 || tile == 5 || tile == 7 || tile == 8 || tile == 9 || tile == 15 || tile == 19))
-      tile = (long)((g.M + 127) / 128) * (g.N / 128) >= 24 ? 5 : 2;
+      tile = (long)((g.M + 127) / 128) * (g.N / 128) >= 24 ? (sizeof(T) == 2 ? 15 : 5) : 2;
   }
   if (epi != EPI_GATE_RES || g.ksplit == 1 || (g.ksplit == 0 && sizeof(T) == 4)) {
     g.ksplit = 1;   // fp32 (parity) mode keeps a fixed summation order

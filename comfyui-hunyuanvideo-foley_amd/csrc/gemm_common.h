@@ -230,32 +230,37 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
   if constexpr (EPI == EPI_GATE_RES || EPI == EPI_STORE_F32) {
     RbCursor rc;
     rc.init(g.rb, row0);
-    f32x4 xv[PASSES], gv[PASSES];
+    constexpr int PB = PASSES > 4 ? 4 : PASSES;   // passes whose global reads are in flight together (register budget)
+    static_assert(PASSES % PB == 0, "pass batching");
 #pragma unroll
-    for (int p = 0; p < PASSES; ++p) {   // all global reads first
-      const int row = row0 + p * RP;
-      const bool ok = col_ok && row < g.M;
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      xv[p] = z;
-      gv[p] = z;
-      if (ok) {
-        if constexpr (EPI == EPI_GATE_RES) xv[p] = *(const f32x4*)(out + (long)row * g.out_row);
-        if (rc.p) gv[p] = *(const f32x4*)(rc.row_ptr() + gcol);
+    for (int p0 = 0; p0 < PASSES; p0 += PB) {
+      f32x4 xv[PB], gv[PB];
+#pragma unroll
+      for (int p = 0; p < PB; ++p) {   // all global reads of the batch first
+        const int row = row0 + (p0 + p) * RP;
+        const bool ok = col_ok && row < g.M;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        xv[p] = z;
+        gv[p] = z;
+        if (ok) {
+          if constexpr (EPI == EPI_GATE_RES) xv[p] = *(const f32x4*)(out + (long)row * g.out_row);
+          if (rc.p) gv[p] = *(const f32x4*)(rc.row_ptr() + gcol);
+        }
+        rc.advance(RP);
       }
-      rc.advance(RP);
-    }
 #pragma unroll
-    for (int p = 0; p < PASSES; ++p) {
-      const int row = row0 + p * RP;
-      if (!(col_ok && row < g.M)) continue;
-      const f32x4 a = *(const f32x4*)(tile + (p * RP + tr) * BN + ca);
-      float v[4];
+      for (int p = 0; p < PB; ++p) {
+        const int row = row0 + (p0 + p) * RP;
+        if (!(col_ok && row < g.M)) continue;
+        const f32x4 a = *(const f32x4*)(tile + ((p0 + p) * RP + tr) * BN + ca);
+        float v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float t = a[u] + bias_a[u];
-        v[u] = EPI == EPI_GATE_RES ? xv[p][u] + t * gv[p][u] : t + gv[p][u];
+        for (int u = 0; u < 4; ++u) {
+          const float t = a[u] + bias_a[u];
+          v[u] = EPI == EPI_GATE_RES ? xv[p][u] + t * gv[p][u] : t + gv[p][u];
+        }
+        VecStore<float>::store((float*)out + (long)row * g.out_row, v);
       }
-      VecStore<float>::store((float*)out + (long)row * g.out_row, v);
     }
   } else {
 #pragma unroll

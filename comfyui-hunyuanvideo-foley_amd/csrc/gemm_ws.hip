@@ -12,7 +12,7 @@
 //    stays at 118 GB/s.
 //
 //   loader wave   : wait(slice kt landed) ; barrier ; issue slice kt+NS-1 into the stage freed by kt-1
-//   consumer wave : barrier ; read fragments of slice kt ; MFMA
+//   consumer wave : barrier ; read fragments of slice kt ; MFMA   (late half of the waves: MFMA of kt-1 first)
 //
 // Same operand addressing as gemm.hip (virtual rows / taps; zero fill through the buffer range
 // check), same source-side XOR swizzle, same epilogues (gemm_common.h).  reference ops: F.linear,
@@ -161,20 +161,15 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
     b_row[j] = (wn * TN + j * 32 + fi) * 128;
     b_sw[j] = ((wn * TN + j * 32 + fi) >> 1) & 7;
   }
-  int stage = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    __builtin_amdgcn_s_barrier();
-    if (kt == 0) tl_stamp(g, 1);
-    const unsigned char* As = lds + stage * STAGE;
-    const unsigned char* Bs = As + BM * 128;
-    bf16x8 fa[4][FM], fb[4][FN];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-#pragma unroll
-      for (int i = 0; i < FM; ++i) fa[s][i] = *(const bf16x8*)(As + a_row[i] + (((s * 2 + kh) ^ a_sw[i]) << 4));
-#pragma unroll
-      for (int j = 0; j < FN; ++j) fb[s][j] = *(const bf16x8*)(Bs + b_row[j] + (((s * 2 + kh) ^ b_sw[j]) << 4));
-    }
+  // Ping-pong between the two consumer waves of a SIMD (waves w and w + NW/2): after each barrier
+  // the early wave reads its fragments while the late wave multiplies the slice it read in the
+  // previous iteration, then they swap pipes - the LDS and the matrix core are both busy instead of
+  // taking turns.  A late wave's fragment reads must have returned before the barrier that lets a
+  // loader overwrite their stage (lgkmcnt(0)).
+  constexpr bool PP = NW == 8;
+  const bool late = PP && wave >= NW / 2;
+  bf16x8 fa[4][FM], fb[4][FN];
+  auto mma = [&]() {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -182,8 +177,26 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
 #pragma unroll
         for (int j = 0; j < FN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
+  };
+  int stage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (late) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt == 0) tl_stamp(g, 1);
+    if (late && kt > 0) mma();
+    const unsigned char* As = lds + stage * STAGE;
+    const unsigned char* Bs = As + BM * 128;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) fa[s][i] = *(const bf16x8*)(As + a_row[i] + (((s * 2 + kh) ^ a_sw[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < FN; ++j) fb[s][j] = *(const bf16x8*)(Bs + b_row[j] + (((s * 2 + kh) ^ b_sw[j]) << 4));
+    }
+    if (!late) mma();
     stage = stage + 1 == NS ? 0 : stage + 1;
   }
+  if (late && nk > 0) mma();
   tl_stamp(g, 2);
   if constexpr (EPI == EPI_QKV_SPLIT) {
     gemm_epilogue_qkv<T, BM, BN, WM, WN>(g, acc, lds, m0, n0);
@@ -240,7 +253,7 @@ int launch_ws_tile(const GemmArgs& g, const GemmArgs* g1, int epi, hipStream_t s
 // (ksplit, vec_out, operand extents) by gemm.hip's launcher
 int launch_gemm_ws(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hipStream_t st) {
   switch (tile) {
-    case 15: return launch_ws_tile<128, 128, 4, 2, 4, 4>(g, g1, epi, st);
+    case 15: return launch_ws_tile<128, 128, 4, 2, 5, 4>(g, g1, epi, st);   // 5 x 32 KiB ring = all 160 KiB of LDS
     case 19: return launch_ws_tile<256, 128, 4, 2, 3, 4>(g, g1, epi, st);
   }
   return foley_set_err("wave-specialised GEMM: unknown tile", __FILE__, __LINE__);
