@@ -189,7 +189,7 @@ def main():
                        "clips_per_gpu": a.bs, "parallelism": f"dp{world}", "hip_graph": not a.no_graph},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "traffic": traffic, "traffic_unit": "bytes per foley_sample launch (rocprofv3 PMC, offline pass)",
-                         "kernel": "gemm_kernel (MFMA GEMM/conv engine; >90% of the device-resident sampler loop)",
+                         "kernel": "gemm_ws_kernel + gemm_conv3_kernel (MFMA GEMM/conv engine; ~80% of the device-resident sampler loop)",
                          "launch": "one foley_sample call = 50 captured iterations, HIP-event timed on its stream",
                          "loop_ms": loop_ms, "dac_decode_ms": dac_ms,
                          "algorithmic_tflop_per_clip": f_clip / 1e12},
