@@ -103,6 +103,14 @@ def draw_noise(batch_size: int, channels: int, length: int, dtype: torch.dtype,
     return torch.randn((batch_size, channels, int(length)), generator=generator, device="cpu", dtype=dtype)
 
 
+def fp8_time_dtype(model):
+    """fp8 type the timestep features are rounded through, or None: an fp8-wrapped reference model
+    under bf16/fp16 autocast casts them to fp8 (embed_layers.py:134, golden g8)."""
+    if getattr(model, "quantization", "none") == "none" or model.dtype == torch.float32:
+        return None
+    return torch.float8_e4m3fn if model.quantization == "fp8_e4m3fn" else torch.float8_e5m2
+
+
 def build_plan(model: FoleyModel, visual_feats: Dict[str, torch.Tensor], text_feats: Dict[str, torch.Tensor],
                La: int, guidance_scale: float, steps: int, batch_size: int, sampler: str) -> dict:
     """Conditioning replication / padding / CFG stacking of utils.py:159-199 + the run's tables."""
@@ -125,7 +133,8 @@ def build_plan(model: FoleyModel, visual_feats: Dict[str, torch.Tensor], text_fe
         sync_in = torch.cat([model.get_empty_sync_sequence(bs=1, len=Ls).float(), sync])
     else:
         ncfg, text_in, clip_in, sync_in = 1, text, clip, sync
-    tb = tables.build_tables(La, Lv, Ls, Lt, steps, sampler, cfg.flow_shift, cfg.time_freq_dim)
+    fp8_time = fp8_time_dtype(model)
+    tb = tables.build_tables(La, Lv, Ls, Lt, steps, sampler, cfg.flow_shift, cfg.time_freq_dim, fp8_time=fp8_time)
     plan = {"ncfg": ncfg, "clips": batch_size, "La": La, "Lv": Lv, "Ls": Ls, "Lt": Lt, "n_iter": steps,
             "guidance": float(guidance_scale), "rope_len": tb["rope_cos"].shape[0],
             "text": text_in.contiguous(), "clip": clip_in.contiguous(), "sync": sync_in.contiguous()}

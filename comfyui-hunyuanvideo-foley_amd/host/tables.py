@@ -12,7 +12,7 @@ These are the step-invariant lookups the reference rebuilds inside its hot loop:
 from __future__ import annotations
 
 import math
-from typing import Dict
+from typing import Dict, Optional
 
 import torch
 
@@ -107,7 +107,9 @@ def interleaved_positions(la: int, lv: int):
 
 
 def build_tables(la: int, lv: int, ls: int, lt: int, steps: int, solver: str, shift: float,
-                 time_freq_dim: int = 256) -> Dict[str, torch.Tensor]:
+                 time_freq_dim: int = 256, fp8_time: Optional[torch.dtype] = None) -> Dict[str, torch.Tensor]:
+    """fp8_time: round the sinusoid timestep features through this fp8 type (fp8-wrapped model under
+    autocast, embed_layers.py:134 - golden g8)."""
     sig = sigma_grid(steps, shift)
     ts = model_timesteps(sig)
     n_iter = steps
@@ -117,7 +119,8 @@ def build_tables(la: int, lv: int, ls: int, lt: int, steps: int, solver: str, sh
     return {
         "sigmas": sig,
         "timesteps": ts,
-        "t_feat": timestep_features(ts, time_freq_dim).contiguous(),
+        "t_feat": (timestep_features(ts, time_freq_dim) if fp8_time is None
+                   else timestep_features(ts, time_freq_dim).to(fp8_time).to(torch.float32)).contiguous(),
         "solver_coef": solver_table(sig, solver, n_iter),
         "rope_cos": cos, "rope_sin": sin,
         "pos_audio_self": pa.to(torch.int32), "pos_visual_self": pv.to(torch.int32),

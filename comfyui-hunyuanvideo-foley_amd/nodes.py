@@ -69,6 +69,33 @@ def _load_state_dict(path):
     return {k: v for k, v in obj.items() if isinstance(v, torch.Tensor)}
 
 
+def fp8_wrapped_key(key: str, tensor) -> bool:
+    """Does the reference's _wrap_fp8_inplace (utils.py:408-485) store this tensor in fp8?  Its deny
+    list never matches, so: the weight of EVERY nn.Linear / nn.Conv1d and nothing else -
+    learned feature rows, position tables, norm gains and biases stay full precision
+    (tests/golden/g8_fp8.npz lists the 56 wrapped modules of the tiny config)."""
+    return key.endswith(".weight") and tensor.dim() >= 2 and tensor.is_floating_point()
+
+
+def fp8_round_state_dict(state_dict, qmode: str, autocast: bool = True):
+    """Weight-only fp8 storage = plain cast, no scales; values are rounded once here and the kernels
+    run on the exactly representable bf16/fp32 images.  Under autocast (bf16/fp16 compute, the only
+    way the reference runs fp8 models) the first TimestepEmbedder bias is rounded too: the wrapper
+    casts it to the activation dtype, which embed_layers.py:134 has made fp8 (golden g8, "Q14");
+    the matching feature rounding lives in host/sampler.py::build_plan."""
+    out = {}
+    qd = {"fp8_e4m3fn": torch.float8_e4m3fn, "fp8_e5m2": torch.float8_e5m2}.get(qmode)
+    for k, v in state_dict.items():
+        if v.dtype in (torch.float8_e4m3fn, torch.float8_e5m2):
+            v = v.to(torch.float32)
+        elif qd is not None and fp8_wrapped_key(k, v):
+            v = v.to(torch.float32).to(qd).to(torch.float32)
+        elif qd is not None and autocast and k == "time_in.mlp.0.bias":
+            v = v.to(torch.float32).to(qd).to(torch.float32)
+        out[k] = v
+    return out
+
+
 def detect_ckpt_fp8(state_dict):
     """'fp8_e5m2' / 'fp8_e4m3fn' if the checkpoint stores such tensors, else None (utils.py:492-504)."""
     for v in state_dict.values():
@@ -134,15 +161,7 @@ class HunyuanModelLoader:
             qmode = (detected or "fp8_e4m3fn") if quantization == "auto" else quantization
             if detected is None and quantization == "auto":
                 qmode = "none"          # nothing to honour: keep full-precision weights
-        sd = {}
-        for k, v in state_dict.items():
-            if v.dtype in (torch.float8_e4m3fn, torch.float8_e5m2):
-                v = v.to(torch.float32)
-            elif qmode != "none" and v.dim() >= 2 and v.is_floating_point():
-                # weight-only fp8: plain cast, no scales (reference utils.py:408-485)
-                qd = torch.float8_e4m3fn if qmode == "fp8_e4m3fn" else torch.float8_e5m2
-                v = v.to(torch.float32).to(qd).to(torch.float32)
-            sd[k] = v
+        sd = fp8_round_state_dict(state_dict, qmode, autocast=dtype != torch.float32)
         return _sampler.FoleyModel(cfg, sd, dtype, device or _torch_device(), quantization=qmode)
 
     def build_model(self, model_name, precision, quantization):

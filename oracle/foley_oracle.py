@@ -179,6 +179,20 @@ def timestep_embedding(t: Tensor, dim: int = 256, max_period: int = 10000) -> Te
     return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
 
 
+def time_embed_fp8_autocast(sd: Dict[str, Tensor], t: Tensor, qdtype: torch.dtype) -> Tensor:
+    """TimestepEmbedder when its Linears are fp8-wrapped and the model runs under bf16 autocast
+    (the only way the reference runs fp8 checkpoints, utils.py:229-234): embed_layers.py:134 casts
+    the sinusoid features to `mlp[0].weight.dtype` = fp8, FP8WeightWrapper.forward (utils.py:361-366)
+    then keeps the weight in fp8 and casts the first BIAS to fp8 as well; autocast runs both Linears
+    in bf16.  The second layer sees a bf16 activation and is an ordinary wrapped Linear."""
+    r8 = lambda v: v.to(qdtype).to(torch.bfloat16)
+    f = r8(timestep_embedding(t, sd["time_in.mlp.0.weight"].shape[1]))
+    h = F.linear(f, r8(sd["time_in.mlp.0.weight"]), r8(sd["time_in.mlp.0.bias"]))
+    h = F.silu(h)
+    y = F.linear(h, r8(sd["time_in.mlp.2.weight"]), sd["time_in.mlp.2.bias"].to(torch.bfloat16))
+    return y.float()
+
+
 def conv1d_cl(x: Tensor, w: Tensor, b: Optional[Tensor], pad: int) -> Tensor:
     """ChannelLastConv1d (mlp_layers.py:104-110): x [B, L, C] -> [B, L, C_out]."""
     return F.conv1d(x.transpose(1, 2), w, b, padding=pad).transpose(1, 2)
@@ -275,7 +289,7 @@ def single_block(sd: SD, p: str, H: int, x: Tensor, cond: Tensor, rope: Tuple[Te
 
 def dit_forward(sd: SD, heads: int, x: Tensor, t: Tensor, cond: Tensor, clip_feat: Tensor,
                 sync_feat: Tensor, n_triple: Optional[int] = None, n_single: Optional[int] = None,
-                taps: Optional[dict] = None) -> Tensor:
+                taps: Optional[dict] = None, fp8_time: Optional[torch.dtype] = None) -> Tensor:
     """HunyuanVideoFoley.forward (hifi_foley.py:707-924) for the shipped configuration:
     add_sync_feat_to_audio, interleaved_audio_visual_rope, no attention mask.
 
@@ -290,8 +304,13 @@ def dit_forward(sd: SD, heads: int, x: Tensor, t: Tensor, cond: Tensor, clip_fea
     D = sd["time_in.mlp.2.weight"].shape[0]
     hd = D // H
     # time embedding (:744, embed_layers.py:104-136)
-    vec = F.linear(F.silu(F.linear(timestep_embedding(t, sd["time_in.mlp.0.weight"].shape[1]),
-                                   sd["time_in.mlp.0.weight"], sd["time_in.mlp.0.bias"])),
+    # fp8_time: fp8-wrapped model under autocast - the features and the first bias pass through fp8
+    # (see time_embed_fp8_autocast; `sd` is expected to hold the fp8-rounded weights already)
+    tf = timestep_embedding(t, sd["time_in.mlp.0.weight"].shape[1])
+    b0 = sd["time_in.mlp.0.bias"]
+    if fp8_time is not None:
+        tf, b0 = tf.to(fp8_time).to(tf.dtype), b0.to(fp8_time).to(b0.dtype)
+    vec = F.linear(F.silu(F.linear(tf, sd["time_in.mlp.0.weight"], b0)),
                    sd["time_in.mlp.2.weight"], sd["time_in.mlp.2.bias"])
     # sync features (:755-762)
     Ls = sync_feat.shape[1]

@@ -29,6 +29,7 @@ import types
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 import yaml
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -369,6 +370,47 @@ def g7():
     save("g7_sampler", **out)
 
 
+# ----------------------------------------------------------------------------- G8
+def g8():
+    """fp8 weight-only storage (utils.py:316-485):
+    (a) which modules of the DiT the reference wraps (its deny list never matches: every Linear /
+        Conv1d, nothing else - learned feature rows and position tables stay full precision);
+    (b) a wrapped Linear and a wrapped channels-last Conv1d forward (weight fp8 -> activation dtype,
+        bias untouched);
+    (c) the TimestepEmbedder under bf16 autocast: embed_layers.py:134 casts the sinusoid features to
+        `mlp[0].weight.dtype`, i.e. to fp8 once the layer is wrapped, and the wrapper then casts the
+        first bias to fp8 as well (utils.py:362-363) - both get rounded through fp8 ("Q14")."""
+    c = C.TINY
+    sd = synth.synth_dit_state_dict(c)
+    out = {}
+    g = torch.Generator().manual_seed(8)
+    xl = torch.randn(5, c.hidden, generator=g)
+    xc = torch.randn(2, 9, c.hidden, generator=g)           # channels-last conv input
+    tt = torch.tensor([700.0, 3.0])
+    out["xl"], out["xc"], out["t"] = xl, xc, tt
+    for q in ("fp8_e4m3fn", "fp8_e5m2"):
+        qd = torch.float8_e4m3fn if q == "fp8_e4m3fn" else torch.float8_e5m2
+        m = build_ref_dit(c, sd)
+        counts, _saved = NS.utils._wrap_fp8_inplace(m, quantization=q, state_dict=None)
+        wrapped = sorted(n for n, mod in m.named_modules() if type(mod).__name__ == "FP8WeightWrapper")
+        assert len(wrapped) == sum(counts.values())
+        n_lin = sum(1 for k, v in sd.items() if k.endswith(".weight") and v.dim() >= 2)
+        print(f"  {q}: {len(wrapped)} wrapped modules; state dict has {n_lin} >=2-D '.weight' tensors")
+        out[q + "_wrapped"] = np.array("\n".join(wrapped))
+        with torch.inference_mode():
+            lin = m.triple_blocks[0].audio_mlp.fc1          # wrapped nn.Linear
+            conv = m.single_blocks[0].linear1                # ChannelLastConv1d -> wrapped nn.Conv1d, channels-last input
+            yl, yc = lin(xl), conv(xc)
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                yt = m.time_in(tt)
+        rq = lambda w: w.to(qd).to(torch.float32)
+        check(f"{q} wrapped linear", F.linear(xl, rq(sd["triple_blocks.0.audio_mlp.fc1.weight"]), sd["triple_blocks.0.audio_mlp.fc1.bias"]), yl)
+        check(f"{q} wrapped conv1d (channels-last)", O.conv1d_cl(xc, rq(sd["single_blocks.0.linear1.weight"]), sd["single_blocks.0.linear1.bias"], 1), yc)
+        check(f"{q} time_in under autocast", O.time_embed_fp8_autocast(sd, tt, qd), yt.float(), 2e-2)
+        out[q + "_lin_y"], out[q + "_conv_y"], out[q + "_time_y"] = yl, yc, yt.float()
+    save("g8_fp8", **out)
+
+
 # ----------------------------------------------------------------------------- G9
 def g9():
     dsd = synth.synth_dac_state_dict(C.DAC48K)
@@ -381,7 +423,7 @@ def g9():
     save("g9_dac", z=z, y=y)
 
 
-ALL = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7, "g9": g9}
+ALL = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9}
 
 
 def main():

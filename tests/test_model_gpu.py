@@ -19,6 +19,8 @@ def _plan_single(model, text, clip, sync, La, t_values):
     n = len(t_values)
     tb = tables.build_tables(La, Lv, Ls, Lt, max(n, 1), "euler", 1.0, model.cfg.time_freq_dim)
     tb["t_feat"] = tables.timestep_features(torch.tensor(t_values, dtype=torch.float32), model.cfg.time_freq_dim)
+    if sampler.fp8_time_dtype(model) is not None:
+        tb["t_feat"] = tb["t_feat"].to(sampler.fp8_time_dtype(model)).float()
     plan = {"ncfg": 1, "clips": 1, "La": La, "Lv": Lv, "Ls": Ls, "Lt": Lt, "n_iter": n, "guidance": 1.0,
             "rope_len": tb["rope_cos"].shape[0], "text": text.float().to(dev).contiguous(),
             "clip": clip.float().to(dev).contiguous(), "sync": sync.float().to(dev).contiguous()}
@@ -210,9 +212,10 @@ def test_xl_dimensions_forward(dev):
 
 
 def test_fp8_weight_only_loader(dev):
-    """Config C5 semantics (reference utils.py:316-485): every >=2-D weight is rounded
-    through fp8 (plain cast, no scales), biases/gains untouched, compute in bf16.  Checked against
-    the oracle run on the same fp8-rounded weights."""
+    """Config C5 semantics (reference utils.py:316-485, SURVEY Q11, golden g8): every Linear / Conv1d
+    weight is rounded through fp8 (plain cast, no scales), everything else untouched - except that
+    under bf16 autocast the timestep features and the first time-embedding bias pass through fp8
+    too.  Checked against the oracle run on the same fp8-rounded weights."""
     from foley_amd import nodes
     c = C.TINY
     sd = synth.synth_dit_state_dict(c)
@@ -220,16 +223,19 @@ def test_fp8_weight_only_loader(dev):
         model = nodes.HunyuanModelLoader.pack_state_dict(sd, "bf16", q, device=dev, cfg=c)
         assert model.quantization == q and model.dtype == torch.bfloat16
         qd = torch.float8_e4m3fn if q == "fp8_e4m3fn" else torch.float8_e5m2
-        sdq = {k: (v.to(qd).float() if v.dim() >= 2 else v) for k, v in sd.items()}
+        sdq = nodes.fp8_round_state_dict(sd, q, autocast=False)
+        assert sum(1 for k in sd if not torch.equal(sd[k], sdq[k])) == 56     # the 56 wrapped modules of golden g8
         g = golden("g5_dit_tiny")
         x, t, cond, clip, sync = (g["a_" + k] for k in ("x", "t", "cond", "clip", "sync"))
         xq = x.to(torch.bfloat16).float()
         y = _forward(model, xq, t, cond, clip, sync)
         with torch.inference_mode():
-            ref = O.dit_forward(sdq, c.heads, xq, t, cond, clip, sync)
+            ref = O.dit_forward(sdq, c.heads, xq, t, cond, clip, sync, fp8_time=qd)
+            ref_no_quirk = O.dit_forward(sdq, c.heads, xq, t, cond, clip, sync)
         assert rel_err(y, ref) < 4e-2, q
+        assert rel_err(y, ref) < rel_err(y, ref_no_quirk), q    # the fp8-rounded time features are really in use
     # a checkpoint that already stores fp8 tensors is honoured by quantization="auto"
-    sd8 = {k: (v.to(torch.float8_e4m3fn) if v.dim() >= 2 else v) for k, v in sd.items()}
+    sd8 = {k: (v.to(torch.float8_e4m3fn) if nodes.fp8_wrapped_key(k, v) else v) for k, v in sd.items()}
     m = nodes.HunyuanModelLoader.pack_state_dict(sd8, "bf16", "auto", device=dev, cfg=c)
     assert m.quantization == "fp8_e4m3fn" and m.dtype == torch.bfloat16
     # precision="auto" looks at bf16/fp16/fp32 tensors only (reference utils.py:507-515): here the

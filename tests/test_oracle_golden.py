@@ -109,3 +109,26 @@ def test_g6_c1_xxl():
                                cond["sync"], 10, 1.0, trace=trace)
         wav = O.dac_decode(synth.synth_dac_state_dict(C.DAC48K), lat)
     assert rel_err(torch.stack(trace), g["latents"]) < 1e-5 and rel_err(wav, g["waveform"]) < 3e-5
+
+
+def test_g8_fp8_weight_only_semantics():
+    """Reference FP8WeightWrapper / _wrap_fp8_inplace (utils.py:316-485): the wrapped set, wrapped
+    Linear / channels-last Conv1d forwards, and the TimestepEmbedder-under-autocast quirk."""
+    from foley_amd import nodes
+    g = golden("g8_fp8")
+    c = C.TINY
+    sd = synth.synth_dit_state_dict(c)
+    for q, qd in (("fp8_e4m3fn", torch.float8_e4m3fn), ("fp8_e5m2", torch.float8_e5m2)):
+        wrapped = set(str(g[q + "_wrapped"]).split("\n"))
+        mine = {k[:-7] for k, v in sd.items() if nodes.fp8_wrapped_key(k, v)}
+        assert mine == wrapped and len(wrapped) == 56
+        rq = lambda w: w.to(qd).to(torch.float32)
+        yl = F.linear(g["xl"], rq(sd["triple_blocks.0.audio_mlp.fc1.weight"]), sd["triple_blocks.0.audio_mlp.fc1.bias"])
+        yc = O.conv1d_cl(g["xc"], rq(sd["single_blocks.0.linear1.weight"]), sd["single_blocks.0.linear1.bias"], 1)
+        assert rel_err(yl, g[q + "_lin_y"]) < 1e-6 and rel_err(yc, g[q + "_conv_y"]) < 1e-6
+        assert rel_err(O.time_embed_fp8_autocast(sd, g["t"], qd), g[q + "_time_y"]) < 1e-2
+        # the loader's rounding rule reproduces exactly those tensors (+ the first time-embedding bias under autocast)
+        sdq = nodes.fp8_round_state_dict(sd, q, autocast=True)
+        changed = {k for k in sd if not torch.equal(sd[k], sdq[k])}
+        assert changed == {k + ".weight" for k in wrapped} | {"time_in.mlp.0.bias"}
+        assert torch.equal(sdq["time_in.mlp.0.bias"], rq(sd["time_in.mlp.0.bias"]))
