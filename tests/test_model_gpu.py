@@ -91,6 +91,28 @@ def test_sampler_golden(tiny, tag, t2a, dur, guid, bs, solver, steps, use_graph)
     assert rel_err(audio[..., ::5], g[tag + "_wave_s5"]) < 1e-3
 
 
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-4), ("bf16", 6e-2)])
+def test_long_clip_matches_oracle(tiny, dev, precision, tol):
+    """C5-shaped sequence lengths (30 s: La=1500, Lv=240, Ls=736; S=1740 joint tokens, several
+    256/128-row tiles, ragged last tiles) with negative-prompt CFG, 3 Euler steps, against the
+    oracle evaluated here on the same noise.  bf16: loose gate only (operand rounding)."""
+    sd, _dsd, model32, _dac = tiny
+    model = model32 if precision == "fp32" else sampler.FoleyModel(C.TINY, sd, torch.bfloat16, dev, dac_cfg=C.DAC_TINY)
+    dur, steps, g = 30.0, 3, 4.5
+    cond = synth.synth_conditioning(C.TINY, dur, t2a=False, sd=sd)
+    noise = torch.randn(1, 128, int(dur * 50), generator=torch.Generator().manual_seed(30))
+    plan = sampler.build_plan(model, {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]},
+                              {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]}, int(dur * 50), g,
+                              steps, 1, "euler")
+    model.ctx.prepare(plan)
+    lat = noise.clone().to(dev)
+    model.ctx.sample(lat, use_graph=True)
+    with torch.inference_mode():
+        ref = O.sample_latents(sd, C.TINY.heads, noise, cond["text"], cond["uncond_text"], cond["clip"], cond["sync"],
+                               steps, g, "euler")
+    assert rel_err(lat, ref) < tol
+
+
 def test_sampler_noise_matches_reference_draw(tiny):
     """The CPU-generator draw (utils.py:114-121) must reproduce the committed golden noise."""
     g = golden("g7_sampler")
