@@ -13,6 +13,19 @@ namespace {
 
 constexpr int HD = 128;
 
+template <typename OutT> struct Pack4Out;
+template <> struct Pack4Out<float> {
+  static __device__ __forceinline__ void store(float* p, const f32x4 v) { *(f32x4*)p = v; }
+};
+template <> struct Pack4Out<bf16_t> {
+  static __device__ __forceinline__ void store(bf16_t* p, const f32x4 v) {
+    uint2 w;
+    w.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+    w.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    *(uint2*)p = w;
+  }
+};
+
 template <typename OutT>
 __global__ __launch_bounds__(64) void attn_kernel(const AttnArgs a) {
   const int lane = threadIdx.x;
@@ -248,6 +261,129 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16, large grids: a workgroup = 4 waves x 32 queries = 128 queries; every wave walks ALL key tiles
+// and the K / V^T tiles are staged once per workgroup in LDS (register-staged double buffer), so
+// the operands are read from L2 once per 128 queries instead of once per 32 (the narrow kernel above
+// re-reads them for each of its 32-query workgroups: ~10x at S = 290).  No cross-wave merge.
+// LDS rows are padded (K: 272 B, V^T: 80 B) so the 16-lane groups of ds_read_b128 hit distinct banks.
+template <typename OutT>
+__global__ __launch_bounds__(256) void attn_bf16_wide_kernel(const AttnArgs a) {
+  constexpr int KP = 272, VP = 80;                       // LDS row pitches in bytes
+  constexpr int STG = 32 * KP + 128 * VP;                // one stage: K tile + V^T tile
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STG];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int j = lane & 31, kh = lane >> 5;
+  const int q0 = blockIdx.x * 128 + w * 32;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int bk = b / a.kv_bdiv;
+  const bf16_t* __restrict__ Q = (const bf16_t*)a.q + ((long)(b * a.H + h) * a.Sq) * HD;
+  const bf16_t* __restrict__ K = (const bf16_t*)a.k + ((long)(bk * a.H + h) * a.Skv) * HD;
+  const bf16_t* __restrict__ VT = (const bf16_t*)a.v + ((long)(bk * a.H + h) * HD) * a.vt_pitch;
+  const float scale = 0.08838834764831845f;
+
+  bf16x8 qf[8];
+  {
+    const bf16_t* p = Q + (long)min(q0 + j, a.Sq - 1) * HD + 8 * kh;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) qf[s] = *(const bf16x8*)(p + 16 * s);
+  }
+  f32x16 o[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // staging: 512 + 512 pieces of 16 B per tile, 2 + 2 per thread
+  const int k_row[2] = {tid >> 4, (tid >> 4) + 16}, k_col = tid & 15;   // K tile: 32 rows x 16 chunks
+  const int v_row[2] = {tid >> 2, (tid >> 2) + 64}, v_col = tid & 3;    // V^T tile: 128 rows x 4 chunks
+  u32x4 rk[2], rv[2];
+  auto gload = [&](int t) {
+    const int kt = t * 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      rk[i] = *(const u32x4*)(K + (long)min(kt + k_row[i], a.Skv - 1) * HD + k_col * 8);
+      rv[i] = *(const u32x4*)(VT + (long)v_row[i] * a.vt_pitch + kt + v_col * 8);
+    }
+  };
+  auto lstore = [&](int stage) {
+    unsigned char* base = lds + stage * STG;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *(u32x4*)(base + k_row[i] * KP + k_col * 16) = rk[i];
+      *(u32x4*)(base + 32 * KP + v_row[i] * VP + v_col * 16) = rv[i];
+    }
+  };
+  const int nt = (a.Skv + 31) >> 5;
+  const int pi = 16 * ((j >> 2) & 1) + (j & 3) + 4 * (j >> 3);  // A-row j carries key kt + pi
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int kt = t * 32;
+    if (t + 1 < nt) gload(t + 1);                 // next tile's global loads fly during this tile's math
+    const unsigned char* Ks = lds + (t & 1) * STG;
+    const unsigned char* Vs = Ks + 32 * KP;
+    f32x16 s;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 8; ++st)
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Ks + pi * KP + (16 * st + 8 * kh) * 2), qf[st], s, 0, 0, 0);
+    // s[e] = score(key kt + 16*kh + e, query q0 + j)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      s[e] = (kt + 16 * kh + e < a.Skv) ? s[e] * scale : -INFINITY;
+      mx = fmaxf(mx, s[e]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = expf(m_run - m_new);
+    float ps = 0.f;
+    bf16x8 pb[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float pv = expf(s[e] - m_new);
+      ps += pv;
+      pb[e >> 3][e & 7] = (__bf16)pv;
+    }
+    ps += __shfl_xor(ps, 32, 64);
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Vs + (d * 32 + j) * VP + (16 * kh + 8 * u) * 2), pb[u], o[d], 0, 0, 0);
+    if (t + 1 < nt) {
+      lstore((t + 1) & 1);        // stage (t+1)&1 was last read in iteration t-1: every wave passed the barrier below since
+      __syncthreads();
+    }
+  }
+
+  const int tok = q0 + j;
+  if (tok >= a.Sq) return;
+  const float inv = 1.0f / l_run;
+  OutT* dst;
+  if (tok < a.split) dst = (OutT*)a.outA + ((long)b * a.split + tok) * (a.H * HD);
+  else dst = (OutT*)a.outB + ((long)b * (a.Sq - a.split) + (tok - a.split)) * (a.H * HD);
+  dst += h * HD;
+  // lane (j, kh) holds dims d*32 + 8*g4 + 4*kh + {0..3} of query j: 4 consecutive outputs per store
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const f32x4 v = {o[d][g4 * 4 + 0] * inv, o[d][g4 * 4 + 1] * inv, o[d][g4 * 4 + 2] * inv, o[d][g4 * 4 + 3] * inv};
+      Pack4Out<OutT>::store(dst + d * 32 + 8 * g4 + 4 * kh, v);
+    }
+}
+
 }  // namespace
 
 int launch_attention(const AttnArgs& a, int out_dtype, hipStream_t st) {
@@ -256,7 +392,12 @@ int launch_attention(const AttnArgs& a, int out_dtype, hipStream_t st) {
   if (a.in_dtype == FOLEY_BF16) {
     if (a.vt_pitch < ((a.Skv + 31) & ~31) || (a.vt_pitch & 7))
       return foley_set_err("attention: V^T pitch must cover Skv rounded up to 32 (multiple of 8)", __FILE__, __LINE__);
-    if (out_dtype == FOLEY_BF16) hipLaunchKernelGGL(attn_bf16_kernel<bf16_t>, grid, dim3(256), 0, st, a);
+    // enough 128-query workgroups to cover the chip => the wide kernel (operands read once per 128 queries)
+    const dim3 gw((a.Sq + 127) / 128, a.H, a.Bq);
+    if ((long)gw.x * gw.y * gw.z >= 256) {
+      if (out_dtype == FOLEY_BF16) hipLaunchKernelGGL(attn_bf16_wide_kernel<bf16_t>, gw, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL(attn_bf16_wide_kernel<float>, gw, dim3(256), 0, st, a);
+    } else if (out_dtype == FOLEY_BF16) hipLaunchKernelGGL(attn_bf16_kernel<bf16_t>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(attn_bf16_kernel<float>, grid, dim3(256), 0, st, a);
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) return foley_set_err(hipGetErrorString(e2), __FILE__, __LINE__);
