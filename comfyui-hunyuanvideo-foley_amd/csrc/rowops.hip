@@ -34,7 +34,7 @@ struct LnPair {
   int blocks0;
 };
 
-template <typename OutT, int MAXV>
+template <typename OutT, int MAXV, bool PEND>
 __global__ __launch_bounds__(128) void ln_mod_kernel(const LnPair pr, int D, float eps) {
   const int sel = (int)blockIdx.x >= pr.blocks0 ? 1 : 0;
   const LnArgs& A = pr.a[sel];
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(128) void ln_mod_kernel(const LnPair pr, int D, flo
     hv[i] = sh ? sh[c] : z4;
     cv[i] = sc ? sc[c] : z4;
   }
-  if (A.pend.partials) {
+  if (PEND && A.pend.partials) {   // (separate instantiation: the slab registers would halve the plain kernel's occupancy)
     // finish the deferred split-K GEMM: x += gate * (sum of partial products + bias), SB slabs in
     // flight at a time (clamped slab index keeps the loads unconditional, weight 0 drops repeats)
     constexpr int SB = 6;
@@ -414,10 +414,16 @@ int launch_ln_mod_pair(const LnArgs& a0, const LnArgs& a1, int D, float eps, int
   const int need = (D / 4 + 63) / 64;   // float4 per lane
   if (out_dtype != FOLEY_F32 && out_dtype != FOLEY_BF16) return foley_set_err("ln_mod: bad dtype", __FILE__, __LINE__);
   const bool f32o = out_dtype == FOLEY_F32;
+  const bool pend = (a0.M > 0 && a0.pend.partials) || (a1.M > 0 && a1.pend.partials);
 #define FOLEY_LN(V)                                                                                        \
   {                                                                                                        \
-    if (f32o) hipLaunchKernelGGL((ln_mod_kernel<float, V>), grid, block, 0, st, pr, D, eps);               \
-    else hipLaunchKernelGGL((ln_mod_kernel<bf16_t, V>), grid, block, 0, st, pr, D, eps);                   \
+    if (pend) {                                                                                            \
+      if (f32o) hipLaunchKernelGGL((ln_mod_kernel<float, V, true>), grid, block, 0, st, pr, D, eps);       \
+      else hipLaunchKernelGGL((ln_mod_kernel<bf16_t, V, true>), grid, block, 0, st, pr, D, eps);           \
+    } else {                                                                                               \
+      if (f32o) hipLaunchKernelGGL((ln_mod_kernel<float, V, false>), grid, block, 0, st, pr, D, eps);      \
+      else hipLaunchKernelGGL((ln_mod_kernel<bf16_t, V, false>), grid, block, 0, st, pr, D, eps);          \
+    }                                                                                                      \
   }
   if (need <= 2) FOLEY_LN(2)
   else if (need <= 4) FOLEY_LN(4)
