@@ -309,7 +309,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmPair p
     const int rl = (wave * AI + i) * 8 + lr;  // row inside the tile
     const int r = m0 + rl;
     const int rr = r < g.M ? r : 0;
-    const int b = rr / g.segV, q = rr - b * g.segV;
+    const int b = g.segV >= g.M ? 0 : rr / g.segV, q = rr - b * g.segV;   // plain GEMM: one segment, no division
     a_base[i] = r < g.M ? (int)((((long)b * g.segS + q) * g.lda + (lp ^ ((rl >> 1) & 7)) * EPC) * ESZ) : -1;
     a_q[i] = q;
   }
