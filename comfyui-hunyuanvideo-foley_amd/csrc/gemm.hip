@@ -670,11 +670,6 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
 int launch_gemm(const GemmArgs& g, int dtype, int epi, int tile, hipStream_t st, int* ksplit_used) {
   if (ksplit_used) *ksplit_used = 1;
   if (g.M <= 0 || g.N <= 0) return 0;
-  if (tile >= 100) {
-    if (dtype != FOLEY_BF16 || epi != EPI_STORE_F32 || g.taps != 1)
-      return foley_set_err("experimental GEMM variants: bf16 plain store only", __FILE__, __LINE__);
-    return launch_gemm_exp(g, tile, st);
-  }
   if (dtype == FOLEY_F32) return launch_typed<float>(g, nullptr, epi, tile, st, ksplit_used);
   if (dtype == FOLEY_BF16) return launch_typed<bf16_t>(g, nullptr, epi, tile, st, ksplit_used);
   return foley_set_err("GEMM: unsupported operand dtype", __FILE__, __LINE__);

@@ -86,8 +86,6 @@ int launch_gemm_pair(const GemmArgs& g0, const GemmArgs& g1, int dtype, int epi,
 int launch_gemm_conv3(const GemmArgs& g, int dtype, int epi, int tile, hipStream_t st);
 // wave-specialised mainloop (gemm_ws.hip, bf16): tile 15 = 128x128, 19 = 256x128; g / g1 resolved by launch_gemm
 int launch_gemm_ws(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hipStream_t st);
-// experimental mainloop variants (bf16, plain fp32 store), tile codes >= 100 - see gemm_exp.hip
-int launch_gemm_exp(const GemmArgs& g, int code, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // Attention: O = softmax(Q K^T / sqrt(128)) V, no mask.  Q [Bq, H, Sq, 128], K/V [Bkv, H, Skv, 128]

@@ -42,8 +42,13 @@ def _q(t, dtype):   # round a CPU reference operand through the compute dtype
     (37, 200, 256, 0), (130, 128, 128, 0), (10, 13824, 1536, 0), (4000, 64, 128, 4), (77, 3072, 768, 0),
     (500, 1536, 1536, 5), (500, 1536, 1536, 6), (500, 1536, 1536, 8), (37, 200, 256, 6), (130, 192, 128, 5),
     (700, 640, 4608, 5),
+    # wave-specialised mainloop (bf16): 128x128 / 256x128 tiles, ragged M and N edges, K = one slice .. many
+    (500, 1536, 1536, 15), (500, 1536, 1536, 19), (37, 200, 64, 15), (700, 640, 4608, 19), (1000, 136, 320, 15),
+    (257, 129, 128, 19),
 ])
 def test_gemm_linear(dev, dtype, M, N, K, tile):
+    if tile in (15, 19) and dtype == torch.float32:
+        pytest.skip("wave-specialised tiles are bf16 only")
     A, W, b = _rand((M, K), 1), _rand((N, K), 2, 1 / math.sqrt(K)), _rand((N,), 3, 0.1)
     ref = F.linear(_q(A, dtype), _q(W, dtype), b)
     out = torch.full((M, N), float("nan"), device=dev)
@@ -65,8 +70,11 @@ def test_gemm_transpose_detecting(dev, dtype, tile):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("tile", [0, 15, 19])
 @pytest.mark.parametrize("epi", ["store_t", "silu", "gelu", "silugate", "gate_res_vec", "gate_res_tok", "addend"])
-def test_gemm_epilogues(dev, dtype, epi):
+def test_gemm_epilogues(dev, dtype, epi, tile):
+    if tile and dtype == torch.float32:
+        pytest.skip("wave-specialised tiles are bf16 only")
     M, N, K = 300, 512, 256
     clips, L = 3, 50                     # rows ordered [cfg=2][clip=3][l=50]
     A, W, b = _rand((M, K), 4), _rand((N, K), 5, 1 / math.sqrt(K)), _rand((N,), 6, 0.1)
@@ -75,32 +83,32 @@ def test_gemm_epilogues(dev, dtype, epi):
     if epi in ("store_t", "silu", "gelu"):
         out = torch.empty(M, N, device=dev, dtype=dtype)
         code = {"store_t": rt.EPI_STORE_T, "silu": rt.EPI_SILU_T, "gelu": rt.EPI_GELU_T}[epi]
-        rt.op_gemm(Ad, Wd, bd, out0=out, epilogue=code)
+        rt.op_gemm(Ad, Wd, bd, out0=out, epilogue=code, tile=tile)
         ref = {"store_t": y, "silu": F.silu(y), "gelu": F.gelu(y, approximate="tanh")}[epi]
         assert rel_err(out.float(), ref) < max(_tol(dtype), 4e-3 if dtype == torch.bfloat16 else 0)
     elif epi == "silugate":
         w1, w3 = W[: N // 2], W[N // 2:]
         Wp = packers.interleave_gate(w1, w3)
         out = torch.empty(M, N // 2, device=dev, dtype=dtype)
-        rt.op_gemm(Ad, Wp.to(dev, dtype), None, out0=out, epilogue=rt.EPI_SILUGATE_T)
+        rt.op_gemm(Ad, Wp.to(dev, dtype), None, out0=out, epilogue=rt.EPI_SILUGATE_T, tile=tile)
         ref = F.silu(F.linear(_q(A, dtype), _q(w1, dtype))) * F.linear(_q(A, dtype), _q(w3, dtype))
         assert rel_err(out.float(), ref) < _tol(dtype) * (1 if dtype == torch.float32 else 1.5)
     elif epi == "gate_res_vec":
         x0, gate = _rand((M, N), 7), _rand((N,), 8)
         x = x0.to(dev).clone()
-        rt.op_gemm(Ad, Wd, bd, out0=x, epilogue=rt.EPI_GATE_RES, rb=rt.rowbcast(gate.to(dev), 0))
+        rt.op_gemm(Ad, Wd, bd, out0=x, epilogue=rt.EPI_GATE_RES, rb=rt.rowbcast(gate.to(dev), 0), tile=tile)
         assert rel_err(x, x0 + y * gate) < _tol(dtype)
     elif epi == "gate_res_tok":
         x0, gate = _rand((M, N), 7), _rand((2, L, N), 8)
         x = x0.to(dev).clone()
         rt.op_gemm(Ad, Wd, bd, out0=x, epilogue=rt.EPI_GATE_RES,
-                   rb=rt.rowbcast(gate.to(dev), 1, rows_per_cfg=clips * L, L=L))
+                   rb=rt.rowbcast(gate.to(dev), 1, rows_per_cfg=clips * L, L=L), tile=tile)
         ref = x0 + y * gate[:, None].expand(2, clips, L, N).reshape(M, N)
         assert rel_err(x, ref) < _tol(dtype)
     else:
         add = _rand((2, L, N), 9)
         out = torch.empty(M, N, device=dev)
-        rt.op_gemm(Ad, Wd, bd, out0=out, rb=rt.rowbcast(add.to(dev), 1, rows_per_cfg=clips * L, L=L))
+        rt.op_gemm(Ad, Wd, bd, out0=out, rb=rt.rowbcast(add.to(dev), 1, rows_per_cfg=clips * L, L=L), tile=tile)
         ref = y + add[:, None].expand(2, clips, L, N).reshape(M, N)
         assert rel_err(out, ref) < _tol(dtype)
 
@@ -129,7 +137,7 @@ def test_gemm_split_k(dev, ksplit, conv):
 
 
 @pytest.mark.parametrize("ksplit", [0, 2, 3, 7])
-@pytest.mark.parametrize("conv", [False, True, 11, 13])
+@pytest.mark.parametrize("conv", [False, True, 11, 13, 15, 19])
 @pytest.mark.parametrize("tok_gate", [False, True])
 def test_gemm_deferred_split_k(dev, ksplit, conv, tok_gate):
     """Deferred split-K: the gated-residual GEMM leaves raw partial products per K range, the next
@@ -150,8 +158,8 @@ def test_gemm_deferred_split_k(dev, ksplit, conv, tok_gate):
     if conv:
         y = O.conv1d_cl(_q(x, dt), _q(w, dt), b, 1).reshape(B * L, N)
         Wp, kw = packers.conv_to_gemm(w), dict(conv=(L, C, 3, 1))
-        if conv in (11, 13):
-            kw["tile"] = conv
+        if conv in (11, 13, 15, 19):
+            kw["tile"] = conv    # tap-fused / wave-specialised conv addressing
     else:
         y = F.linear(_q(x, dt).reshape(B * L, C), _q(w[:, :, 0], dt), b)
         Wp, kw = w[:, :, 0].contiguous(), {}
@@ -177,9 +185,11 @@ def test_gemm_deferred_split_k(dev, ksplit, conv, tok_gate):
 
 # ----------------------------------------------------------------------------- GEMM: conv addressing
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("tile", [0, 3, 5, 6, 11, 13])
+@pytest.mark.parametrize("tile", [0, 3, 5, 6, 11, 13, 15, 19])
 @pytest.mark.parametrize("B,L,Cin,Cout", [(2, 50, 256, 384), (3, 7, 128, 64), (1, 250, 1536, 256), (5, 33, 128, 200)])
 def test_conv3_channels_last(dev, dtype, tile, B, L, Cin, Cout):
+    if tile in (15, 19) and dtype == torch.float32:
+        pytest.skip("wave-specialised tiles are bf16 only")
     """ChannelLastConv1d k=3 pad=1 (mlp_layers.py:104-110) as a GEMM over overlapping rows
     (register-staged and direct-to-LDS mainloops)."""
     x, w, b = _rand((B, L, Cin), 10), _rand((Cout, Cin, 3), 11, 1 / math.sqrt(3 * Cin)), _rand((Cout,), 12, 0.1)
@@ -369,12 +379,13 @@ def test_qkv_split_bf16_transposed_v(dev):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,L,H,Lv,tile", [(2, 11, 3, 4, 0), (2, 250, 2, 40, 0), (3, 70, 2, 3, 5), (2, 250, 1, 40, 9),
+                                           (2, 250, 2, 40, 15), (3, 70, 1, 3, 19),
                                            (4, 37, 2, 8, 2)])
 def test_gemm_fused_head_split(dev, dtype, B, L, H, Lv, tile):
     """q/k/v projection with the head split fused into the GEMM epilogue (RMSNorm + RoPE into
     [B, H, S, 128]; bf16: V transposed [B, H, 128, pitch]) vs the unfused oracle math."""
-    if tile == 9 and dtype == torch.float32:
-        pytest.skip("256x128 tile is bf16 only")
+    if tile in (9, 15, 19) and dtype == torch.float32:
+        pytest.skip("bf16-only tile")
     K = 256
     S = L + Lv
     pitch = (S + 31) // 32 * 32
