@@ -609,7 +609,9 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     if (want > nk / 12) want = nk / 12;
     if (deferred) {   // one resident round of workgroups: as many K ranges as fit on 256 CUs (>= 4 slices each)
       const int per_cu = (tile == 3 || tile == 6 || tile == 13) ? 3 : 1;   // resident workgroups per CU
-      want = 256L * per_cu / blocks;
+      long both = blocks;   // a two-problem launch (audio + visual stream) shares the round and the K split
+      if (g1) both += (long)((g1->M + bm[tile] - 1) / bm[tile]) * ((g1->N + bn[tile] - 1) / bn[tile]);
+      want = 256L * per_cu / both;
       if (want > nk / 4) want = nk / 4;
     }
     g.ksplit = (int)(want < 1 ? 1 : (want > 16 ? 16 : want));
