@@ -77,23 +77,36 @@ def fp8_wrapped_key(key: str, tensor) -> bool:
     return key.endswith(".weight") and tensor.dim() >= 2 and tensor.is_floating_point()
 
 
-def fp8_round_state_dict(state_dict, qmode: str, autocast: bool = True):
+def fp8_round_state_dict(state_dict, qmode: str, autocast: bool = True, param_dtype=torch.float32):
     """Weight-only fp8 storage = plain cast, no scales; values are rounded once here and the kernels
-    run on the exactly representable bf16/fp32 images.  Under autocast (bf16/fp16 compute, the only
-    way the reference runs fp8 models) the first TimestepEmbedder bias is rounded too: the wrapper
-    casts it to the activation dtype, which embed_layers.py:134 has made fp8 (golden g8, "Q14");
-    the matching feature rounding lives in host/sampler.py::build_plan."""
+    run on the exactly representable bf16/fp32 images.  Order as in the reference loader
+    (nodes.py:96-124): checkpoint -> parameters of the requested precision (`param_dtype`; fp8
+    checkpoint tensors are upcast exactly) -> cast to the fp8 storage type, so an fp32 checkpoint is
+    rounded twice and an fp8 checkpoint of the other flavour is re-rounded.  Under autocast
+    (bf16/fp16 compute, the only way the reference runs fp8 models) the first TimestepEmbedder bias
+    is rounded too: the wrapper casts it to the activation dtype, which embed_layers.py:134 has made
+    fp8 (golden g8, "Q14"); the matching feature rounding lives in host/sampler.py::build_plan."""
     out = {}
     qd = {"fp8_e4m3fn": torch.float8_e4m3fn, "fp8_e5m2": torch.float8_e5m2}.get(qmode)
     for k, v in state_dict.items():
         if v.dtype in (torch.float8_e4m3fn, torch.float8_e5m2):
             v = v.to(torch.float32)
-        elif qd is not None and fp8_wrapped_key(k, v):
-            v = v.to(torch.float32).to(qd).to(torch.float32)
-        elif qd is not None and autocast and k == "time_in.mlp.0.bias":
-            v = v.to(torch.float32).to(qd).to(torch.float32)
+        if qd is not None and v.is_floating_point() and (fp8_wrapped_key(k, v) or (autocast and k == "time_in.mlp.0.bias")):
+            v = v.to(torch.float32).to(param_dtype).to(qd).to(torch.float32)
         out[k] = v
     return out
+
+
+def resolve_quantization(quantization: str, detected):
+    """Reference nodes.py:109-122: 'auto' honours fp8 tensors found in the checkpoint, else e4m3fn
+    (its e5m2 fallback is for compute capability < 9; gfx950 reports 9.x and implements OCP e4m3fn /
+    e5m2 natively) - i.e. the DEFAULT widget value rounds every Linear / Conv weight through fp8,
+    exactly like the reference does on a capable device."""
+    if quantization == "none":
+        return "none"
+    if quantization == "auto":
+        return detected or "fp8_e4m3fn"
+    return quantization
 
 
 def detect_ckpt_fp8(state_dict):
@@ -155,13 +168,9 @@ class HunyuanModelLoader:
         if precision == "auto" or dtype is None:
             major = detect_ckpt_major_precision(state_dict)
             dtype = torch.float32 if major == torch.float32 else torch.bfloat16
-        qmode = "none"
-        if quantization != "none":
-            # gfx950 implements OCP e4m3fn/e5m2 natively => 'auto' honours the checkpoint, else e4m3fn
-            qmode = (detected or "fp8_e4m3fn") if quantization == "auto" else quantization
-            if detected is None and quantization == "auto":
-                qmode = "none"          # nothing to honour: keep full-precision weights
-        sd = fp8_round_state_dict(state_dict, qmode, autocast=dtype != torch.float32)
+        qmode = resolve_quantization(quantization, detected)
+        param_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}.get(precision, dtype)
+        sd = fp8_round_state_dict(state_dict, qmode, autocast=dtype != torch.float32, param_dtype=param_dtype)
         return _sampler.FoleyModel(cfg, sd, dtype, device or _torch_device(), quantization=qmode)
 
     def build_model(self, model_name, precision, quantization):

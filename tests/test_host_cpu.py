@@ -280,6 +280,15 @@ def test_checkpoint_detection_helpers():
     assert nodes.detect_ckpt_major_precision(sd) == torch.bfloat16 and nodes.detect_ckpt_fp8(sd) is None
     sd["c"] = torch.zeros(4, 4).to(torch.float8_e4m3fn)
     assert nodes.detect_ckpt_fp8(sd) == "fp8_e4m3fn"
+    # quantization widget resolution (reference nodes.py:109-122): auto = checkpoint's flavour, else e4m3fn
+    assert nodes.resolve_quantization("auto", None) == "fp8_e4m3fn" and nodes.resolve_quantization("auto", "fp8_e5m2") == "fp8_e5m2"
+    assert nodes.resolve_quantization("none", "fp8_e5m2") == "none" and nodes.resolve_quantization("fp8_e5m2", None) == "fp8_e5m2"
+    # rounding order: checkpoint -> parameter dtype -> fp8 (double rounding of fp32 checkpoints, re-rounding of the other flavour)
+    w = torch.tensor([[1.0 + 2 ** -8 + 2 ** -12, 0.3]])
+    r = nodes.fp8_round_state_dict({"a.weight": w}, "fp8_e4m3fn", param_dtype=torch.bfloat16)["a.weight"]
+    assert torch.equal(r, w.to(torch.bfloat16).to(torch.float8_e4m3fn).float())
+    r2 = nodes.fp8_round_state_dict({"a.weight": w.to(torch.float8_e5m2)}, "fp8_e4m3fn")["a.weight"]
+    assert torch.equal(r2, w.to(torch.float8_e5m2).float().to(torch.float8_e4m3fn).float())
     f = nodes.select_frames(torch.rand(20, 4, 4, 3), 1.0, 16.0)
     assert f[0].shape == (8, 3, 4, 4) and f[1].shape == (25, 3, 4, 4) and f[0].dtype == torch.uint8
 

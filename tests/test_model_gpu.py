@@ -245,7 +245,7 @@ def test_fp8_weight_only_loader(dev):
         model = nodes.HunyuanModelLoader.pack_state_dict(sd, "bf16", q, device=dev, cfg=c)
         assert model.quantization == q and model.dtype == torch.bfloat16
         qd = torch.float8_e4m3fn if q == "fp8_e4m3fn" else torch.float8_e5m2
-        sdq = nodes.fp8_round_state_dict(sd, q, autocast=False)
+        sdq = nodes.fp8_round_state_dict(sd, q, autocast=False, param_dtype=torch.bfloat16)
         assert sum(1 for k in sd if not torch.equal(sd[k], sdq[k])) == 56     # the 56 wrapped modules of golden g8
         g = golden("g5_dit_tiny")
         x, t, cond, clip, sync = (g["a_" + k] for k in ("x", "t", "cond", "clip", "sync"))
@@ -260,6 +260,9 @@ def test_fp8_weight_only_loader(dev):
     sd8 = {k: (v.to(torch.float8_e4m3fn) if nodes.fp8_wrapped_key(k, v) else v) for k, v in sd.items()}
     m = nodes.HunyuanModelLoader.pack_state_dict(sd8, "bf16", "auto", device=dev, cfg=c)
     assert m.quantization == "fp8_e4m3fn" and m.dtype == torch.bfloat16
+    # ... and without fp8 tensors 'auto' (the widget default) still means e4m3fn, as in the reference
+    assert nodes.HunyuanModelLoader.pack_state_dict(sd, "bf16", "auto", device=dev, cfg=c).quantization == "fp8_e4m3fn"
+    assert nodes.HunyuanModelLoader.pack_state_dict(sd, "bf16", "none", device=dev, cfg=c).quantization == "none"
     # precision="auto" looks at bf16/fp16/fp32 tensors only (reference utils.py:507-515): here the
     # fp32 biases dominate, exactly as the reference would decide
     assert nodes.detect_ckpt_major_precision(sd8) == torch.float32
