@@ -301,3 +301,28 @@ def test_text_padding_and_noise_draw():
     g = golden("g6_c1_xxl")
     n = sampler.draw_noise(1, 128, 50, torch.float32, torch.Generator("cpu").manual_seed(1234))
     assert torch.equal(n, g["noise"])
+
+
+def test_checkpoint_file_formats(tmp_path):
+    """On-disk formats either side of the loader boundary: .safetensors (incl. fp8
+    tensors), .pth flat dict, .pth {"state_dict": ...} (reference utils.py:49-59, nodes.py:86)."""
+    from safetensors.torch import save_file
+    from foley_amd import nodes
+    sd = synth.synth_dit_state_dict(C.TINY)
+    keys = sorted(sd)[:40]
+    small = {k: sd[k].contiguous() for k in keys}
+    small8 = {k: (v.to(torch.float8_e4m3fn) if nodes.fp8_wrapped_key(k, v) else v) for k, v in small.items()}
+    p1, p2, p3, p4 = (str(tmp_path / n) for n in ("a.safetensors", "b.pth", "c.pth", "d.safetensors"))
+    save_file(small, p1)
+    torch.save(small, p2)
+    torch.save({"state_dict": small, "metadata": {"x": 1}}, p3)
+    save_file(small8, p4)
+    for p in (p1, p2, p3):
+        got = nodes._load_state_dict(p)
+        assert sorted(got) == keys and all(torch.equal(got[k], small[k]) for k in keys)
+    got8 = nodes._load_state_dict(p4)
+    assert nodes.detect_ckpt_fp8(got8) == "fp8_e4m3fn"
+    # an fp8 checkpoint is honoured verbatim by quantization="auto": same values as rounding the fp32 one
+    a = nodes.fp8_round_state_dict(got8, nodes.resolve_quantization("auto", nodes.detect_ckpt_fp8(got8)))
+    b = nodes.fp8_round_state_dict(small, "fp8_e4m3fn")
+    assert all(torch.equal(a[k], b[k]) for k in keys)
