@@ -38,7 +38,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
   const int sel = (int)blockIdx.x >= pr.tiles0 ? 1 : 0;
   const GemmArgs& g = pr.g[sel];
   constexpr int NW = WM * WN;
-  constexpr int EPC = 8, BK = 64, ESZ = 2, OOB = 0x7ffffff0;
+  constexpr int BK = 64, ESZ = 2, OOB = 0x7ffffff0;
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
   constexpr int AI = BM / 8 / LW, BI = BN / 8 / LW;  // 1 KiB pieces per loader wave and K-slice
   constexpr int STAGE = (BM + BN) * 128;
@@ -84,7 +84,8 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
       const int r = m0 + rl;
       const int rr = r < g.M ? r : 0;
       const int b = g.segV >= g.M ? 0 : rr / g.segV, q = rr - b * g.segV;   // plain GEMM: one segment, no division
-      a_base[i] = r < g.M ? (int)((((long)b * g.segS + q) * g.lda + (lp ^ ((rl >> 1) & 7)) * EPC) * ESZ) : -1;
+      // 32-bit math: the launcher guarantees both operand extents < 2^31 bytes
+      a_base[i] = r < g.M ? (int)((unsigned)(b * g.segS + q) * (unsigned)(g.lda * ESZ) + (unsigned)((lp ^ ((rl >> 1) & 7)) * 16)) : -1;
       a_q[i] = q;
     }
     int vW[BI];
@@ -92,7 +93,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
     for (int i = 0; i < BI; ++i) {
       const int rl = (lw * BI + i) * 8 + lr;
       const int n = n0 + rl;
-      vW[i] = (n < g.N) ? (int)(((long)n * g.K + (lp ^ ((rl >> 1) & 7)) * EPC) * ESZ) : OOB;
+      vW[i] = (n < g.N) ? (int)((unsigned)n * (unsigned)(g.K * ESZ) + (unsigned)((lp ^ ((rl >> 1) & 7)) * 16)) : OOB;
     }
     auto set_tap = [&](int toff) {   // per-lane offsets of the current tap (VALU, once per tap)
 #pragma unroll
