@@ -13,6 +13,22 @@ namespace {
 
 constexpr int HD = 128;
 
+// 1-D grid -> (query tile, head, batch) with a bijective XCD-aware remap: workgroup id i runs on XCD
+// i % 8, so ids are regrouped such that all query tiles of one (batch, head) - which read the same
+// K / V - land on the same XCD and share its L2 instead of fetching the operands once per XCD.
+__device__ __forceinline__ void attn_block_coords(const AttnArgs& a, int qtile, int& qt, int& h, int& b) {
+  const int nq = (a.Sq + qtile - 1) / qtile;
+  const int nwg = nq * a.H * a.Bq;
+  int bid = (int)blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  qt = bid % nq;
+  const int bh = bid / nq;
+  h = bh % a.H;
+  b = bh / a.H;
+}
+
 template <typename OutT> struct Pack4Out;
 template <> struct Pack4Out<float> {
   static __device__ __forceinline__ void store(float* p, const f32x4 v) { *(f32x4*)p = v; }
@@ -142,8 +158,9 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
   __shared__ float sM[4][32], sL[4][32];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int j = lane & 31, kh = lane >> 5;
-  const int q0 = blockIdx.x * 32;
-  const int h = blockIdx.y, b = blockIdx.z;
+  int qt, h, b;
+  attn_block_coords(a, 32, qt, h, b);
+  const int q0 = qt * 32;
   const int bk = b / a.kv_bdiv;
   const bf16_t* __restrict__ Q = (const bf16_t*)a.q + ((long)(b * a.H + h) * a.Sq) * HD;
   const bf16_t* __restrict__ K = (const bf16_t*)a.k + ((long)(bk * a.H + h) * a.Skv) * HD;
@@ -274,8 +291,9 @@ __global__ __launch_bounds__(256) void attn_bf16_wide_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STG];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int j = lane & 31, kh = lane >> 5;
-  const int q0 = blockIdx.x * 128 + w * 32;
-  const int h = blockIdx.y, b = blockIdx.z;
+  int qt, h, b;
+  attn_block_coords(a, 128, qt, h, b);
+  const int q0 = qt * 128 + w * 32;
   const int bk = b / a.kv_bdiv;
   const bf16_t* __restrict__ Q = (const bf16_t*)a.q + ((long)(b * a.H + h) * a.Sq) * HD;
   const bf16_t* __restrict__ K = (const bf16_t*)a.k + ((long)(bk * a.H + h) * a.Skv) * HD;
@@ -389,16 +407,17 @@ __global__ __launch_bounds__(256) void attn_bf16_wide_kernel(const AttnArgs a) {
 int launch_attention(const AttnArgs& a, int out_dtype, hipStream_t st) {
   if (a.Sq <= 0 || a.Skv <= 0) return foley_set_err("attention: empty sequence", __FILE__, __LINE__);
   dim3 grid((a.Sq + 31) / 32, a.H, a.Bq), block(64);
+  const dim3 grid1(grid.x * grid.y * grid.z);   // bf16 kernels: 1-D grid, XCD-aware remap inside
   if (a.in_dtype == FOLEY_BF16) {
     if (a.vt_pitch < ((a.Skv + 31) & ~31) || (a.vt_pitch & 7))
       return foley_set_err("attention: V^T pitch must cover Skv rounded up to 32 (multiple of 8)", __FILE__, __LINE__);
     // enough 128-query workgroups to cover the chip => the wide kernel (operands read once per 128 queries)
-    const dim3 gw((a.Sq + 127) / 128, a.H, a.Bq);
-    if ((long)gw.x * gw.y * gw.z >= 256) {
+    const dim3 gw(((a.Sq + 127) / 128) * a.H * a.Bq);
+    if ((long)gw.x >= 256) {
       if (out_dtype == FOLEY_BF16) hipLaunchKernelGGL(attn_bf16_wide_kernel<bf16_t>, gw, dim3(256), 0, st, a);
       else hipLaunchKernelGGL(attn_bf16_wide_kernel<float>, gw, dim3(256), 0, st, a);
-    } else if (out_dtype == FOLEY_BF16) hipLaunchKernelGGL(attn_bf16_kernel<bf16_t>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(attn_bf16_kernel<float>, grid, dim3(256), 0, st, a);
+    } else if (out_dtype == FOLEY_BF16) hipLaunchKernelGGL(attn_bf16_kernel<bf16_t>, grid1, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(attn_bf16_kernel<float>, grid1, dim3(256), 0, st, a);
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) return foley_set_err(hipGetErrorString(e2), __FILE__, __LINE__);
     return 0;
