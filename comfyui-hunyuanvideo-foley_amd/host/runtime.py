@@ -124,7 +124,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         fn = getattr(lib, name)     # AttributeError if the .so does not export the ABI
         fn.restype = res
         fn.argtypes = args
-    if lib.foley_abi_version() != 1:
+    if lib.foley_abi_version() != 2:
         raise FoleyRuntimeError("libfoley_hip.so ABI version mismatch")
     if path is None:
         _LIB = lib

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FOLEY_ABI_VERSION 1
+#define FOLEY_ABI_VERSION 2   /* 2: foley_gemm_desc gained partials / qkv, foley_op_ln_mod_pending added */
 
 enum foley_dtype { FOLEY_DT_F32 = 0, FOLEY_DT_BF16 = 1, FOLEY_DT_I32 = 2 };
 
