@@ -872,6 +872,104 @@ extern "C" int foley_dac_decode(foley_ctx* c, const float* latents, int clips, i
   return 0;
 }
 
+// --------------------------------------------------------------------------- DAC encoder (row N4)
+// DAC.encode, continuous=True (dac.py:236-278): waveform [clips, 1, T] (T a multiple of the hop) ->
+// posterior parameters [clips, 2*latent, T/hop] = quant_conv(encoder(x)).  Same engine as the
+// decoder: time-major fp32 activations, conv-as-GEMM with the residual + snake epilogue; the strided
+// down-sampling convs (k = 2s, stride s, pad ceil(s/2)) are GEMMs over virtual rows that advance s
+// source rows (GemmArgs::rstride).
+extern "C" int foley_dac_encode(foley_ctx* c, const float* wave, int clips, int T, int enc_dim, const int32_t* rates,
+                                int n_rates, float* params, void* stream_v) {
+  if (!c || !wave || !params || !rates || clips < 1 || T < 1 || n_rates < 1 || n_rates > 8 || enc_dim < 1)
+    return FAIL(FOLEY_ERR_INVALID, "bad argument");
+  long hop = 1;
+  for (int i = 0; i < n_rates; ++i) hop *= rates[i];
+  if (T % hop) return FAIL(FOLEY_ERR_INVALID, "waveform length must be a multiple of the codec hop (DAC.preprocess pads it)");
+  hipStream_t st = (hipStream_t)stream_v;
+  HIPTRY(hipSetDevice(c->device));
+  const foley_config& f = c->cfg;
+  const int L = f.latent_dim;
+  size_t maxel = 0;
+  {
+    long t = T;
+    int ch = enc_dim;
+    for (int i = 0; i <= n_rates; ++i) {
+      maxel = std::max(maxel, (size_t)t * ch);
+      if (i < n_rates) { t /= rates[i]; ch *= 2; }
+    }
+  }
+  const int Tz = (int)(T / hop);
+  HIPTRY(hipStreamSynchronize(st));
+  TRY(grow(c->dacP, maxel * clips * 4));
+  TRY(grow(c->dacQ, maxel * clips * 4));
+  TRY(grow(c->dacR, maxel * clips * 4));
+  TRY(grow(c->dacZ, (size_t)clips * Tz * L * 4 * 3));
+  float *S_in = (float*)c->dacP.p, *X = (float*)c->dacQ.p, *S_alt = (float*)c->dacR.p;
+  float* Z0 = (float*)c->dacZ.p;
+  float* Z1 = Z0 + (size_t)clips * Tz * L;
+  HIPTRY(hipEventRecord(c->ev0, st));
+
+  int Tin = T, C = enc_dim;
+  {
+    const void *w, *b, *a;
+    TRY(get_tensor(c, "enc.in.w", FOLEY_F32, {7 * C}, &w));
+    TRY(get_tensor(c, "enc.in.b", FOLEY_F32, {C}, &b));
+    TRY(get_tensor(c, "enc.0.0.a1", FOLEY_F32, {C}, &a));
+    TRY(launch_dac_in(wave, (const float*)w, (const float*)b, (const float*)a, clips, T, C, X, S_in, st));
+  }
+  for (int i = 0; i < n_rates; ++i) {
+    const int s = rates[i], Cout = 2 * C, Tout = Tin / s, pad = (s + 1) / 2;
+    const std::string p = "enc." + std::to_string(i) + ".";
+    for (int j = 0; j < 3; ++j) {
+      const int d = f.dac_dilations[j];
+      const std::string u = p + std::to_string(j) + ".";
+      Lin c7, c1;
+      const void *a2, *an;
+      TRY(get_lin(c, u + "c7", FOLEY_F32, C, 7 * C, true, &c7));
+      TRY(get_lin(c, u + "c1", FOLEY_F32, C, C, true, &c1));
+      TRY(get_tensor(c, u + "a2", FOLEY_F32, {C}, &a2));
+      // alpha of whatever consumes this unit's output next: the next unit, or the snake before the strided conv
+      TRY(get_tensor(c, j < 2 ? p + std::to_string(j + 1) + ".a1" : p + "alpha", FOLEY_F32, {C}, &an));
+      {
+        GemmArgs g = gemm_conv(S_in, clips * Tin, Tin, C, 7, d, c7, nullptr, C);
+        g.out1 = S_alt; g.alpha = (const float*)a2; g.alphaC = C;
+        TRY(launch_gemm(g, FOLEY_F32, EPI_DAC, 0, st));
+      }
+      {
+        GemmArgs g = gemm_plain(S_alt, clips * Tin, c1, X, C);
+        g.res = X; g.out1 = S_in; g.alpha = (const float*)an; g.alphaC = C;
+        TRY(launch_gemm(g, FOLEY_F32, EPI_DAC, 0, st));
+      }
+    }
+    {
+      // strided conv: output row q of a clip reads source rows q*s - pad + j, j < 2s  (dac.py:55-61)
+      Lin down;
+      const void* an;
+      TRY(get_lin(c, p + "down", FOLEY_F32, Cout, 2 * s * C, true, &down));
+      TRY(get_tensor(c, i + 1 < n_rates ? "enc." + std::to_string(i + 1) + ".0.a1" : std::string("enc.out.alpha"), FOLEY_F32,
+                     {Cout}, &an));
+      GemmArgs g = gemm_plain(S_in, clips * Tout, down, X, Cout);
+      g.lda = C; g.segV = Tout; g.segS = Tin; g.taps = 2 * s; g.tapC = C; g.dil = 1; g.tap0 = -pad; g.rstride = s;
+      g.out1 = S_alt; g.alpha = (const float*)an; g.alphaC = Cout;
+      TRY(launch_gemm(g, FOLEY_F32, EPI_DAC, 0, st));
+      std::swap(S_in, S_alt);
+    }
+    Tin = Tout;
+    C = Cout;
+  }
+  {
+    Lin co, qc;
+    TRY(get_lin(c, "enc.out", FOLEY_F32, L, 3 * C, true, &co));
+    TRY(get_lin(c, "enc.qc", FOLEY_F32, 2 * L, L, true, &qc));
+    TRY(launch_gemm(gemm_conv(S_in, clips * Tin, Tin, C, 3, 1, co, Z0, L), FOLEY_F32, EPI_STORE_F32, 0, st));
+    TRY(launch_gemm(gemm_plain(Z0, clips * Tin, qc, Z1, 2 * L), FOLEY_F32, EPI_STORE_F32, 0, st));
+    TRY(launch_rows_to_planes(Z1, clips, Tin, 2 * L, params, st));
+  }
+  HIPTRY(hipEventRecord(c->ev1, st));
+  c->timed = true;
+  return 0;
+}
+
 // --------------------------------------------------------------------------- op-level entry points
 static RowBcast to_rb(const foley_rowbcast* r) {
   if (!r || !r->p) return rb_none();
@@ -887,6 +985,7 @@ extern "C" int foley_op_gemm(const foley_gemm_desc* d, void* stream) {
   g.out_shift = d->out_shift; g.out_check = d->out_check; g.rb = to_rb(&d->rb); g.res = d->res;
   g.alpha = d->alpha; g.alphaC = d->alphaC > 0 ? d->alphaC : 1;
   g.ksplit = d->ksplit;
+  g.rstride = d->rstride;
   if (d->partials) {
     if (d->partial_slabs < 1) return FAIL(FOLEY_ERR_INVALID, "partials need partial_slabs >= 1");
     g.partials = d->partials; g.partial_stride = (long)d->M * d->N; g.partial_cap = d->partial_slabs;

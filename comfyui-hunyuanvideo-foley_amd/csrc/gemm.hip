@@ -65,8 +65,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmPair pr) {
       b = rr / g.segV;
       q = rr - b * g.segV;
     }
-    ap[i] = (const T*)g.A + ((long)b * g.segS + q) * g.lda + chunk * EPC;
-    a_q[i] = q;
+    const int qs = q * (g.rstride > 1 ? g.rstride : 1);   // source row of tap offset 0 (strided conv)
+    ap[i] = (const T*)g.A + ((long)b * g.segS + qs) * g.lda + chunk * EPC;
+    a_q[i] = qs;
   }
   const T* wp[RB];
   bool w_ok[RB];
@@ -310,8 +311,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmPair p
     const int r = m0 + rl;
     const int rr = r < g.M ? r : 0;
     const int b = g.segV >= g.M ? 0 : rr / g.segV, q = rr - b * g.segV;   // plain GEMM: one segment, no division
-    a_base[i] = r < g.M ? (int)((((long)b * g.segS + q) * g.lda + (lp ^ ((rl >> 1) & 7)) * EPC) * ESZ) : -1;
-    a_q[i] = q;
+    const int qs = q * (g.rstride > 1 ? g.rstride : 1);   // source row of tap offset 0 (strided conv)
+    a_base[i] = r < g.M ? (int)((((long)b * g.segS + qs) * g.lda + (lp ^ ((rl >> 1) & 7)) * EPC) * ESZ) : -1;
+    a_q[i] = qs;
   }
   int vW[BI];
 #pragma unroll
@@ -539,7 +541,7 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     return foley_set_err("GEMM: K / tap width / lda must be multiples of the 128-byte K-slice", __FILE__, __LINE__);
   if (((uintptr_t)g.A | (uintptr_t)g.W) & 15)
     return foley_set_err("GEMM: operands must be 16-byte aligned", __FILE__, __LINE__);
-  const bool conv3_ok = !g1 && g.taps == 3 && g.dil == 1 && g.tap0 == -1 && g.segV == g.segS && g.lda == g.tapC &&
+  const bool conv3_ok = !g1 && g.taps == 3 && g.dil == 1 && g.tap0 == -1 && g.rstride <= 1 && g.segV == g.segS && g.lda == g.tapC &&
                         g.osegV >= g.M && (epi == EPI_STORE_F32 || epi == EPI_GATE_RES || epi == EPI_SILUGATE_T);
   const bool tile_auto = tile == 0;
   // deferred split-K available (bf16 mode, caller provided partial slabs): reductions are cheap

@@ -85,8 +85,9 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
       const int rr = r < g.M ? r : 0;
       const int b = g.segV >= g.M ? 0 : rr / g.segV, q = rr - b * g.segV;   // plain GEMM: one segment, no division
       // 32-bit math: the launcher guarantees both operand extents < 2^31 bytes
-      a_base[i] = r < g.M ? (int)((unsigned)(b * g.segS + q) * (unsigned)(g.lda * ESZ) + (unsigned)((lp ^ ((rl >> 1) & 7)) * 16)) : -1;
-      a_q[i] = q;
+      const int qs = q * (g.rstride > 1 ? g.rstride : 1);   // source row of tap offset 0 (strided conv)
+      a_base[i] = r < g.M ? (int)((unsigned)(b * g.segS + qs) * (unsigned)(g.lda * ESZ) + (unsigned)((lp ^ ((rl >> 1) & 7)) * 16)) : -1;
+      a_q[i] = qs;
     }
     int vW[BI];
 #pragma unroll

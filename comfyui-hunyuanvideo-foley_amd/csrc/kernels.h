@@ -46,6 +46,7 @@ struct GemmArgs {
   long lda;           // elements between source rows of A
   int segV, segS;     // virtual / source rows per segment
   int taps, tapC, dil, tap0;
+  int rstride;        // source rows advanced per virtual row (strided conv: tap t of row q reads q*rstride + tap0 + t*dil); 0 = 1
   // output mapping: element (r, n) -> b*out_seg + q*out_row + n + out_shift with (b, q) taken
   // over osegV rows; skipped when out_check and the in-segment offset leaves [0, out_seg)
   void* out0;
@@ -170,5 +171,9 @@ struct StepArgs {
 int launch_solver_step(const StepArgs& a, hipStream_t st);
 
 // DAC tail: out[b, t] = tanh(bias + sum_{j<7, c<C} w[j*C + c] * s[b, t + j - 3, c])
+// DAC encoder: input conv 1 -> C (k=7) writing y and snake(y); rows [B*T, C] -> planes [B, C, T]
+int launch_dac_in(const float* x, const float* w, const float* bias, const float* alpha, int B, int T, int C,
+                  float* out0, float* out1, hipStream_t st);
+int launch_rows_to_planes(const float* rows, int B, int T, int C, float* out, hipStream_t st);
 int launch_dac_out(const float* s, const float* w, const float* bias, int B, int T, int C, float* out,
                    hipStream_t st);

@@ -392,6 +392,50 @@ __global__ __launch_bounds__(256) void dac_out_kernel(const float* __restrict__ 
   if (part == 0 && t < T) out[(long)b * T + t] = tanhf(acc + bias[0]);
 }
 
+// ------------------------------------------------------------------ DAC encoder input conv (1 -> C, k=7)
+// reference: Encoder.block[0] = WNConv1d(1, d_model, 7, padding=3) (dac.py:86); the first residual
+// unit needs both y (trunk) and snake(y) (its conv input), so both are written.
+__global__ __launch_bounds__(256) void dac_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, const float* __restrict__ alpha,
+                                                     int B, int T, int C, float* __restrict__ out0,
+                                                     float* __restrict__ out1) {
+  const int c4n = C >> 2;
+  const long n = (long)B * T * c4n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    const long bt = i / c4n;
+    const int t = (int)(bt % T);
+    const float* xr = x + (bt - t);
+    f32x4 acc = *(const f32x4*)(bias + c);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int tt = t + j - 3;
+      const float xv = (tt >= 0 && tt < T) ? xr[tt] : 0.f;
+      const f32x4 wv = *(const f32x4*)(w + j * C + c);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] += xv * wv[u];
+    }
+    *(f32x4*)(out0 + bt * C + c) = acc;
+    const f32x4 al = *(const f32x4*)(alpha + c);
+    f32x4 sn;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) sn[u] = snake_f(acc[u], al[u], 1.0f / (al[u] + 1e-9f));
+    *(f32x4*)(out1 + bt * C + c) = sn;
+  }
+}
+
+// rows [B*T, C] -> planes [B, C, T] (the [B, 2*latent, T'] layout DAC.encode returns)
+__global__ void rows_to_planes_kernel(const float* __restrict__ rows, int B, int T, int C, float* __restrict__ out) {
+  const long n = (long)B * T * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % T);
+    const long bc = i / T;
+    const int c = (int)(bc % C);
+    const long b = bc / C;
+    out[i] = rows[(b * T + t) * C + c];
+  }
+}
+
 inline int grid1d(long n, int block) {
   long g = (n + block - 1) / block;
   return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
@@ -541,6 +585,21 @@ int launch_solver_step(const StepArgs& a, hipStream_t st) {
   else hipLaunchKernelGGL(solver_step_kernel<float>, grid, block, 0, st, a);
   FOLEY_LAUNCH_CHECK();
   hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, st, a.step_ptr);
+  FOLEY_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_dac_in(const float* x, const float* w, const float* bias, const float* alpha, int B, int T, int C,
+                  float* out0, float* out1, hipStream_t st) {
+  if (C % 4) return foley_set_err("dac_in: channel count must be a multiple of 4", __FILE__, __LINE__);
+  hipLaunchKernelGGL(dac_in_kernel, dim3(grid1d((long)B * T * (C / 4), 256)), dim3(256), 0, st, x, w, bias, alpha, B, T, C,
+                     out0, out1);
+  FOLEY_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_rows_to_planes(const float* rows, int B, int T, int C, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(rows_to_planes_kernel, dim3(grid1d((long)B * T * C, 256)), dim3(256), 0, st, rows, B, T, C, out);
   FOLEY_LAUNCH_CHECK();
   return 0;
 }

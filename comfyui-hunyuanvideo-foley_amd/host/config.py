@@ -58,6 +58,9 @@ class DACConfig:
     rates: Tuple[int, ...] = (8, 5, 4, 3, 2)
     sample_rate: int = 48000
     dilations: Tuple[int, ...] = (1, 3, 9)
+    # encoder half (dac.py:47-95; `_DAC_KWARGS` utils.py:32-44): channels double per stage
+    encoder_dim: int = 128
+    encoder_rates: Tuple[int, ...] = (2, 3, 4, 5, 8)
 
     @property
     def hop(self) -> int:
@@ -75,6 +78,8 @@ DAC48K = DACConfig()
 # narrow decoder for fast tests (same topology: 5 stages, same rates); the last stage keeps 32
 # channels = one 128-byte fp32 K-slice, the engine's minimum tap width
 DAC_TINY = DACConfig(decoder_dim=1024)
+# narrow codec for the encoder tests: 32 -> 64 -> 128 channels, hop 6 (latent width stays 128 = the DiT's)
+DAC_ENC_TINY = DACConfig(latent_dim=128, decoder_dim=128, rates=(3, 2), encoder_dim=32, encoder_rates=(2, 3))
 
 _BY_NAME = {"xxl": XXL, "xl": XL, "tiny": TINY}
 

@@ -180,6 +180,40 @@ def pack_dac(sd: Dict[str, Tensor], cfg: DACConfig) -> "OrderedDict[str, Tensor]
     return out
 
 
+def has_dac_encoder(sd: Dict[str, Tensor]) -> bool:
+    return "encoder.block.0.bias" in sd and "quant_conv.weight" in sd
+
+
+def pack_dac_encoder(sd: Dict[str, Tensor], cfg: DACConfig) -> "OrderedDict[str, Tensor]":
+    """Encoder half + quant_conv of the DAC-VAE state dict -> packed fp32 tensors (dac.py:47-95, 196;
+    SURVEY N4).  Strided convs are packed tap-major like every other conv: GEMM row q reads source rows
+    q*s - ceil(s/2) + j for tap j < 2s."""
+    out: "OrderedDict[str, Tensor]" = OrderedDict()
+    w0 = fold_weight_norm(sd, "encoder.block.0")                       # [d, 1, 7]
+    out["enc.in.w"] = w0[:, 0, :].permute(1, 0).reshape(-1).contiguous()   # [7][d]
+    out["enc.in.b"] = _f32(sd["encoder.block.0.bias"])
+    n = len(cfg.encoder_rates)
+    for i, s in enumerate(cfg.encoder_rates):
+        r, p = f"encoder.block.{i + 1}.block.", f"enc.{i}."
+        for j in range(3):
+            q, u = r + f"{j}.block.", p + f"{j}."
+            out[u + "a1"] = _f32(sd[q + "0.alpha"]).reshape(-1)
+            out[u + "c7.w"] = conv_to_gemm(fold_weight_norm(sd, q + "1"))
+            out[u + "c7.b"] = _f32(sd[q + "1.bias"])
+            out[u + "a2"] = _f32(sd[q + "2.alpha"]).reshape(-1)
+            out[u + "c1.w"] = fold_weight_norm(sd, q + "3").squeeze(-1).contiguous()
+            out[u + "c1.b"] = _f32(sd[q + "3.bias"])
+        out[p + "alpha"] = _f32(sd[r + "3.alpha"]).reshape(-1)
+        out[p + "down.w"] = conv_to_gemm(fold_weight_norm(sd, r + "4"))
+        out[p + "down.b"] = _f32(sd[r + "4.bias"])
+    out["enc.out.alpha"] = _f32(sd[f"encoder.block.{n + 1}.alpha"]).reshape(-1)
+    out["enc.out.w"] = conv_to_gemm(fold_weight_norm(sd, f"encoder.block.{n + 2}"))
+    out["enc.out.b"] = _f32(sd[f"encoder.block.{n + 2}.bias"])
+    out["enc.qc.w"] = _f32(sd["quant_conv.weight"]).squeeze(-1).contiguous()
+    out["enc.qc.b"] = _f32(sd["quant_conv.bias"])
+    return out
+
+
 # ----------------------------------------------------------------------------- arena
 _ALIGN = 256
 

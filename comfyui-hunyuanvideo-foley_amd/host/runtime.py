@@ -69,7 +69,7 @@ class GemmDescC(C.Structure):
         ("rb", RowBcastC), ("res", C.c_void_p), ("alpha", C.c_void_p), ("alphaC", C.c_int32),
         ("dtype", C.c_int32), ("epilogue", C.c_int32), ("tile", C.c_int32), ("ksplit", C.c_int32),
         ("partials", C.c_void_p), ("partial_slabs", C.c_int32), ("ksplit_used", C.POINTER(C.c_int32)),
-        ("qkv", C.POINTER(QkvSplitDescC)),
+        ("qkv", C.POINTER(QkvSplitDescC)), ("rstride", C.c_int32),
     ]
 
 
@@ -85,6 +85,8 @@ _SIGNATURES = {
     "foley_dit_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "foley_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, PROGRESS_CB, C.c_void_p, C.c_void_p]),
     "foley_dac_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "foley_dac_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int,
+                                   C.c_void_p, C.c_void_p]),
     "foley_last_elapsed_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "foley_op_gemm": (C.c_int, [C.POINTER(GemmDescC), C.c_void_p]),
     "foley_op_attention": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int,
@@ -250,6 +252,27 @@ class FoleyContext:
                    "foley_dac_decode")
         return wave
 
+    def dac_encode(self, wave: torch.Tensor) -> torch.Tensor:
+        """DAC.encode (continuous=True): wave [clips, 1, T] fp32 on the GPU -> posterior parameters
+        [clips, 2*latent, T'] (rows [:latent] mean, [latent:] logvar).  The waveform is right-padded
+        to a multiple of the hop like DAC.preprocess (dac.py:225-234)."""
+        cfg = self.dac_cfg
+        rates = list(cfg.encoder_rates)
+        hop = 1
+        for r in rates:
+            hop *= r
+        clips, _one, T = wave.shape
+        Tp = -(-T // hop) * hop
+        if Tp != T:
+            wave = torch.nn.functional.pad(wave, (0, Tp - T))
+        wave = wave.contiguous().float()
+        out = torch.empty(clips, 2 * cfg.latent_dim, Tp // hop, dtype=torch.float32, device=self.device)
+        arr = (C.c_int32 * len(rates))(*rates)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.foley_dac_encode(self._h, _ptr(wave), clips, Tp, cfg.encoder_dim, arr, len(rates),
+                                                       _ptr(out), _stream()), "foley_dac_encode")
+        return out
+
     def last_elapsed_ms(self) -> float:
         ms = C.c_float()
         _check(self.lib, self.lib.foley_last_elapsed_ms(self._h, C.byref(ms)), "foley_last_elapsed_ms")
@@ -271,8 +294,9 @@ def rowbcast(t: Optional[torch.Tensor], mode: int = 0, rows_per_cfg: int = 1, L:
 
 def op_gemm(A, W, bias=None, *, M=None, epilogue=EPI_STORE_F32, out0=None, out1=None, ldc=None, conv=None,
             convT=None, rb: Optional[RowBcastC] = None, res=None, alpha=None, alphaC=1, tile=0, ksplit=0,
-            partials=None, qkv: Optional["QkvSplitDescC"] = None) -> int:
-    """Thin wrapper over foley_op_gemm.  conv=(seg, C, taps, dil) ; convT=(Tin, Cin, stride, Cout).
+            partials=None, qkv: Optional["QkvSplitDescC"] = None, sconv=None) -> int:
+    """Thin wrapper over foley_op_gemm.  conv=(seg, C, taps, dil) ; convT=(Tin, Cin, stride, Cout) ;
+    sconv=(Tin, Cin, stride): strided conv k=2*stride, pad ceil(stride/2) over clips of Tin rows.
     partials: fp32 [slabs, M, N] workspace for the deferred split-K of the gated-residual epilogue.
     Returns the K split the launcher used."""
     lib = load_library()
@@ -288,6 +312,14 @@ def op_gemm(A, W, bias=None, *, M=None, epilogue=EPI_STORE_F32, out0=None, out1=
         d.segV, d.segS, d.taps, d.tapC, d.dil, d.tap0 = Tin + 1, Tin, 2, Cin, 1, -1
         d.osegV, d.out_seg, d.out_row = Tin + 1, Tin * s * Cout, s * Cout
         d.out_shift, d.out_check = -((s + 1) // 2) * Cout, 1
+    elif sconv is not None:
+        Tin, Cin, st_ = sconv
+        clips = A.numel() // (Tin * Cin)
+        Tout = Tin // st_
+        d.M, d.lda = clips * Tout, Cin
+        d.segV, d.segS, d.taps, d.tapC, d.dil, d.tap0 = Tout, Tin, 2 * st_, Cin, 1, -((st_ + 1) // 2)
+        d.rstride = st_
+        d.osegV, d.out_seg, d.out_row, d.out_shift, d.out_check = d.M, 0, (ldc or N), 0, 0
     elif conv is not None:
         seg, Cc, taps, dil = conv
         d.M = A.numel() // Cc if M is None else M

@@ -79,12 +79,17 @@ class FoleyDAC:
         self.cfg = cfg
         self.sample_rate = cfg.sample_rate
         self.device = torch.device(device)
-        self.arena = packers.Arena.from_packed(packers.pack_dac(dac_state, cfg), self.device)
+        packed = packers.pack_dac(dac_state, cfg)
+        self.has_encoder = packers.has_dac_encoder(dac_state)
+        if self.has_encoder:     # full checkpoints (the reference loads them strict=True) also carry the encoder
+            packed.update(packers.pack_dac_encoder(dac_state, cfg))
+        self.arena = packers.Arena.from_packed(packed, self.device)
 
     @classmethod
     def from_arena(cls, arena, device, cfg: DACConfig = DAC48K):
         self = cls.__new__(cls)
         self.cfg, self.sample_rate, self.device, self.arena = cfg, cfg.sample_rate, torch.device(device), arena
+        self.has_encoder = "enc.in.w" in arena.table
         return self
 
 

@@ -156,6 +156,34 @@ def dac_decoder_schema(cfg: DACConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...
     return sd
 
 
+def dac_encoder_schema(cfg: DACConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...], float, float]]":
+    """Encoder-side keys of `DAC(**_DAC_KWARGS).state_dict()` (dac.py:47-95, 196): first conv,
+    one EncoderBlock per rate (3 residual units at the incoming width, snake, strided conv k=2s that
+    doubles the channels), snake + conv k=3 to the latent width, and the 1x1 `quant_conv` that emits
+    the posterior's (mean, logvar)."""
+    sd: "OrderedDict[str, Tuple[Tuple[int, ...], float, float]]" = OrderedDict()
+    d = cfg.encoder_dim
+    _wn(sd, "encoder.block.0", (d, 1, 7), d, d, g_mean=1.0)
+    for i, s_ in enumerate(cfg.encoder_rates):
+        p = f"encoder.block.{i + 1}.block."
+        for j in range(3):
+            q = p + f"{j}.block."
+            sd[q + "0.alpha"] = ((1, d, 1), 0.15, 1.0)
+            _wn(sd, q + "1", (d, d, 7), d, d)
+            sd[q + "2.alpha"] = ((1, d, 1), 0.15, 1.0)
+            _wn(sd, q + "3", (d, d, 1), d, d, g_mean=0.3)
+        sd[p + "3.alpha"] = ((1, d, 1), 0.15, 1.0)
+        _wn(sd, p + "4", (2 * d, d, 2 * s_), 2 * d, 2 * d, g_mean=1.0)
+        d *= 2
+    n = len(cfg.encoder_rates)
+    sd[f"encoder.block.{n + 1}.alpha"] = ((1, d, 1), 0.15, 1.0)
+    _wn(sd, f"encoder.block.{n + 2}", (cfg.latent_dim, d, 3), cfg.latent_dim, cfg.latent_dim, g_mean=1.0)
+    L = cfg.latent_dim
+    sd["quant_conv.weight"] = ((2 * L, L, 1), 1.0 / math.sqrt(L), 0.0)
+    sd["quant_conv.bias"] = ((2 * L,), 0.05, 0.0)
+    return sd
+
+
 def materialize(schema, device="cpu", seed: int = 0, dtype=torch.float32,
                 keys: Iterable[str] = None) -> Dict[str, torch.Tensor]:
     out: Dict[str, torch.Tensor] = OrderedDict()
@@ -170,8 +198,12 @@ def synth_dit_state_dict(cfg: DiTConfig, device="cpu", seed: int = 0, dtype=torc
     return materialize(dit_schema(cfg), device=device, seed=seed, dtype=dtype)
 
 
-def synth_dac_state_dict(cfg: DACConfig, device="cpu", seed: int = 0):
-    return materialize(dac_decoder_schema(cfg), device=device, seed=seed)
+def synth_dac_state_dict(cfg: DACConfig, device="cpu", seed: int = 0, encoder: bool = False):
+    """Decoder-side checkpoint (what the sampler needs); encoder=True adds the encoder / quant_conv keys."""
+    sd = materialize(dac_decoder_schema(cfg), device=device, seed=seed)
+    if encoder:
+        sd.update(materialize(dac_encoder_schema(cfg), device=device, seed=seed))
+    return sd
 
 
 def synth_conditioning(cfg: DiTConfig, duration_s: float, *, t2a: bool, sd=None, seed: int = 1,

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FOLEY_ABI_VERSION 2   /* 2: foley_gemm_desc gained partials / qkv, foley_op_ln_mod_pending added */
+#define FOLEY_ABI_VERSION 2   /* 2: foley_gemm_desc gained partials / qkv / rstride; foley_op_ln_mod_pending, foley_dac_encode added */
 
 enum foley_dtype { FOLEY_DT_F32 = 0, FOLEY_DT_BF16 = 1, FOLEY_DT_I32 = 2 };
 
@@ -111,7 +111,16 @@ int foley_sample(foley_ctx* ctx, float* latents, int use_graph, foley_progress_c
 /* DAC-VAE decoder: latents [clips, latent_dim, T] fp32 -> waveform [clips, 1, T*hop] fp32. */
 int foley_dac_decode(foley_ctx* ctx, const float* latents, int clips, int T, float* wave, void* stream);
 
-/* HIP-event time (ms) of the last foley_sample / foley_dac_decode call on this context (syncs). */
+/* DAC-VAE encoder (DAC.encode with continuous=True, dac.py:236-278 + Encoder :47-95):
+ * waveform [clips, 1, T] fp32, T a multiple of the hop (DAC.preprocess right-pads, :225-234) ->
+ * posterior parameters [clips, 2*latent_dim, T/hop] fp32 (rows [:latent] mean, [latent:] logvar of the
+ * DiagonalGaussianDistribution, nn/vae_utils.py:24-31).  enc_dim / rates: encoder_dim and
+ * encoder_rates of the checkpoint (128, {2,3,4,5,8} for the 48 kHz VAE, utils.py:32-44); needs the
+ * packed `enc.*` tensors registered. */
+int foley_dac_encode(foley_ctx* ctx, const float* wave, int clips, int T, int enc_dim, const int32_t* rates,
+                     int n_rates, float* params, void* stream);
+
+/* HIP-event time (ms) of the last foley_sample / foley_dac_decode / foley_dac_encode call on this context (syncs). */
 int foley_last_elapsed_ms(foley_ctx* ctx, float* ms);
 
 /* ------------------------------------------------------------------ op-level entry points */
@@ -157,6 +166,7 @@ typedef struct foley_gemm_desc {
   float* partials; int32_t partial_slabs; int32_t* ksplit_used;
   /* epilogue 7 (fused head split): N = nK*H*128, out0 unused, results go to qkv->dst[] */
   const foley_qkv_split_desc* qkv;
+  int32_t rstride; /* source rows advanced per virtual row (strided conv, dac.py:55-61); 0 or 1 = dense */
 } foley_gemm_desc;
 
 int foley_op_gemm(const foley_gemm_desc* d, void* stream);

@@ -404,6 +404,44 @@ def dac_decode(sd: SD, z: Tensor, rates: Sequence[int] = (8, 5, 4, 3, 2),
     return torch.tanh(x)
 
 
+def dac_preprocess(audio: Tensor, hop: int) -> Tensor:
+    """DAC.preprocess (dac.py:225-234): right-pad the waveform to a multiple of the hop."""
+    T = audio.shape[-1]
+    return F.pad(audio, (0, math.ceil(T / hop) * hop - T))
+
+
+def dac_encode(sd: SD, audio: Tensor, rates: Sequence[int] = (2, 3, 4, 5, 8),
+               dilations: Sequence[int] = (1, 3, 9)) -> Tensor:
+    """DAC.encode, continuous=True (dac.py:236-278): audio [B,1,T] (T a multiple of the hop) ->
+    posterior parameters [B, 2*latent, T/hop] = quant_conv(encoder(audio)); rows [:latent] are the
+    mean, rows [latent:] the log-variance of the DiagonalGaussianDistribution (vae_utils.py:24-31).
+    Encoder (dac.py:47-95): conv7 -> per rate s {3 residual units (dil 1/3/9) -> snake -> conv k=2s,
+    stride s, pad ceil(s/2), doubling the channels} -> snake -> conv3 to the latent width."""
+    x = F.conv1d(audio, _wn_weight(sd, "encoder.block.0"), sd["encoder.block.0.bias"], padding=3)
+    for i, s in enumerate(rates):
+        p = f"encoder.block.{i + 1}.block."
+        for j, d in enumerate(dilations):                                               # dac.py:28-44
+            q = p + f"{j}.block."
+            y = snake(x, sd[q + "0.alpha"])
+            y = F.conv1d(y, _wn_weight(sd, q + "1"), sd[q + "1.bias"], dilation=d, padding=3 * d)
+            y = snake(y, sd[q + "2.alpha"])
+            y = F.conv1d(y, _wn_weight(sd, q + "3"), sd[q + "3.bias"])
+            x = x + y
+        x = snake(x, sd[p + "3.alpha"])
+        x = F.conv1d(x, _wn_weight(sd, p + "4"), sd[p + "4.bias"], stride=s, padding=math.ceil(s / 2))
+    n = len(rates)
+    x = snake(x, sd[f"encoder.block.{n + 1}.alpha"])
+    x = F.conv1d(x, _wn_weight(sd, f"encoder.block.{n + 2}"), sd[f"encoder.block.{n + 2}.bias"], padding=1)
+    return F.conv1d(x, sd["quant_conv.weight"], sd["quant_conv.bias"])                  # :274
+
+
+def gaussian_posterior(params: Tensor):
+    """DiagonalGaussianDistribution (vae_utils.py:24-31): (mean, std) with logvar clamped to [-30, 20];
+    mode() = mean, sample() = mean + std * N(0, 1)."""
+    mean, logvar = torch.chunk(params, 2, dim=1)
+    return mean, torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
+
+
 # =============================================================================
 # Sampler  (/utils.py:125-258)
 # =============================================================================

@@ -423,7 +423,39 @@ def g9():
     save("g9_dac", z=z, y=y)
 
 
-ALL = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9}
+# ----------------------------------------------------------------------------- G10
+def g10():
+    """DAC encoder half (row N4): narrow codec (32 -> 64 -> 128 channels, rates (2,3), odd stride
+    included) on ragged-length audio through preprocess + encode, the posterior's mean / std, and the
+    real 128 -> 4096-channel encoder on two latent frames of audio."""
+    out = {}
+    for tag, dc, n_samp in (("tiny", C.DAC_ENC_TINY, 6 * 17 - 4), ("full", C.DAC48K, 960 * 2)):
+        dsd = synth.synth_dac_state_dict(dc, encoder=True)
+        m = NS.dac.DAC(encoder_dim=dc.encoder_dim, encoder_rates=list(dc.encoder_rates), latent_dim=dc.latent_dim,
+                       decoder_dim=dc.decoder_dim, decoder_rates=list(dc.rates), n_codebooks=9, codebook_size=1024,
+                       codebook_dim=8, quantizer_dropout=False, sample_rate=dc.sample_rate, continuous=True)
+        missing, unexpected = m.load_state_dict(dsd, strict=False)
+        assert not unexpected and all(k.startswith("quantizer") for k in missing), (missing[:5], unexpected[:5])
+        g = torch.Generator().manual_seed(10)
+        audio = 0.5 * torch.randn(2 if tag == "tiny" else 1, 1, n_samp, generator=g)
+        with torch.inference_mode():
+            a = m.preprocess(audio, dc.sample_rate)
+            post = m.encode(a)[0]
+        hop = 1
+        for r in dc.encoder_rates:
+            hop *= r
+        assert m.hop_length == hop
+        ap = O.dac_preprocess(audio, hop)
+        check(f"dac preprocess {tag}", ap, a)
+        check(f"dac encode {tag}", O.dac_encode(dsd, ap, dc.encoder_rates), post.parameters)
+        mean, std = O.gaussian_posterior(post.parameters)
+        check(f"posterior mean {tag}", mean, post.mode())
+        check(f"posterior std {tag}", std, post.std)
+        out[tag + "_audio"], out[tag + "_params"], out[tag + "_std"] = audio, post.parameters, post.std
+    save("g10_dac_encode", **out)
+
+
+ALL = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10}
 
 
 def main():

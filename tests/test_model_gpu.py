@@ -149,6 +149,35 @@ def test_dac_golden_full_width(dev):
         assert rel_err(y3[i:i + 1], model.ctx.dac_decode(z3[i:i + 1].contiguous())) < 1e-6
 
 
+def test_dac_encoder_golden(dev):
+    """G10: DAC.encode on the HIP engine vs the reference - narrow codec on ragged-length
+    audio (right-padded to the hop like DAC.preprocess) and the real 128 -> 4096-channel encoder; then
+    decode(encode(x).mode()) keeps the waveform length (codec round trip through both halves)."""
+    g = golden("g10_dac_encode")
+    for tag, dc in (("tiny", C.DAC_ENC_TINY), ("full", C.DAC48K)):
+        dsd = synth.synth_dac_state_dict(dc, device=dev, encoder=True)
+        model = sampler.FoleyModel(C.TINY, synth.synth_dit_state_dict(C.TINY), torch.float32, dev, dac_cfg=dc)
+        dac = sampler.FoleyDAC(dsd, dev, dc)
+        assert dac.has_encoder
+        model.attach_dac(dac)
+        params = model.ctx.dac_encode(g[tag + "_audio"].to(dev))
+        assert params.shape == g[tag + "_params"].shape
+        assert rel_err(params, g[tag + "_params"]) < 2e-5, tag
+        mean, std = O.gaussian_posterior(params.cpu())
+        assert rel_err(std, g[tag + "_std"]) < 2e-5
+        if dc.latent_dim == C.TINY.latent_dim:      # the decoder of this context consumes latent_dim-wide codes
+            wave = model.ctx.dac_decode(mean.to(dev).contiguous())
+            assert wave.shape == (params.shape[0], 1, params.shape[2] * dc.hop) and bool(torch.isfinite(wave).all())
+    # batch of clips == independent clips (segment handling of the strided convs)
+    a3 = 0.3 * torch.randn(3, 1, 6 * 11, generator=torch.Generator().manual_seed(3))
+    dc = C.DAC_ENC_TINY
+    model = sampler.FoleyModel(C.TINY, synth.synth_dit_state_dict(C.TINY), torch.float32, dev, dac_cfg=dc)
+    model.attach_dac(sampler.FoleyDAC(synth.synth_dac_state_dict(dc, device=dev, encoder=True), dev, dc))
+    p3 = model.ctx.dac_encode(a3.to(dev))
+    for i in range(3):
+        assert rel_err(model.ctx.dac_encode(a3[i:i + 1].to(dev)), p3[i:i + 1]) < 1e-6
+
+
 def test_batch_equals_independent_clips(tiny):
     """Clips in a batch are independent: bs=3 must equal three bs=1 runs."""
     sd, _dsd, model, dac = tiny

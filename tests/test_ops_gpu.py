@@ -200,6 +200,23 @@ def test_conv3_channels_last(dev, dtype, tile, B, L, Cin, Cout):
     assert rel_err(out, ref) < _tol(dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("stride,B,Tin,Cin,Cout", [(2, 2, 60, 64, 128), (3, 1, 51, 32, 64), (5, 2, 40, 128, 96), (8, 1, 64, 64, 128)])
+def test_strided_conv_as_gemm(dev, dtype, stride, B, Tin, Cin, Cout):
+    """DAC EncoderBlock down-sampling conv (dac.py:55-61): k = 2s, stride s, pad ceil(s/2), as a GEMM
+    whose virtual rows advance s source rows (zero padding through the operand range check)."""
+    if dtype == torch.bfloat16 and Cin % 64:
+        pytest.skip("bf16 K-slices are 64 channels wide")
+    x, w, b = _rand((B, Cin, Tin), 40), _rand((Cout, Cin, 2 * stride), 41, 1 / math.sqrt(2 * stride * Cin)), _rand((Cout,), 42, 0.1)
+    ref = F.conv1d(_q(x, dtype), _q(w, dtype), b, stride=stride, padding=math.ceil(stride / 2)).transpose(1, 2)
+    Tout = Tin // stride
+    assert ref.shape[1] == Tout
+    xs = x.transpose(1, 2).contiguous().to(dev, dtype)                   # [B, Tin, Cin] time-major
+    out = torch.full((B * Tout, Cout), float("nan"), device=dev)
+    rt.op_gemm(xs, packers.conv_to_gemm(w).to(dev, dtype), b.to(dev), out0=out, sconv=(Tin, Cin, stride))
+    assert rel_err(out.view(B, Tout, Cout), ref) < _tol(dtype)
+
+
 @pytest.mark.parametrize("dil", [1, 3, 9])
 @pytest.mark.parametrize("B,T,C", [(2, 100, 64), (1, 37, 128)])
 def test_dac_conv7_snake(dev, dil, B, T, C):

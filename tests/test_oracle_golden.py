@@ -132,3 +132,22 @@ def test_g8_fp8_weight_only_semantics():
         changed = {k for k in sd if not torch.equal(sd[k], sdq[k])}
         assert changed == {k + ".weight" for k in wrapped} | {"time_in.mlp.0.bias"}
         assert torch.equal(sdq["time_in.mlp.0.bias"], rq(sd["time_in.mlp.0.bias"]))
+
+
+def test_g10_dac_encoder():
+    """DAC encoder half (dac.py:47-95, 225-278) + posterior (vae_utils.py:24-31): narrow codec on
+    ragged-length audio and the real 4096-channel encoder on two latent frames."""
+    g = golden("g10_dac_encode")
+    for tag, dc in (("tiny", C.DAC_ENC_TINY), ("full", C.DAC48K)):
+        dsd = synth.synth_dac_state_dict(dc, encoder=True)
+        hop = 1
+        for r in dc.encoder_rates:
+            hop *= r
+        a = O.dac_preprocess(g[tag + "_audio"], hop)
+        assert a.shape[-1] % hop == 0 and a.shape[-1] - g[tag + "_audio"].shape[-1] < hop
+        with torch.inference_mode():
+            params = O.dac_encode(dsd, a, dc.encoder_rates)
+        assert params.shape == g[tag + "_params"].shape == (a.shape[0], 2 * dc.latent_dim, a.shape[-1] // hop)
+        assert rel_err(params, g[tag + "_params"]) < 1e-5
+        mean, std = O.gaussian_posterior(params)
+        assert torch.equal(mean, params[:, :dc.latent_dim]) and rel_err(std, g[tag + "_std"]) < 1e-5

@@ -20,6 +20,7 @@ ap.add_argument("--precision", default="bf16")
 ap.add_argument("--model", default="xxl")
 ap.add_argument("--graph", action="store_true")
 ap.add_argument("--no-dac", action="store_true")
+ap.add_argument("--encode", action="store_true", help="also time the DAC encoder on the decoded waveform (codec round trip)")
 ap.add_argument("--duration", type=float, default=5.0)
 ap.add_argument("--phases", action="store_true", help="sum workgroup-0 prologue / K-loop / epilogue time over all GEMM launches of the loop (eager)")
 a = ap.parse_args()
@@ -31,7 +32,7 @@ cond = synth.synth_conditioning(cfg, a.duration, t2a=True, sd=sd, device=dev)
 LA = int(a.duration * 50)
 model = sampler.FoleyModel(cfg, sd, dtype, dev)
 del sd
-dac = sampler.FoleyDAC(synth.synth_dac_state_dict(C.DAC48K, device=dev), dev)
+dac = sampler.FoleyDAC(synth.synth_dac_state_dict(C.DAC48K, device=dev, encoder=a.encode), dev)
 model.attach_dac(dac)
 plan = sampler.build_plan(model, {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]},
                           {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]}, LA, 4.5, a.iters,
@@ -58,6 +59,11 @@ if a.phases:
           f"K loop {d[1] / 100 / a.iters:.0f} us, epilogue {d[2] / 100 / a.iters:.0f} us (workgroup 0 of each launch)")
 print("loop ms/iter:", model.ctx.last_elapsed_ms() / a.iters)
 if not a.no_dac:
-    model.ctx.dac_decode(lat)
+    wave = model.ctx.dac_decode(lat)
     torch.cuda.synchronize()
     print("dac ms:", model.ctx.last_elapsed_ms())
+    if a.encode:
+        for _ in range(2):
+            params = model.ctx.dac_encode(wave)
+            torch.cuda.synchronize()
+        print("dac encode ms:", model.ctx.last_elapsed_ms(), tuple(params.shape))
