@@ -285,6 +285,13 @@ def test_full_size_properties(dev):
     assert rel_err(f32b[1], f32[0]) < 1e-5                                       # (1) fp32: batch row == single clip
     print("bf16 single-vs-batch %.2e, bf16-vs-fp32 %.2e, fp32 single-vs-batch %.2e" %
           (rel_err(s1[0], b3[0]), rel_err(s1, f32), rel_err(f32b[1], f32[0])))
+    # (5) the bs=8 configuration (256x128 tiles, wide attention kernel, no K split): every clip of the
+    #     batch against its own single-clip run
+    n8 = torch.randn(8, 128, La, generator=torch.Generator().manual_seed(13))
+    b8 = run(n8, 4.5, True)
+    errs = [rel_err(b8[i], run(n8[i:i + 1], 4.5, True)[0]) for i in (0, 3, 7)]
+    print("bs=8 rows vs single-clip runs:", ["%.2e" % e for e in errs])
+    assert max(errs) < 5e-2
 
 
 def test_xl_dimensions_forward(dev):
