@@ -331,13 +331,39 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&ac
       for (int w = 0; w < 4; ++w) { bias[u + w] = bv[w]; gain[u + w] = gv[w]; }
     }
     const int* pos = q.pos[o];
+    // rotation angles of every pass are fetched up front (two dependent global loads each: position,
+    // then table row) - left inside the pass loop they serialise behind the stores of the previous pass
+    int pb[PASSES], pl[PASSES];
+    float cs[PASSES][CP / 2], sn[PASSES][CP / 2];
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int row = m0 + p * RP + tr;
+      const int rr = row < g.M ? row : g.M - 1;
+      pb[p] = rr / q.L;
+      pl[p] = rr - pb[p] * q.L;
+    }
+    if (pos) {
+      long pp[PASSES];
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) pp[p] = (long)pos[pl[p]] * 64 + (tc >> 1);
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) {
+        if constexpr (CP == 8) {
+          const f32x4 c4 = *(const f32x4*)(q.cos_tab + pp[p]), s4 = *(const f32x4*)(q.sin_tab + pp[p]);
+#pragma unroll
+          for (int w = 0; w < 4; ++w) { cs[p][w] = c4[w]; sn[p][w] = s4[w]; }
+        } else {
+          cs[p][0] = q.cos_tab[pp[p]]; cs[p][1] = q.cos_tab[pp[p] + 1];
+          sn[p][0] = q.sin_tab[pp[p]]; sn[p][1] = q.sin_tab[pp[p] + 1];
+        }
+      }
+    }
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int rl = p * RP + tr;
       const int row = m0 + rl;
       const bool ok = row < g.M;
-      const int rr = ok ? row : g.M - 1;
-      const int b = rr / q.L, l = rr - b * q.L;
+      const int b = pb[p], l = pl[p];
       float v[CP];
 #pragma unroll
       for (int u = 0; u < CP; u += 4) {
@@ -349,28 +375,19 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&ac
         float ss = 0.f;
 #pragma unroll
         for (int u = 0; u < CP; ++u) ss += v[u] * v[u];
-#pragma unroll
-        for (int off = 1; off < TPR; off <<= 1) ss += __shfl_xor(ss, off);
+        ss = row16_sum(ss);                                   // TPR is 16 (bf16) or 32 (fp32) lanes per row
+        if constexpr (TPR == 32) ss += __shfl_xor(ss, 16);
+        static_assert(TPR == 16 || TPR == 32, "head-split epilogue: 16 or 32 lanes per row");
         const float rinv = rsqrtf(ss * (1.0f / 128.0f) + q.eps);
 #pragma unroll
         for (int u = 0; u < CP; ++u) v[u] = v[u] * rinv * gain[u];
       }
       if (pos) {
-        const long pp = (long)pos[l] * 64 + (tc >> 1);
-        float cs[CP / 2], sn[CP / 2];
-        if constexpr (CP == 8) {
-          const f32x4 c4 = *(const f32x4*)(q.cos_tab + pp), s4 = *(const f32x4*)(q.sin_tab + pp);
-#pragma unroll
-          for (int w = 0; w < 4; ++w) { cs[w] = c4[w]; sn[w] = s4[w]; }
-        } else {
-          cs[0] = q.cos_tab[pp]; cs[1] = q.cos_tab[pp + 1];
-          sn[0] = q.sin_tab[pp]; sn[1] = q.sin_tab[pp + 1];
-        }
 #pragma unroll
         for (int w = 0; w < CP / 2; ++w) {
           const float y0 = v[2 * w], y1 = v[2 * w + 1];
-          v[2 * w] = y0 * cs[w] - y1 * sn[w];
-          v[2 * w + 1] = y1 * cs[w] + y0 * sn[w];
+          v[2 * w] = y0 * cs[p][w] - y1 * sn[p][w];
+          v[2 * w + 1] = y1 * cs[p][w] + y0 * sn[p][w];
         }
       }
       if (ok) VecStore<T>::store((T*)q.dst[o] + (((long)b * q.H + h) * q.S_tot + q.tok_off + l) * 128 + tc, v);

@@ -27,6 +27,7 @@ ap.add_argument("--tile", default="5", help="comma list")
 ap.add_argument("--ksplit", default="0", help="comma list; 0 = plain fp32 store epilogue")
 ap.add_argument("--partials", action="store_true", help="deferred split-K (partial slabs) instead of atomics")
 ap.add_argument("--brief", action="store_true")
+ap.add_argument("--fused-qkv", action="store_true", help="fused head-split epilogue (shape qkv: 3 x 12 heads, clips of 250 tokens)")
 ap.add_argument("--ablate", type=int, default=0, help="debug bits: 1 no MFMA, 2 no fragment reads, 4 no global->LDS loads (glds kernels)")
 ap.add_argument("--conv", action="store_true")
 ap.add_argument("--warm", action="store_true", help="measure with the weight matrix just used (L2 / Infinity-Cache warm)")
@@ -46,8 +47,24 @@ gate = torch.randn(N, device=dev)
 slabs = torch.empty(16, a.m, N, device=dev) if a.partials else None
 
 
+qkv_desc = None
+if a.fused_qkv:
+    from foley_amd.host import tables
+    Hh, Lq = N // 384, 250
+    clips_q = a.m // Lq
+    dq, dk = (torch.zeros(clips_q, Hh, Lq, 128, device=dev, dtype=torch.bfloat16) for _ in range(2))
+    dvt = torch.zeros(clips_q, Hh, 128, 256, device=dev, dtype=torch.bfloat16)
+    cos_t, sin_t = tables.rope_table(Lq + 1)
+    gq = torch.ones(128, device=dev)
+    posq = torch.arange(Lq, dtype=torch.int32, device=dev)
+    qkv_desc = rt.qkv_split_desc(Lq, Hh, [gq, gq, None], [posq, posq, None], [dq, dk, dvt], Lq, 0, 1e-6, cos_t.to(dev), sin_t.to(dev),
+                                 vt_pitch=256)
+
+
 def run(W, tile, ksplit):
-    if ksplit:
+    if qkv_desc is not None:
+        rt.op_gemm(A, W, None, epilogue=rt.EPI_QKV_SPLIT, qkv=qkv_desc, tile=tile)
+    elif ksplit:
         rt.op_gemm(A, W, None, out0=x, tile=tile, epilogue=rt.EPI_GATE_RES, rb=rt.rowbcast(gate, 0), ksplit=ksplit,
                    partials=slabs, **ckw)
     else:
