@@ -1,20 +1,31 @@
 """Headline benchmark: audio-seconds generated per wall-second for the Foley sampling path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--bs B] [--precision bf16|fp32]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5] [--bs B] [--precision bf16|fp32]
 
-A "step" is ONE pass of the whole hot path over one batch of synthetic input: step-invariant
-precompute + 50-iteration Euler/CFG loop over the xxl DiT + DAC-VAE 48 kHz decode of `bs` clips
-of 5 s (BASELINE.json configs[1]: T2A 5 s, 50 steps, CFG 4.5, bf16, hunyuanvideo-foley-xxl).
-Inputs (noise, conditioning, weights) are resident in HBM when the timed region starts.  With
-N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL) every rank processes its
-own `bs` clips (weak scaling) after ONE broadcast of the packed weight arena; value is the
-whole-job aggregate.  Rank 0 prints one JSON line.
+A "step" is ONE pass of the whole hot path over one batch of synthetic input, host to host: H2D of
+the CPU-generator noise, step-invariant precompute, the 50-iteration Euler/CFG loop over the xxl
+DiT, the DAC-VAE 48 kHz decode of `bs` clips and the D2H of the waveform.  Weights and
+conditioning are resident in HBM when the timed region starts.
+
+Configurations (BASELINE.json `configs`):
+  c2 (default)  T2A 5 s, 50 Euler steps, CFG 4.5, bf16, hunyuanvideo-foley-xxl        - the headline metric
+  c3            V2A: same shapes, non-empty SigLIP2 / Synchformer stand-in features (seed 2)
+  c5            fp8_e4m3fn weight storage, 30 s clip, negative-prompt CFG
+
+Multi-GPU: `python bench.py --gpus N` SPAWNS its own N ranks (one process per GPU, RCCL) when it
+is not already running under a launcher; under `torch.distributed.run` (RANK / WORLD_SIZE set) it
+joins that job instead.  Clips are independent, so every rank processes its own `bs` clips (weak
+scaling) after ONE broadcast of the bundle [DiT arena | DAC arena | conditioning]
+(host/distributed.py); value is the whole-job aggregate.  Rank 0 prints one JSON line.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,7 +33,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-from __graft_entry__ import load_package  # noqa: E402
+from __graft_entry__ import PKG_DIR, load_package  # noqa: E402
 
 load_package()
 from foley_amd.host import config as C  # noqa: E402
@@ -30,7 +41,16 @@ from foley_amd.host import distributed as D  # noqa: E402
 from foley_amd.host import packers, sampler, synth  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
-DURATION_S, STEPS_PER_CLIP, GUIDANCE = 5.0, 50, 4.5
+PEAK_HBM_GBS = 8000.0
+STEPS_PER_CLIP, GUIDANCE = 50, 4.5
+CONFIGS = {
+    "c2": dict(duration=5.0, t2a=True, quantization="none",
+               desc="T2A 5 s, 50 Euler steps, CFG 4.5"),
+    "c3": dict(duration=5.0, t2a=False, quantization="none",
+               desc="V2A 5 s @ 8 fps (SigLIP2 + Synchformer stand-in features), 50 Euler steps, CFG 4.5"),
+    "c5": dict(duration=30.0, t2a=True, quantization="fp8_e4m3fn",
+               desc="fp8_e4m3fn weight storage, 30 s long-form, negative-prompt CFG 4.5, 50 Euler steps"),
+}
 
 
 def flops_forward(cfg: C.DiTConfig, la: int, lv: int, ls: int, lt: int = 77) -> float:
@@ -48,7 +68,18 @@ def flops_clip(cfg: C.DiTConfig, duration: float, steps: int, guidance: float) -
     return steps * (2 if guidance > 1.0 else 1) * flops_forward(cfg, la, lv, ls) + 2.30933e9 * la
 
 
-def cpu_baseline(sd_gpu, dsd_gpu, cfg, cond, noise, threads=16):
+def kernel_src_sha() -> str:
+    """Identity of the kernel sources a counter pass was taken on (profiles/*_pmc_traffic.json)."""
+    h = hashlib.sha256()
+    d = os.path.join(PKG_DIR, "csrc")
+    for n in sorted(os.listdir(d)):
+        if n.endswith((".hip", ".h")):
+            h.update(n.encode())
+            h.update(open(os.path.join(d, n), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(sd_gpu, dsd_gpu, cfg, cond, noise, duration, threads=16):
     """The CPU oracle (a port of the reference's fp32 CPU path) on this box's host cores, on a
     bounded sample of the same workload: three DiT forwards of the conditional half (the loop does
     2 x 50 of them per clip) + the DAC decode, extrapolated.  Thread count is capped: the torch
@@ -76,132 +107,278 @@ def cpu_baseline(sd_gpu, dsd_gpu, cfg, cond, noise, threads=16):
         O.dac_decode(dsd, x - v)
         t_dec = time.perf_counter() - t0
     t_clip = n_fwd * t_fwd + t_dec
-    return {"value": DURATION_S / t_clip, "unit": "audio-sec/sec", "cores": cores, "kind": "port",
+    return {"value": duration / t_clip, "unit": "audio-sec/sec", "cores": cores, "kind": "port",
             "sample": f"{n_sample} of {n_fwd} DiT forwards ({t_fwd:.2f}s each, fp32 torch-CPU oracle, {cores} threads of "
-                      f"{avail} available) + the DAC decode ({t_dec:.2f}s) of the same 5 s clip, extrapolated"}
+                      f"{avail} available) + the DAC decode ({t_dec:.2f}s) of the same {duration:g} s clip, extrapolated"}
 
 
-def main():
+# ----------------------------------------------------------------------------- self-launch
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n: int, argv) -> int:
+    """Run this script as `n` ranks of one job (LOCAL_RANK = RANK, rendezvous on 127.0.0.1).  Rank 0
+    inherits stdout (its JSON line is this process's output); the first failing rank ends the job."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FOLEY_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                for q in alive:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc
+
+
+# ----------------------------------------------------------------------------- one rank
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--bs", type=int, default=1, help="clips per GPU per step")
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--bs", type=int, default=None, help="clips per GPU per step (default 1, plus an extra bs=8 measurement)")
+    ap.add_argument("--duration", type=float, default=None)
+    ap.add_argument("--quantization", default=None, choices=["none", "fp8_e4m3fn", "fp8_e5m2"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--model", default="xxl", choices=["xxl", "xl", "tiny"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    a = ap.parse_args()
+    ap.add_argument("--no-extra", action="store_true", help="skip the per-kernel profile pass and the bs=8 measurement")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--dry-run", action="store_true",
+                    help="setup only (pack, the single broadcast, sharding) on CPU tensors - no HIP work; used by the gloo tests")
+    return ap.parse_args(argv)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    use_dist = world > 1 or ("RANK" in os.environ and os.environ.get("FOLEY_BENCH_FORCE_DIST"))
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse_args(argv)
+    if a.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        return 2
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not launched and a.gpus > 1:
+        if not a.dry_run and torch.cuda.device_count() < a.gpus:
+            print(f"bench.py: --gpus {a.gpus} but only {torch.cuda.device_count()} HIP device(s) are visible",
+                  file=sys.stderr)
+            return 2
+        return spawn_ranks(a.gpus, argv)
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
+    rank = int(os.environ.get("RANK", "0")) if launched else 0
+    local = int(os.environ.get("LOCAL_RANK", "0")) if launched else 0
+    if a.gpus != world:
+        print(f"bench.py: --gpus {a.gpus} does not match the launcher's WORLD_SIZE={world}", file=sys.stderr)
+        return 2
+    return run_rank(a, world, rank, local, launched)
+
+
+def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
+    import torch.distributed as dist
+    conf = dict(CONFIGS[a.config])
+    if a.duration is not None:
+        conf["duration"] = a.duration
+    if a.quantization is not None:
+        conf["quantization"] = a.quantization
+    duration, quant = conf["duration"], conf["quantization"]
+    use_dist = world > 1 or (launched and bool(os.environ.get("FOLEY_BENCH_FORCE_DIST")))
+    on_gpu = not a.dry_run
+    dev = torch.device("cuda", local) if on_gpu else torch.device("cpu")
+    if on_gpu:
+        torch.cuda.set_device(dev)
     if use_dist:
-        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
     cfg = C.dit_config(a.model)
+    dac_cfg = C.DAC48K if a.model != "tiny" else C.DAC_TINY
     dtype = packers.torch_dtype(a.precision)
+    if quant != "none" and dtype == torch.float32:
+        print("bench.py: fp8 weight storage needs bf16 compute (the reference cannot run it in fp32 either)", file=sys.stderr)
+        return 2
 
-    # ---- setup (untimed): rank 0 synthesises + packs, ONE broadcast ships the arena
+    # ---- setup (untimed): rank 0 synthesises + packs INTO the bundle, ONE broadcast ships it
+    spec = D.bundle_spec(cfg, dac_cfg, dtype, duration)
+    bundle = D.Bundle(spec, dev)
     sd = dsd = None
     if rank == 0:
+        from foley_amd import nodes
         sd = synth.synth_dit_state_dict(cfg, device=dev)
-        dsd = synth.synth_dac_state_dict(C.DAC48K, device=dev)
-        cond = synth.synth_conditioning(cfg, DURATION_S, t2a=True, sd=sd, device=dev)
-        dit_arena = packers.Arena.from_packed(packers.pack_dit(sd, cfg, dtype), dev)
-        dac_arena = packers.Arena.from_packed(packers.pack_dac(dsd, C.DAC48K), dev)
-    else:
-        cond = dit_arena = dac_arena = None
-    if use_dist:
-        dit_arena = D.broadcast_arena(dit_arena, dev)
-        dac_arena = D.broadcast_arena(dac_arena, dev)
-        cond = D.broadcast_tensors(cond, dev)
-    model = sampler.FoleyModel.from_arena(cfg, dit_arena, dtype, dev)
-    dac = sampler.FoleyDAC.from_arena(dac_arena, dev)
+        dsd = synth.synth_dac_state_dict(dac_cfg, device=dev)
+        cond = synth.synth_conditioning(cfg, duration, t2a=conf["t2a"], sd=sd, device=dev, seed=1)
+        sdq = nodes.fp8_round_state_dict(sd, quant, autocast=True, param_dtype=dtype) if quant != "none" else sd
+        bundle.fill(packers.pack_dit(sdq, cfg, dtype), packers.pack_dac(dsd, dac_cfg), cond)
+        del sdq
+    bcast_s = D.broadcast_bundle(bundle) if use_dist else 0.0
+    cond = {k: v.clone() for k, v in bundle.cond_views().items()}
+    la = int(duration * cfg.frame_rate)
+    bs_main = a.bs or 1
+    gen = torch.Generator("cpu").manual_seed(1234)
+    noise_all = sampler.draw_noise(world * bs_main, cfg.latent_dim, la, dtype, gen)     # same on every rank
+    lo, hi = D.shard_range(world * bs_main, rank, world)
+
+    if a.dry_run:
+        # the collective plumbing only (CPU tests): every rank checks what it received against a local re-synthesis
+        ref_sd = synth.synth_dit_state_dict(cfg)
+        ok = all(torch.equal(bundle.dit_arena().view(k), v) for k, v in packers.pack_dit(ref_sd, cfg, dtype).items())
+        ok = ok and all(torch.equal(bundle.dac_arena().view(k), v)
+                        for k, v in packers.pack_dac(synth.synth_dac_state_dict(dac_cfg), dac_cfg).items())
+        cref = synth.synth_conditioning(cfg, duration, t2a=conf["t2a"], sd=ref_sd, seed=1)
+        ok = ok and torch.equal(cond["clip"], cref["clip"]) and torch.equal(cond["sync"], cref["sync"])
+        ok = ok and torch.equal(cond["text"][:, :cref["text"].shape[1]], cref["text"])
+        rec = {"rank": rank, "ok": bool(ok), "shard": [lo, hi], "noise_sum": float(noise_all[lo:hi].double().sum())}
+        recs = [None] * world
+        if use_dist:
+            dist.all_gather_object(recs, rec)
+        else:
+            recs = [rec]
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "backend": a.backend if use_dist else None,
+                              "collectives": 1 if use_dist else 0, "broadcast_s": bcast_s, "bundle_bytes": spec.total,
+                              "ranks": recs, "noise_total": float(noise_all.double().sum())}), flush=True)
+        if use_dist:
+            dist.destroy_process_group()
+        return 0 if ok else 1
+
+    model = sampler.FoleyModel.from_arena(cfg, bundle.dit_arena(), dtype, dev, dac_cfg=dac_cfg, quantization=quant)
+    dac = sampler.FoleyDAC.from_arena(bundle.dac_arena(), dev, dac_cfg)
     visual = {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]}
     text = {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]}
-    la = int(DURATION_S * cfg.frame_rate)
-    gen = torch.Generator("cpu").manual_seed(1234)
-    noise_all = sampler.draw_noise(world * a.bs, cfg.latent_dim, la, dtype, gen)     # same on every rank
-    lo, hi = D.shard_range(world * a.bs, rank, world)
-    noise = noise_all[lo:hi].to(dev)
-
-    def one_pass():
-        audio, _sr = sampler.denoise_process_with_generator(
-            visual, text, DURATION_S, model, dac, GUIDANCE, STEPS_PER_CLIP, a.bs, "euler", noise=noise,
-            use_graph=not a.no_graph)
-        return audio
+    graph = not a.no_graph
 
     def barrier():
         torch.cuda.synchronize()
         if use_dist:
-            torch.distributed.barrier()
+            dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        one_pass()
-    barrier()
-    t0 = time.perf_counter()
-    ev_ms = 0.0
-    for _ in range(a.steps):
-        audio = one_pass()
-        # HIP-event time of the device-resident loop / decoder, recorded on the launch stream by the library
-    barrier()
-    dt = time.perf_counter() - t0
-    # event-timed sampler loop of the last pass (prepare + decode excluded) for the roofline object
-    model.ctx.sample(noise.float().clone(), use_graph=not a.no_graph)
-    torch.cuda.synchronize()
-    loop_ms = model.ctx.last_elapsed_ms()
-    model.ctx.dac_decode(torch.zeros(a.bs, cfg.latent_dim, la, device=dev))
-    torch.cuda.synchronize()
-    dac_ms = model.ctx.last_elapsed_ms()
-    if use_dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    assert audio.shape == (a.bs, 1, la * 960) and bool(torch.isfinite(audio).all())
+    def measure(bs: int, noise_cpu: torch.Tensor, steps: int, warmup: int):
+        """Host-to-host passes: pinned CPU noise in, CPU waveform out."""
+        noise_cpu = noise_cpu.pin_memory()
+
+        def one_pass():
+            audio, _sr = sampler.denoise_process_with_generator(
+                visual, text, duration, model, dac, GUIDANCE, STEPS_PER_CLIP, bs, "euler",
+                noise=noise_cpu.to(dev, non_blocking=True), use_graph=graph)
+            return audio.cpu()
+
+        for _ in range(warmup):
+            one_pass()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            audio = one_pass()
+        barrier()
+        dt = time.perf_counter() - t0
+        # event-timed pieces of one more pass (loop / decode; recorded by the library on the launch stream)
+        lat = noise_cpu.to(dev).float().contiguous()
+        model.ctx.sample(lat, use_graph=graph)
+        torch.cuda.synchronize()
+        loop_ms = model.ctx.last_elapsed_ms()
+        model.ctx.dac_decode(lat)
+        torch.cuda.synchronize()
+        dac_ms = model.ctx.last_elapsed_ms()
+        if use_dist:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        assert audio.shape == (bs, 1, la * dac_cfg.hop) and bool(torch.isfinite(audio).all())
+        return dt, loop_ms, dac_ms
+
+    dt, loop_ms, dac_ms = measure(bs_main, noise_all[lo:hi], a.steps, a.warmup)
+    f_clip = flops_clip(cfg, duration, STEPS_PER_CLIP, GUIDANCE)
+    f_loop = f_clip - 2.30933e9 * la
+    peak = PEAK_TFLOPS[a.precision]
+
+    # ---- per-kernel profile (HIP-event brackets around every launch of an eager forward, mid-loop iteration)
+    kernels, bracket_us = [], None
+    if not a.no_extra:
+        lat = noise_all[lo:hi].to(dev).float().contiguous()
+        prof, bracket_us = model.ctx.profile_forward(lat, it=STEPS_PER_CLIP // 2, repeats=2)
+        for e in prof:
+            tf = e["flop_per_launch"] / (e["avg_us"] * 1e-6) / 1e12 if e["avg_us"] > 0 else 0.0
+            gbs = e["bytes_per_launch"] / (e["avg_us"] * 1e-6) / 1e9 if e["avg_us"] > 0 else 0.0
+            kernels.append({"name": e["label"], "calls_per_iteration": e["calls_per_forward"],
+                            "avg_us": round(e["avg_us"], 2), "us_per_iteration": round(e["avg_us"] * e["calls_per_forward"], 1),
+                            "gflop_per_launch": round(e["flop_per_launch"] / 1e9, 3),
+                            "mbytes_per_launch": round(e["bytes_per_launch"] / 1e6, 3),
+                            "tflops": round(tf, 1), "frac": round(tf / peak, 4), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4)})
+        kernels.sort(key=lambda k: -k["us_per_iteration"])
+
+    # ---- the bs=8-per-GPU half of the BASELINE metric, same JSON line
+    extra = {}
+    if not a.no_extra and a.bs is None and a.config == "c2":
+        gen8 = torch.Generator("cpu").manual_seed(1234)
+        n8 = sampler.draw_noise(world * 8, cfg.latent_dim, la, dtype, gen8)
+        lo8, hi8 = D.shard_range(world * 8, rank, world)
+        dt8, loop8, dac8 = measure(8, n8[lo8:hi8], 2, 1)
+        extra["bs8"] = {"value": world * 8 * 2 * duration / dt8, "unit": "audio-sec/sec", "clips_per_gpu": 8, "steps": 2,
+                        "warmup": 1, "ms_per_step": 1e3 * dt8 / 2, "loop_ms": loop8, "dac_decode_ms": dac8,
+                        "loop_frac": 8 * f_loop / (loop8 * 1e-3) / 1e12 / peak}
 
     if rank == 0:
-        clips = world * a.bs * a.steps
-        f_clip = flops_clip(cfg, DURATION_S, STEPS_PER_CLIP, GUIDANCE)
-        f_loop = f_clip - 2.30933e9 * la
-        peak = PEAK_TFLOPS[a.precision]
-        ach = a.bs * f_loop / (loop_ms * 1e-3) / 1e12
-        traffic = None   # PMC counters cannot be read live; the committed rocprofv3 --pmc passes give it
+        clips = world * bs_main * a.steps
+        loop_tf = bs_main * f_loop / (loop_ms * 1e-3) / 1e12
+        traffic, traffic_src = None, None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if a.bs == 1 and a.precision == "bf16" and a.model == "xxl":
-                traffic = tj["hbm_bytes_per_loop_iteration"] * STEPS_PER_CLIP
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+            if tj.get("kernel_src_sha") == kernel_src_sha() and tj.get("workload") == f"{a.config}/bs{bs_main}/{a.precision}/{a.model}":
+                traffic = tj["hbm_bytes_per_loop_iteration"]
+                traffic_src = {"file": "profiles/r02_pmc_traffic.json", "kernel_src_sha": tj["kernel_src_sha"],
+                               "unit": "bytes per loop iteration (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes on these kernel sources)"}
         except Exception:
             pass
+        dom = kernels[0] if kernels else None
+        roof = {"bound": "mfma", "peak": peak, "unit": "TFLOP/s",
+                "achieved": dom["tflops"] if dom else loop_tf, "frac": dom["frac"] if dom else loop_tf / peak,
+                "kernel": dom["name"] if dom else "whole sampler loop",
+                "launch": ("dominant kernel of the loop (largest time per iteration): algorithmic FLOPs of one launch / its HIP-event "
+                           "bracket on the launch stream, eager forward at iteration 25, after the timed region"),
+                "traffic": traffic, "traffic_source": traffic_src,
+                "loop_frac": loop_tf / peak, "loop_achieved": loop_tf, "loop_ms": loop_ms, "dac_decode_ms": dac_ms,
+                "algorithmic_tflop_per_clip": f_clip / 1e12, "event_bracket_us": bracket_us, "kernels": kernels}
         out = {
-            "metric": "audio-sec/sec (5s clip, 50-step Euler, CFG 4.5)",
-            "value": clips * DURATION_S / dt, "unit": "audio-sec/sec", "n_gpus": world, "steps": a.steps,
+            "metric": f"audio-sec/sec ({duration:g}s clip, 50-step Euler, CFG 4.5)",
+            "value": clips * duration / dt, "unit": "audio-sec/sec", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-            "config": {"workload": f"T2A 5 s, 50 Euler steps, CFG 4.5, hunyuanvideo-foley-{a.model}, "
-                                   f"bs={a.bs}/GPU, {a.precision} GEMM operands / fp32 accumulate, "
-                                   f"DAC-VAE fp32 decode to 48 kHz",
-                       "clips_per_gpu": a.bs, "parallelism": f"dp{world}", "hip_graph": not a.no_graph},
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                         "traffic": traffic, "traffic_unit": "bytes per foley_sample launch (rocprofv3 PMC, offline pass)",
-                         "kernel": "gemm_ws_kernel + gemm_conv3_kernel (MFMA GEMM/conv engine; ~80% of the device-resident sampler loop)",
-                         "launch": "one foley_sample call = 50 captured iterations, HIP-event timed on its stream",
-                         "loop_ms": loop_ms, "dac_decode_ms": dac_ms,
-                         "algorithmic_tflop_per_clip": f_clip / 1e12},
+            "config": {"workload": f"{a.config}: {conf['desc']}, hunyuanvideo-foley-{a.model}, bs={bs_main}/GPU, "
+                                   f"{a.precision} GEMM operands / fp32 accumulate, weight storage {quant}, "
+                                   f"DAC-VAE fp32 decode to 48 kHz, host-to-host (H2D noise + D2H waveform timed)",
+                       "clips_per_gpu": bs_main, "parallelism": f"dp{world}", "hip_graph": graph,
+                       "collectives": 1 if use_dist else 0, "broadcast_s": bcast_s, "bundle_bytes": spec.total},
+            "roofline": roof,
         }
-        if world == 1 and not a.no_cpu_baseline and a.model == "xxl":
-            out["cpu_baseline"] = cpu_baseline(sd, dsd, cfg, cond, noise_all)
+        if extra:
+            out["extra"] = extra
+        if world == 1 and not a.no_cpu_baseline and a.model == "xxl" and a.config != "c5":
+            out["cpu_baseline"] = cpu_baseline(sd, dsd, cfg, cond, noise_all, duration)
         print(json.dumps(out), flush=True)
     if use_dist:
-        torch.distributed.destroy_process_group()
+        dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -5,6 +5,7 @@
 #include "../../include/foley_hip.h"
 #include "kernels.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -51,10 +52,56 @@ struct DevBuf {  // context-owned workspace block
   size_t bytes = 0;
 };
 
+struct Lin {  // a packed linear / conv-as-GEMM layer
+  const void* w = nullptr;
+  const float* b = nullptr;
+  int N = 0, K = 0;
+};
+
+// Weights of the DiT forward resolved once per registration (foley_prepare) instead of ~600 string
+// lookups per eager iteration; index 0 = audio stream, 1 = visual stream.
+struct TripleW {
+  Lin qkv[2], proj[2], cq[2], cproj[2], fc1[2], fc2[2];
+  const float *qn[2], *kn[2], *cqn[2];
+};
+struct SingleW {
+  Lin qkv, lin1, w13, w2;
+  const float *qn, *kn;
+};
+struct ForwardW {
+  std::vector<TripleW> t;
+  std::vector<SingleW> s;
+  Lin audio_in, fin, smod;
+  bool ok = false;
+};
+
+// Per-launch HIP-event brackets of one eager forward (foley_profile_forward): label -> time / work.
+struct ProfRec {
+  const char* label;
+  double flop, bytes;
+  hipEvent_t e0, e1;
+};
+struct Profiler {
+  bool on = false;
+  std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  hipEvent_t get() {
+    if (used == pool.size()) {
+      hipEvent_t e = nullptr;
+      (void)hipEventCreate(&e);
+      pool.push_back(e);
+    }
+    return pool[used++];
+  }
+};
+
 struct foley_ctx {
   int device = 0;
   foley_config cfg{};
   std::unordered_map<std::string, TensorRef> tensors;
+  ForwardW fw;
+  Profiler prof;
   // run state (valid after foley_prepare)
   bool prepared = false;
   foley_plan plan{};
@@ -93,6 +140,7 @@ struct foley_ctx {
   // ctx-owned copies of the plan's lookup tables (stable addresses across foley_prepare calls)
   float *rope_cos = nullptr, *rope_sin = nullptr, *solver_coef = nullptr;
   int *pos_audio_self = nullptr, *pos_visual_self = nullptr, *pos_linear = nullptr, *sync_gather = nullptr;
+  int* rep_idx = nullptr;           // [clips*Lv] j -> j % Lv: replicates the visual projection per clip in one launch
   void *tA = nullptr, *tB = nullptr;  // precompute scratch
   float* tF = nullptr;
   bool have_buffers = false;        // workspace allocated for `plan`'s dimensions
@@ -200,12 +248,6 @@ static RowBcast rb_none() { return RowBcast{nullptr, 0, 0, 1, 1, nullptr, 0}; }
 // (deferred split-K, kernels.h GemmArgs::partials)
 constexpr int PART_CAP = 8;
 
-struct Lin {  // a packed linear / conv-as-GEMM layer
-  const void* w = nullptr;
-  const float* b = nullptr;
-  int N = 0, K = 0;
-};
-
 static int get_lin(foley_ctx* c, const std::string& name, int dtype, int N, int K, bool bias, Lin* out) {
   const void* w;
   TRY(get_tensor(c, name + ".w", dtype, {N, K}, &w));
@@ -265,7 +307,7 @@ extern "C" int foley_ctx_create(int device, const foley_config* cfg, foley_ctx**
   (void)hipEventCreate(&c->ev1);
   (void)hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
   (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-  c->ev_mod.resize(cfg->depth_single);
+  c->ev_mod.resize(cfg->depth_single > 0 ? cfg->depth_single : 1);
   for (auto& e : c->ev_mod) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
   *out = c;
   return 0;
@@ -282,6 +324,7 @@ extern "C" void foley_ctx_destroy(foley_ctx* c) {
   if (c->side) hipStreamDestroy(c->side);
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
   for (auto e : c->ev_mod) hipEventDestroy(e);
+  for (auto e : c->prof.pool) hipEventDestroy(e);
   delete c;
 }
 
@@ -296,6 +339,7 @@ extern "C" int foley_set_tensor(foley_ctx* c, const char* name, const void* p, i
   auto it = c->tensors.find(name);
   if (it != c->tensors.end() && it->second.p != p) ctx_drop_graph(c);  // captured kernels hold the old address
   c->tensors[name] = t;
+  c->fw.ok = false;     // resolved pointers are refreshed by the next foley_prepare
   c->prepared = false;  // cached tables depend on the weights
   return 0;
 }
@@ -304,6 +348,53 @@ extern "C" int foley_last_elapsed_ms(foley_ctx* c, float* ms) {
   if (!c || !ms || !c->timed) return FAIL(FOLEY_ERR_STATE, "nothing timed yet");
   HIPTRY(hipEventSynchronize(c->ev1));
   HIPTRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return 0;
+}
+
+// --------------------------------------------------------------------------- resolved weights
+static int get_vec(foley_ctx* c, const std::string& name, int n, const float** out) {
+  const void* p;
+  TRY(get_tensor(c, name, FOLEY_F32, {n}, &p));
+  *out = (const float*)p;
+  return 0;
+}
+
+static int resolve_forward_weights(foley_ctx* c) {
+  const foley_config& f = c->cfg;
+  const int D = f.hidden, T = f.compute_dtype, Hc = f.conv_hidden;
+  ForwardW& w = c->fw;
+  w.ok = false;
+  w.t.assign(f.depth_triple, TripleW{});
+  w.s.assign(f.depth_single, SingleW{});
+  for (int b = 0; b < f.depth_triple; ++b) {
+    TripleW& t = w.t[b];
+    for (int s = 0; s < 2; ++s) {
+      const std::string p = "t" + std::to_string(b) + (s ? ".v_" : ".a_");
+      TRY(get_lin(c, p + "qkv", T, 3 * D, D, true, &t.qkv[s]));
+      TRY(get_lin(c, p + "proj", T, D, D, true, &t.proj[s]));
+      TRY(get_lin(c, p + "cq", T, D, D, true, &t.cq[s]));
+      TRY(get_lin(c, p + "cproj", T, D, D, true, &t.cproj[s]));
+      TRY(get_lin(c, p + "fc1", T, f.mlp_hidden, D, true, &t.fc1[s]));
+      TRY(get_lin(c, p + "fc2", T, D, f.mlp_hidden, true, &t.fc2[s]));
+      TRY(get_vec(c, p + "qn", 128, &t.qn[s]));
+      TRY(get_vec(c, p + "kn", 128, &t.kn[s]));
+      TRY(get_vec(c, p + "cqn", 128, &t.cqn[s]));
+    }
+  }
+  for (int b = 0; b < f.depth_single; ++b) {
+    SingleW& q = w.s[b];
+    const std::string p = "s" + std::to_string(b) + ".";
+    TRY(get_lin(c, p + "qkv", T, 3 * D, D, true, &q.qkv));
+    TRY(get_lin(c, p + "lin1", T, D, 3 * D, true, &q.lin1));
+    TRY(get_lin(c, p + "w13", T, 2 * Hc, 3 * D, false, &q.w13));
+    TRY(get_lin(c, p + "w2", T, D, 3 * Hc, false, &q.w2));
+    TRY(get_vec(c, p + "qn", 128, &q.qn));
+    TRY(get_vec(c, p + "kn", 128, &q.kn));
+  }
+  TRY(get_lin(c, "audio_in", T, D, f.latent_dim, true, &w.audio_in));
+  TRY(get_lin(c, "final", T, f.latent_dim, D, true, &w.fin));
+  if (f.depth_single > 0) TRY(get_lin(c, "smod_all", T, f.depth_single * 6 * D, D, true, &w.smod));
+  w.ok = true;
   return 0;
 }
 
@@ -331,7 +422,8 @@ extern "C" int foley_prepare(foley_ctx* c, const foley_plan* pl, void* stream_v)
   const int hidmax = f.mlp_hidden > f.conv_hidden ? f.mlp_hidden : f.conv_hidden;
   const int Lmax = std::max(std::max(La, Lv), Lt);
   const int rmax = std::max(std::max(NI, ncfg * Lt), std::max(ncfg * Lv, ncfg * Ls));
-  const size_t tcols = std::max(std::max(D, f.sync_hidden), 768);
+  // widest row any precompute stage writes into the scratch (every configurable feature width)
+  const size_t tcols = std::max({D, f.sync_hidden, f.cond_dim, f.clip_dim, f.sync_dim, f.time_freq_dim});
 
 #define ALLOC(ptr, bytes) TRY(ctx_alloc(c, (bytes), (void**)&(ptr)))
   if (!reuse) {
@@ -373,6 +465,12 @@ extern "C" int foley_prepare(foley_ctx* c, const foley_plan* pl, void* stream_v)
     ALLOC(c->pos_visual_self, (size_t)Lv * 4);
     ALLOC(c->pos_linear, (size_t)Lmax * 4);
     ALLOC(c->sync_gather, (size_t)La * 4);
+    ALLOC(c->rep_idx, (size_t)clips * Lv * 4);
+    {
+      std::vector<int> idx((size_t)clips * Lv);
+      for (size_t j = 0; j < idx.size(); ++j) idx[j] = (int)(j % Lv);
+      HIPTRY(hipMemcpy(c->rep_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
+    }
     // scratch of the precompute
     ALLOC(c->tA, (size_t)rmax * tcols * es);
     ALLOC(c->tB, (size_t)rmax * tcols * es);
@@ -469,6 +567,7 @@ extern "C" int foley_prepare(foley_ctx* c, const foley_plan* pl, void* stream_v)
     TRY(launch_gather_rows(tF, pl->sync_gather, La, ncfg, Ls, D, c->add_sync, st));
   }
   HIPTRY(hipStreamSynchronize(st));
+  if (!c->fw.ok) TRY(resolve_forward_weights(c));
   c->prepared = true;
   return 0;
 }
@@ -481,9 +580,32 @@ static RowBcast rb_tok(const float* base, long ld, int rows_per_cfg, int L) {
   return RowBcast{base, ld, 1, rows_per_cfg, L, nullptr, 0};
 }
 
+// Launch bracket of the per-kernel profile (foley_profile_forward): two events around one launch,
+// tagged with the op's algorithmic FLOPs / bytes.  Compiles to the bare call when profiling is off.
+static int prof_begin(foley_ctx* c, hipStream_t st, const char* label, double flop, double bytes) {
+  if (!c->prof.on) return 0;
+  ProfRec r{label, flop, bytes, c->prof.get(), c->prof.get()};
+  HIPTRY(hipEventRecord(r.e0, st));
+  c->prof.recs.push_back(r);
+  return 0;
+}
+static int prof_end(foley_ctx* c, hipStream_t st) {
+  if (!c->prof.on) return 0;
+  HIPTRY(hipEventRecord(c->prof.recs.back().e1, st));
+  return 0;
+}
+#define PROF(label, flop, bytes, call)            \
+  do {                                            \
+    TRY(prof_begin(c, st, (label), (flop), (bytes))); \
+    TRY(call);                                    \
+    TRY(prof_end(c, st));                         \
+  } while (0)
+
 static int run_forward(foley_ctx* c, hipStream_t st) {
   const foley_config& f = c->cfg;
   const foley_plan& pl = c->plan;
+  const ForwardW& W = c->fw;
+  if (!W.ok) return FAIL(FOLEY_ERR_STATE, "forward weights are not resolved (foley_prepare)");
   const int D = f.hidden, H = f.heads, C = f.latent_dim, T = f.compute_dtype;
   const int ncfg = pl.ncfg, clips = pl.clips, La = pl.La, Lv = pl.Lv, Lt = pl.Lt, NI = pl.n_iter;
   const int Bc = ncfg * clips, M = Bc * La, Mv = Bc * Lv, S = La + Lv;
@@ -491,37 +613,43 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
   const size_t es = esize(T);
   const int Sp = (S + 31) & ~31, Lap = (La + 31) & ~31;  // V^T row pitches (bf16 attention)
   const int* sp = c->step_ctr;
+  // algorithmic work of one launch (profile labels): dense contraction FLOPs, operand + result bytes
+  auto gf = [](double m, double n, double k) { return 2.0 * m * n * k; };
+  auto gb = [&](double m, double n, double k, double out_es) { return (m * k + n * k) * (double)es + m * n * out_es; };
+  auto af = [&](double b, double sq, double skv) { return 4.0 * b * H * sq * skv * 128.0; };
+  auto ab = [&](double b, double sq, double skv) { return (2.0 * b * H * sq * 128.0 + 2.0 * b * H * skv * 128.0) * (double)es; };
 
   // ---- side stream: per-token conditioning of the single-stream blocks, SiLU(add_sync + vec)
   // (hifi_foley.py:866-867), and every single block's modulation GEMM (hifi_foley.py:366).  They
   // depend on the iteration only, and are identical for every clip of a CFG half (M = ncfg*La).
+  // (Profiling runs them in line on the main stream so that the brackets do not overlap.)
   {
-    hipStream_t sd = c->side;
-    HIPTRY(hipEventRecord(c->ev_fork, st));
-    HIPTRY(hipStreamWaitEvent(sd, c->ev_fork, 0));
+    hipStream_t sd = c->prof.on ? st : c->side;
+    if (!c->prof.on) {
+      HIPTRY(hipEventRecord(c->ev_fork, st));
+      HIPTRY(hipStreamWaitEvent(sd, c->ev_fork, 0));
+    }
     TRY(launch_rows_add_act(c->add_sync, rb_vec(c->vec_table, D, sp), ncfg * La, D, 1, c->svec, T, sd));
     if (f.depth_single > 0) {
       // one GEMM for all blocks: [ncfg*La, D] x [n_single*6D, D]^T -> smod [ncfg*La, n_single*6D]
-      Lin mod;
-      TRY(get_lin(c, "smod_all", T, f.depth_single * 6 * D, D, true, &mod));
-      TRY(launch_gemm(gemm_plain(c->svec, ncfg * La, mod, c->smod, (long)f.depth_single * 6 * D), T, EPI_STORE_F32, 0, sd));
-      HIPTRY(hipEventRecord(c->ev_mod[0], sd));
+      const double n = (double)f.depth_single * 6 * D;
+      TRY(prof_begin(c, st, "single.modulation (all blocks, one GEMM)", gf(ncfg * La, n, D), gb(ncfg * La, n, D, 4)));
+      TRY(launch_gemm(gemm_plain(c->svec, ncfg * La, W.smod, c->smod, (long)f.depth_single * 6 * D), T, EPI_STORE_F32, 0, sd));
+      TRY(prof_end(c, st));
     }
+    // the join point always exists (also with depth_single == 0): a forked capture stream must be
+    // joined before the capture ends, and eager callers must not race on svec
+    if (!c->prof.on) HIPTRY(hipEventRecord(c->ev_mod[0], sd));
   }
 
   // audio_embedder (conv k=1 == linear over the transposed latents) + add_sync (hifi_foley.py:768, 838-839)
   {
-    Lin ain;
-    TRY(get_lin(c, "audio_in", T, D, C, true, &ain));
-    GemmArgs g = gemm_plain(c->xin, M, ain, c->audio, D);
+    GemmArgs g = gemm_plain(c->xin, M, W.audio_in, c->audio, D);
     g.rb = rb_tok(c->add_sync, D, clips * La, La);
-    TRY(launch_gemm(g, T, EPI_STORE_F32, 0, st));
+    PROF("audio_embedder", gf(M, D, C), gb(M, D, C, 4), launch_gemm(g, T, EPI_STORE_F32, 0, st));
   }
-  // visual stream starts from the step-invariant projection, replicated per clip
-  for (int g = 0; g < ncfg; ++g)
-    for (int b = 0; b < clips; ++b)
-      HIPTRY(hipMemcpyAsync(c->vcond + ((size_t)(g * clips + b) * Lv) * D, c->v_cond0 + (size_t)g * Lv * D,
-                            (size_t)Lv * D * 4, hipMemcpyDeviceToDevice, st));
+  // visual stream starts from the step-invariant projection, replicated per clip (one gather launch)
+  TRY(launch_gather_rows(c->v_cond0, c->rep_idx, clips * Lv, ncfg, Lv, D, c->vcond, st));
 
   // residual updates left pending by deferred split-K GEMMs, per stream (audio, visual); the next
   // LayerNorm of that stream applies them
@@ -531,27 +659,25 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
     g.partial_stride = (long)g.M * g.N;
     g.partial_cap = PART_CAP;
   };
+  const double ln_bytes_t = (double)(M + Mv) * D * (4 + 4 + es), ln_bytes_s = (double)M * D * (4 + 4 + es);
   for (int blk = 0; blk < f.depth_triple; ++blk) {
-    const std::string p = "t" + std::to_string(blk) + ".";
+    const TripleW& w = W.t[blk];
     auto tb = [&](int s, int chunk) {
       return rb_vec(c->modtab + ((size_t)(blk * 2 + s) * NI) * 9 * D + (size_t)chunk * D, 9L * D, sp);
     };
-    struct Stream { const char* pre; float* x; void* xn; float* qkv; void* att; void* hid; int rows, L, tok_off; const int* pos; };
-    Stream ss[2] = {{"a_", c->audio, c->xn_a, c->qkv_a, c->att_a, c->hid_a, M, La, Lv, pl.pos_audio_self},
-                    {"v_", c->vcond, c->xn_v, c->qkv_v, c->att_v, c->hid_v, Mv, Lv, 0, pl.pos_visual_self}};
+    struct Stream { float* x; void* xn; float* qkv; void* att; void* hid; int rows, L, tok_off; const int* pos; };
+    Stream ss[2] = {{c->audio, c->xn_a, c->qkv_a, c->att_a, c->hid_a, M, La, Lv, pl.pos_audio_self},
+                    {c->vcond, c->xn_v, c->qkv_v, c->att_v, c->hid_v, Mv, Lv, 0, pl.pos_visual_self}};
     // Both streams go through the same sequence of ops with their own weights; each op is ONE
     // launch covering the audio problem and the (much smaller) visual problem.
-    auto lin2 = [&](const char* name, int N, int K, Lin* la, Lin* lv) -> int {
-      TRY(get_lin(c, p + "a_" + name, T, N, K, true, la));
-      return get_lin(c, p + "v_" + name, T, N, K, true, lv);
-    };
     auto ln2 = [&](int c_shift, int c_scale) -> int {
       LnArgs a0{ss[0].x, ss[0].rows, tb(0, c_shift), tb(0, c_scale), ss[0].xn, pend[0]};
       LnArgs a1{ss[1].x, ss[1].rows, tb(1, c_shift), tb(1, c_scale), ss[1].xn, pend[1]};
       pend[0] = pend[1] = LnPending{};
-      return launch_ln_mod_pair(a0, a1, D, 1e-6f, T, st);
+      PROF("triple.layernorm+modulate (+pending split-K sum)", 0.0, ln_bytes_t, launch_ln_mod_pair(a0, a1, D, 1e-6f, T, st));
+      return 0;
     };
-    auto gated2 = [&](const Lin& la, const Lin& lv, bool from_hid, int c_gate) -> int {
+    auto gated2 = [&](const char* label, const Lin& la, const Lin& lv, bool from_hid, int c_gate) -> int {
       GemmArgs g0 = gemm_plain(from_hid ? ss[0].hid : ss[0].att, ss[0].rows, la, ss[0].x, D);
       GemmArgs g1 = gemm_plain(from_hid ? ss[1].hid : ss[1].att, ss[1].rows, lv, ss[1].x, D);
       g0.rb = tb(0, c_gate);
@@ -559,7 +685,8 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
       with_partials(g0, c->part_a);
       with_partials(g1, c->part_v);
       int ks = 1;
-      TRY(launch_gemm_pair(g0, g1, T, EPI_GATE_RES, st, &ks));
+      PROF(label, gf(M + Mv, la.N, la.K), gb(M + Mv, la.N, la.K, 4) + (double)la.N * la.K * es,
+           launch_gemm_pair(g0, g1, T, EPI_GATE_RES, st, &ks));
       if (ks > 1) {
         pend[0] = LnPending{c->part_a, ks, g0.partial_stride, la.b, g0.rb};
         pend[1] = LnPending{c->part_v, ks, g1.partial_stride, lv.b, g1.rb};
@@ -579,118 +706,97 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
     };
     // 1. joint self attention (hifi_foley.py:215-269)
     {
-      Lin qa, qv;
-      const void *aqn, *akn, *vqn, *vkn;
-      TRY(lin2("qkv", 3 * D, D, &qa, &qv));
-      TRY(get_tensor(c, p + "a_qn", FOLEY_F32, {128}, &aqn));
-      TRY(get_tensor(c, p + "a_kn", FOLEY_F32, {128}, &akn));
-      TRY(get_tensor(c, p + "v_qn", FOLEY_F32, {128}, &vqn));
-      TRY(get_tensor(c, p + "v_kn", FOLEY_F32, {128}, &vkn));
       TRY(ln2(0, 1));
-      GemmArgs g0 = gemm_plain(ss[0].xn, ss[0].rows, qa, ss[0].qkv, 3 * D);
-      GemmArgs g1 = gemm_plain(ss[1].xn, ss[1].rows, qv, ss[1].qkv, 3 * D);
-      g0.qs = split_args(0, 3, aqn, akn, ss[0].pos);
-      g1.qs = split_args(1, 3, vqn, vkn, ss[1].pos);
-      TRY(launch_gemm_pair(g0, g1, T, EPI_QKV_SPLIT, st));   // head split fused into the projection
+      GemmArgs g0 = gemm_plain(ss[0].xn, ss[0].rows, w.qkv[0], ss[0].qkv, 3 * D);
+      GemmArgs g1 = gemm_plain(ss[1].xn, ss[1].rows, w.qkv[1], ss[1].qkv, 3 * D);
+      g0.qs = split_args(0, 3, w.qn[0], w.kn[0], ss[0].pos);
+      g1.qs = split_args(1, 3, w.qn[1], w.kn[1], ss[1].pos);
+      PROF("triple.qkv GEMM + RMSNorm/RoPE head split", gf(M + Mv, 3 * D, D), gb(M + Mv, 3 * D, D, es) + 3.0 * D * D * es,
+           launch_gemm_pair(g0, g1, T, EPI_QKV_SPLIT, st));   // head split fused into the projection
       AttnArgs a{c->Q, c->K, c->V, Bc, H, S, S, 1, c->att_v, c->att_a, Lv, T, bf ? Sp : 0};
-      TRY(launch_attention(a, T, st));
-      Lin pa, pv;
-      TRY(lin2("proj", D, D, &pa, &pv));
-      TRY(gated2(pa, pv, false, 2));
+      PROF("triple.self attention", af(Bc, S, S), ab(Bc, S, S), launch_attention(a, T, st));
+      TRY(gated2("triple.self proj GEMM (gated residual)", w.proj[0], w.proj[1], false, 2));
     }
     // 2. cross attention to the (cached) text keys/values (hifi_foley.py:271-319)
     {
-      Lin qa, qv;
-      const void *aqn, *vqn;
-      TRY(lin2("cq", D, D, &qa, &qv));
-      TRY(get_tensor(c, p + "a_cqn", FOLEY_F32, {128}, &aqn));
-      TRY(get_tensor(c, p + "v_cqn", FOLEY_F32, {128}, &vqn));
       TRY(ln2(3, 4));
-      GemmArgs g0 = gemm_plain(ss[0].xn, ss[0].rows, qa, ss[0].qkv, D);
-      GemmArgs g1 = gemm_plain(ss[1].xn, ss[1].rows, qv, ss[1].qkv, D);
-      g0.qs = split_args(0, 1, aqn, nullptr, pl.pos_linear);
-      g1.qs = split_args(1, 1, vqn, nullptr, pl.pos_linear);
-      TRY(launch_gemm_pair(g0, g1, T, EPI_QKV_SPLIT, st));
+      GemmArgs g0 = gemm_plain(ss[0].xn, ss[0].rows, w.cq[0], ss[0].qkv, D);
+      GemmArgs g1 = gemm_plain(ss[1].xn, ss[1].rows, w.cq[1], ss[1].qkv, D);
+      g0.qs = split_args(0, 1, w.cqn[0], nullptr, pl.pos_linear);
+      g1.qs = split_args(1, 1, w.cqn[1], nullptr, pl.pos_linear);
+      PROF("triple.cross q GEMM + head split", gf(M + Mv, D, D), gb(M + Mv, D, D, es) + 1.0 * D * D * es,
+           launch_gemm_pair(g0, g1, T, EPI_QKV_SPLIT, st));
       const int Ltp = (Lt + 31) & ~31;
       const size_t offk = (size_t)blk * ncfg * H * Lt * 128 * es;
       const size_t offv = (size_t)blk * ncfg * H * (bf ? Ltp : Lt) * 128 * es;
       AttnArgs a{c->Q, (char*)c->txt_k + offk, (char*)c->txt_v + offv, Bc, H, S, Lt, clips, c->att_v, c->att_a, Lv,
                  T, bf ? Ltp : 0};
-      TRY(launch_attention(a, T, st));
-      Lin pa, pv;
-      TRY(lin2("cproj", D, D, &pa, &pv));
-      TRY(gated2(pa, pv, false, 5));
+      PROF("triple.cross attention", af(Bc, S, Lt), ab(Bc, S, Lt), launch_attention(a, T, st));
+      TRY(gated2("triple.cross proj GEMM (gated residual)", w.cproj[0], w.cproj[1], false, 5));
     }
     // 3. GELU-tanh MLPs (hifi_foley.py:321-331)
     {
-      Lin f1a, f1v, f2a, f2v;
-      TRY(lin2("fc1", f.mlp_hidden, D, &f1a, &f1v));
-      TRY(lin2("fc2", D, f.mlp_hidden, &f2a, &f2v));
       TRY(ln2(6, 7));
-      TRY(launch_gemm_pair(gemm_plain(ss[0].xn, ss[0].rows, f1a, ss[0].hid, f.mlp_hidden),
-                           gemm_plain(ss[1].xn, ss[1].rows, f1v, ss[1].hid, f.mlp_hidden), T, EPI_GELU_T, st));
-      TRY(gated2(f2a, f2v, true, 8));
+      PROF("triple.mlp fc1 GEMM + GELU", gf(M + Mv, f.mlp_hidden, D), gb(M + Mv, f.mlp_hidden, D, es) + (double)f.mlp_hidden * D * es,
+           launch_gemm_pair(gemm_plain(ss[0].xn, ss[0].rows, w.fc1[0], ss[0].hid, f.mlp_hidden),
+                            gemm_plain(ss[1].xn, ss[1].rows, w.fc1[1], ss[1].hid, f.mlp_hidden), T, EPI_GELU_T, st));
+      TRY(gated2("triple.mlp fc2 GEMM (gated residual)", w.fc2[0], w.fc2[1], true, 8));
     }
   }
 
+  // join: the single blocks' modulation table is ready (profiling ran it in line)
+  if (!c->prof.on) HIPTRY(hipStreamWaitEvent(st, c->ev_mod[0], 0));
   const int Hc = f.conv_hidden;
   for (int blk = 0; blk < f.depth_single; ++blk) {
-    const std::string p = "s" + std::to_string(blk) + ".";
-    Lin qkv, lin1, w13, w2;
-    const void *qn, *kn;
-    TRY(get_lin(c, p + "qkv", T, 3 * D, D, true, &qkv));
-    TRY(get_lin(c, p + "lin1", T, D, 3 * D, true, &lin1));
-    TRY(get_lin(c, p + "w13", T, 2 * Hc, 3 * D, false, &w13));
-    TRY(get_lin(c, p + "w2", T, D, 3 * Hc, false, &w2));
-    TRY(get_tensor(c, p + "qn", FOLEY_F32, {128}, &qn));
-    TRY(get_tensor(c, p + "kn", FOLEY_F32, {128}, &kn));
+    const SingleW& w = W.s[blk];
     const float* smod_b = c->smod + (size_t)blk * 6 * D;   // column block of the fused table
     auto sm = [&](int chunk) { return rb_tok(smod_b + (size_t)chunk * D, 6L * D * f.depth_single, clips * La, La); };
-    if (blk == 0) HIPTRY(hipStreamWaitEvent(st, c->ev_mod[0], 0));   // join: the modulation table is ready
-    TRY(launch_ln_mod_pending(c->audio, M, D, 1e-5f, sm(0), sm(1), c->xn_a, T, pend[0], st));
+    PROF("single.layernorm+modulate (+pending split-K sum)", 0.0, ln_bytes_s,
+         launch_ln_mod_pending(c->audio, M, D, 1e-5f, sm(0), sm(1), c->xn_a, T, pend[0], st));
     pend[0] = LnPending{};
-    GemmArgs gq = gemm_plain(c->xn_a, M, qkv, c->qkv_a, 3 * D);
+    GemmArgs gq = gemm_plain(c->xn_a, M, w.qkv, c->qkv_a, 3 * D);
     QkvSplitArgs q{};
     q.qkv = c->qkv_a; q.M = M; q.L = La; q.H = H; q.nK = 3;
-    q.gain[0] = (const float*)qn; q.gain[1] = (const float*)kn;
+    q.gain[0] = w.qn; q.gain[1] = w.kn;
     q.pos[0] = pl.pos_linear; q.pos[1] = pl.pos_linear;
     q.dst[0] = c->Q; q.dst[1] = c->K; q.dst[2] = c->V;
     q.out_dtype = T; q.vt_pitch = bf ? Lap : 0;
     q.S_tot = La; q.tok_off = 0; q.eps = 1.1920928955078125e-07f;  // nn.RMSNorm(eps=None) -> finfo(fp32).eps
     q.cos_tab = pl.rope_cos; q.sin_tab = pl.rope_sin;
     gq.qs = q;
-    TRY(launch_gemm(gq, T, EPI_QKV_SPLIT, 0, st));
+    PROF("single.qkv GEMM + RMSNorm/RoPE head split", gf(M, 3 * D, D), gb(M, 3 * D, D, es), launch_gemm(gq, T, EPI_QKV_SPLIT, 0, st));
     {
       AttnArgs a{c->Q, c->K, c->V, Bc, H, La, La, 1, c->att_a, c->att_a, 0, T, bf ? Lap : 0};
-      TRY(launch_attention(a, T, st));
+      PROF("single.self attention", af(Bc, La, La), ab(Bc, La, La), launch_attention(a, T, st));
     }
     {
-      GemmArgs g = gemm_conv(c->att_a, M, La, D, 3, 1, lin1, c->audio, D);
+      GemmArgs g = gemm_conv(c->att_a, M, La, D, 3, 1, w.lin1, c->audio, D);
       g.rb = sm(2);
       with_partials(g, c->part_a);
       int ks = 1;
-      TRY(launch_gemm(g, T, EPI_GATE_RES, 0, st, &ks));
-      if (ks > 1) pend[0] = LnPending{c->part_a, ks, g.partial_stride, lin1.b, g.rb};
+      PROF("single.linear1 conv3 GEMM (gated residual)", gf(M, D, 3 * D), gb(M, D, 3 * D, 4), launch_gemm(g, T, EPI_GATE_RES, 0, st, &ks));
+      if (ks > 1) pend[0] = LnPending{c->part_a, ks, g.partial_stride, w.lin1.b, g.rb};
     }
-    TRY(launch_ln_mod_pending(c->audio, M, D, 1e-5f, sm(3), sm(4), c->xn_a, T, pend[0], st));
+    PROF("single.layernorm+modulate (+pending split-K sum)", 0.0, ln_bytes_s,
+         launch_ln_mod_pending(c->audio, M, D, 1e-5f, sm(3), sm(4), c->xn_a, T, pend[0], st));
     pend[0] = LnPending{};
-    TRY(launch_gemm(gemm_conv(c->xn_a, M, La, D, 3, 1, w13, c->hid_a, Hc), T, EPI_SILUGATE_T, 0, st));
+    PROF("single.w1/w3 conv3 GEMM + SiLU gate", gf(M, 2 * Hc, 3 * D), gb(M, 2 * Hc, 3 * D, es) - (double)M * Hc * es,
+         launch_gemm(gemm_conv(c->xn_a, M, La, D, 3, 1, w.w13, c->hid_a, Hc), T, EPI_SILUGATE_T, 0, st));
     {
-      GemmArgs g = gemm_conv(c->hid_a, M, La, Hc, 3, 1, w2, c->audio, D);
+      GemmArgs g = gemm_conv(c->hid_a, M, La, Hc, 3, 1, w.w2, c->audio, D);
       g.rb = sm(5);
       with_partials(g, c->part_a);
       int ks = 1;
-      TRY(launch_gemm(g, T, EPI_GATE_RES, 0, st, &ks));
-      if (ks > 1) pend[0] = LnPending{c->part_a, ks, g.partial_stride, w2.b, g.rb};
+      PROF("single.w2 conv3 GEMM (gated residual)", gf(M, D, 3 * Hc), gb(M, D, 3 * Hc, 4), launch_gemm(g, T, EPI_GATE_RES, 0, st, &ks));
+      if (ks > 1) pend[0] = LnPending{c->part_a, ks, g.partial_stride, w.w2.b, g.rb};
     }
   }
 
   // FinalLayer1D: adaLN is a no-op with 3-D conditioning => linear(LayerNorm(x))
   {
-    Lin fin;
-    TRY(get_lin(c, "final", T, C, D, true, &fin));
-    TRY(launch_ln_mod_pending(c->audio, M, D, 1e-6f, rb_none(), rb_none(), c->xn_a, T, pend[0], st));
-    TRY(launch_gemm(gemm_plain(c->xn_a, M, fin, c->pred, C), T, EPI_STORE_F32, 0, st));
+    PROF("final.layernorm", 0.0, ln_bytes_s,
+         launch_ln_mod_pending(c->audio, M, D, 1e-6f, rb_none(), rb_none(), c->xn_a, T, pend[0], st));
+    PROF("final.linear", gf(M, C, D), gb(M, C, D, 4), launch_gemm(gemm_plain(c->xn_a, M, W.fin, c->pred, C), T, EPI_STORE_F32, 0, st));
   }
   return 0;
 }
@@ -708,6 +814,68 @@ extern "C" int foley_dit_forward(foley_ctx* c, const float* latents, int iter, f
   TRY(launch_latent_rows(latents, pl.clips, C, pl.La, pl.ncfg, c->xin, c->cfg.compute_dtype, st));
   TRY(run_forward(c, st));
   HIPTRY(hipMemcpyAsync(out_rows, c->pred, (size_t)pl.ncfg * pl.clips * pl.La * C * 4, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+// --------------------------------------------------------------------------- per-kernel profile
+// `repeats` eager forwards at loop iteration `iter` with a HIP-event bracket around every launch
+// (recorded on the launch stream), aggregated by op label.  bracket_ms = mean elapsed time of an
+// EMPTY bracket (two back-to-back event records): the marker-processing cost every entry's time
+// includes once per call - subtract calls * bracket_ms for the kernel time proper.
+extern "C" int foley_profile_forward(foley_ctx* c, const float* latents, int iter, int repeats, foley_prof_entry* out,
+                                     int cap, int* n_out, float* bracket_ms, void* stream_v) {
+  if (!c || !latents || !out || !n_out || cap < 1 || repeats < 1) return FAIL(FOLEY_ERR_INVALID, "bad argument");
+  if (!c->prepared) return FAIL(FOLEY_ERR_STATE, "foley_prepare has not been called");
+  if (iter < 0 || iter >= c->plan.n_iter) return FAIL(FOLEY_ERR_INVALID, "iteration out of range");
+  hipStream_t st = (hipStream_t)stream_v;
+  HIPTRY(hipSetDevice(c->device));
+  const foley_plan& pl = c->plan;
+  HIPTRY(hipMemcpyAsync(c->step_ctr, &iter, sizeof(int), hipMemcpyHostToDevice, st));
+  HIPTRY(hipStreamSynchronize(st));
+  TRY(launch_latent_rows(latents, pl.clips, c->cfg.latent_dim, pl.La, pl.ncfg, c->xin, c->cfg.compute_dtype, st));
+  TRY(run_forward(c, st));   // warm: code objects loaded, caches in their steady state
+  c->prof.recs.clear();
+  c->prof.used = 0;
+  c->prof.on = true;
+  int rc = 0;
+  for (int r = 0; r < repeats && rc == 0; ++r) rc = run_forward(c, st);
+  c->prof.on = false;
+  if (rc) return rc;
+  // empty brackets for the calibration
+  constexpr int NCAL = 32;
+  hipEvent_t cal[2 * NCAL];
+  for (int i = 0; i < 2 * NCAL; ++i) cal[i] = c->prof.get();
+  for (int i = 0; i < NCAL; ++i) {
+    HIPTRY(hipEventRecord(cal[2 * i], st));
+    HIPTRY(hipEventRecord(cal[2 * i + 1], st));
+  }
+  HIPTRY(hipStreamSynchronize(st));
+  double cal_ms = 0.0;
+  for (int i = 0; i < NCAL; ++i) {
+    float ms = 0.f;
+    HIPTRY(hipEventElapsedTime(&ms, cal[2 * i], cal[2 * i + 1]));
+    cal_ms += ms;
+  }
+  if (bracket_ms) *bracket_ms = (float)(cal_ms / NCAL);
+  int n = 0;
+  for (const ProfRec& r : c->prof.recs) {
+    float ms = 0.f;
+    HIPTRY(hipEventElapsedTime(&ms, r.e0, r.e1));
+    int j = 0;
+    for (; j < n; ++j)
+      if (!strcmp(out[j].label, r.label)) break;
+    if (j == n) {
+      if (n == cap) return FAIL(FOLEY_ERR_INVALID, "profile: entry buffer too small");
+      memset(&out[n], 0, sizeof(out[n]));
+      strncpy(out[n].label, r.label, sizeof(out[n].label) - 1);
+      ++n;
+    }
+    out[j].calls += 1;
+    out[j].total_ms += ms;
+    out[j].flop += r.flop;
+    out[j].bytes += r.bytes;
+  }
+  *n_out = n;
   return 0;
 }
 

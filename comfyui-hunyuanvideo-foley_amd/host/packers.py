@@ -229,16 +229,24 @@ def arena_layout(packed: Dict[str, Tensor]) -> Tuple[int, "OrderedDict[str, Tupl
 
 
 class Arena:
-    """One flat device buffer holding every packed tensor (single-broadcast friendly)."""
+    """One flat device buffer holding every packed tensor (single-broadcast friendly).  `buffer` may be
+    a uint8 view into a larger allocation (the multi-GPU bundle, host/distributed.py)."""
 
-    def __init__(self, total_bytes: int, table, device):
+    def __init__(self, total_bytes: int, table, device, buffer: Tensor = None):
         self.table = table
-        self.buffer = torch.empty(max(total_bytes, _ALIGN), dtype=torch.uint8, device=device)
+        n = max(total_bytes, _ALIGN)
+        if buffer is None:
+            buffer = torch.empty(n, dtype=torch.uint8, device=device)
+        elif buffer.dtype != torch.uint8 or buffer.numel() < n or not buffer.is_contiguous():
+            raise ValueError("arena buffer must be a contiguous uint8 tensor of at least the layout's size")
+        elif buffer.device.type != "meta" and buffer.data_ptr() % 16:
+            raise ValueError("arena buffer must be 16-byte aligned (libfoley_hip.so's operand alignment)")
+        self.buffer = buffer[:n]
 
     @classmethod
-    def from_packed(cls, packed: Dict[str, Tensor], device) -> "Arena":
+    def from_packed(cls, packed: Dict[str, Tensor], device, buffer: Tensor = None) -> "Arena":
         total, table = arena_layout(packed)
-        a = cls(total, table, device)
+        a = cls(total, table, device, buffer=buffer)
         for k, t in packed.items():
             a.view(k).copy_(t, non_blocking=False)
         return a
@@ -254,6 +262,23 @@ class Arena:
     def items(self) -> Iterable[Tuple[str, Tensor]]:
         for k in self.table:
             yield k, self.view(k)
+
+
+def _meta_state(schema) -> Dict[str, Tensor]:
+    return {k: torch.empty(shape, device="meta") for k, (shape, _std, _mean) in schema.items()}
+
+
+def dit_arena_layout(cfg: DiTConfig, dtype: torch.dtype):
+    """(total bytes, table) of the packed DiT arena, derived from the config alone (the packers run on
+    meta tensors of the reference state-dict schema): every rank of a multi-GPU job can lay out the
+    arena it is about to receive without a metadata exchange."""
+    from . import synth
+    return arena_layout(pack_dit(_meta_state(synth.dit_schema(cfg)), cfg, dtype))
+
+
+def dac_arena_layout(cfg: DACConfig):
+    from . import synth
+    return arena_layout(pack_dac(_meta_state(synth.dac_decoder_schema(cfg)), cfg))
 
 
 def torch_dtype(name: str) -> torch.dtype:

@@ -73,7 +73,13 @@ class GemmDescC(C.Structure):
     ]
 
 
+class ProfEntryC(C.Structure):
+    _fields_ = [("label", C.c_char * 80), ("calls", C.c_int32), ("total_ms", C.c_float), ("flop", C.c_double),
+                ("bytes", C.c_double)]
+
+
 PROGRESS_CB = C.CFUNCTYPE(None, C.c_int32, C.c_int32, C.c_void_p)
+ABI_VERSION = 3
 
 _SIGNATURES = {
     "foley_abi_version": (C.c_uint32, []),
@@ -88,6 +94,8 @@ _SIGNATURES = {
     "foley_dac_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int,
                                    C.c_void_p, C.c_void_p]),
     "foley_last_elapsed_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "foley_profile_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(ProfEntryC), C.c_int,
+                                        C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_void_p]),
     "foley_op_gemm": (C.c_int, [C.POINTER(GemmDescC), C.c_void_p]),
     "foley_op_attention": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                                                         C.c_void_p]),
@@ -126,7 +134,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         fn = getattr(lib, name)     # AttributeError if the .so does not export the ABI
         fn.restype = res
         fn.argtypes = args
-    if lib.foley_abi_version() != 2:
+    if lib.foley_abi_version() != ABI_VERSION:
         raise FoleyRuntimeError("libfoley_hip.so ABI version mismatch")
     if path is None:
         _LIB = lib
@@ -272,6 +280,23 @@ class FoleyContext:
             _check(self.lib, self.lib.foley_dac_encode(self._h, _ptr(wave), clips, Tp, cfg.encoder_dim, arr, len(rates),
                                                        _ptr(out), _stream()), "foley_dac_encode")
         return out
+
+    def profile_forward(self, latents: torch.Tensor, it: int = 0, repeats: int = 2):
+        """Per-op HIP-event profile of the eager DiT forward: list of dicts (label, calls_per_forward, avg_us
+        with the empty-bracket cost removed, flop / bytes per launch) + the bracket cost in us."""
+        cap = 64
+        arr = (ProfEntryC * cap)()
+        n, br = C.c_int(0), C.c_float(0.0)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.foley_profile_forward(self._h, _ptr(latents), int(it), int(repeats), arr, cap,
+                                                            C.byref(n), C.byref(br), _stream()), "foley_profile_forward")
+        out = []
+        for e in arr[:n.value]:
+            calls = max(e.calls, 1)
+            out.append({"label": e.label.decode(), "calls_per_forward": e.calls / repeats,
+                        "avg_us": max(1e3 * e.total_ms / calls - 1e3 * br.value, 0.0),
+                        "flop_per_launch": e.flop / calls, "bytes_per_launch": e.bytes / calls})
+        return out, 1e3 * br.value
 
     def last_elapsed_ms(self) -> float:
         ms = C.c_float()

@@ -36,11 +36,11 @@ class FoleyModel:
 
     @classmethod
     def from_arena(cls, cfg: DiTConfig, arena: "packers.Arena", compute_dtype: torch.dtype, device,
-                   dac_cfg: DACConfig = DAC48K) -> "FoleyModel":
+                   dac_cfg: DACConfig = DAC48K, quantization: str = "none") -> "FoleyModel":
         """Adopt an already packed arena (e.g. one received by broadcast on a non-root rank)."""
         self = cls.__new__(cls)
         self.cfg, self.dac_cfg, self.dtype, self.device = cfg, dac_cfg, compute_dtype, torch.device(device)
-        self.quantization = "none"
+        self.quantization = quantization
         self.arena = arena
         self._finish_init()
         return self

@@ -93,8 +93,13 @@ def rope_table(n_pos: int, dim: int = 128, theta: float = 10000.0):
 
 
 def nearest_exact_index(out_len: int, in_len: int) -> torch.Tensor:
-    i = torch.arange(out_len, dtype=torch.float64)
-    return torch.clamp(torch.floor((i + 0.5) * (in_len / out_len)).long(), max=in_len - 1)
+    """Source index of F.interpolate(x, size=out_len, mode='nearest-exact') (hifi_foley.py:44,58,761).
+    ATen evaluates it in *float32*: scale = float(in)/float(out), idx = min(int(floor((i + 0.5f) * scale)),
+    in-1) - a float64 evaluation picks the neighbouring row for ~5 % of the widget-reachable
+    durations (1.1 s, 2.7 s, 30.1 s ...), so the float32 arithmetic is reproduced operation by operation."""
+    scale = torch.tensor(float(in_len), dtype=torch.float32) / torch.tensor(float(out_len), dtype=torch.float32)
+    i = torch.arange(out_len, dtype=torch.float32)
+    return torch.clamp(torch.floor((i + 0.5) * scale).long(), max=in_len - 1)
 
 
 def interleaved_positions(la: int, lv: int):

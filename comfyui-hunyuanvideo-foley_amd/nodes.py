@@ -57,13 +57,16 @@ def _torch_device():
 def _load_state_dict(path):
     try:
         from comfy.utils import load_torch_file  # type: ignore
-        obj = load_torch_file(path, device=torch.device("cpu"))
     except ImportError:
-        if str(path).endswith(".safetensors"):
-            from safetensors.torch import load_file
-            obj = load_file(path)
-        else:
-            obj = torch.load(path, map_location="cpu")
+        load_torch_file = None
+    if load_torch_file is not None:
+        obj = load_torch_file(path, device=torch.device("cpu"))
+    elif str(path).endswith(".safetensors"):
+        from safetensors.torch import load_file
+        obj = load_file(path)
+    else:
+        # tensors only: never unpickle arbitrary objects from a downloaded .pth (comfy's loader does the same)
+        obj = torch.load(path, map_location="cpu", weights_only=True)
     if isinstance(obj, dict) and isinstance(obj.get("state_dict"), dict):   # utils.py:49-59
         obj = obj["state_dict"]
     return {k: v for k, v in obj.items() if isinstance(v, torch.Tensor)}

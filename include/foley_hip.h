@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FOLEY_ABI_VERSION 2   /* 2: foley_gemm_desc gained partials / qkv / rstride; foley_op_ln_mod_pending, foley_dac_encode added */
+#define FOLEY_ABI_VERSION 3   /* 3: foley_profile_forward; 2: foley_gemm_desc gained partials / qkv / rstride; foley_op_ln_mod_pending, foley_dac_encode */
 
 enum foley_dtype { FOLEY_DT_F32 = 0, FOLEY_DT_BF16 = 1, FOLEY_DT_I32 = 2 };
 
@@ -119,6 +119,21 @@ int foley_dac_decode(foley_ctx* ctx, const float* latents, int clips, int T, flo
  * packed `enc.*` tensors registered. */
 int foley_dac_encode(foley_ctx* ctx, const float* wave, int clips, int T, int enc_dim, const int32_t* rates,
                      int n_rates, float* params, void* stream);
+
+/* Per-kernel profile of the DiT forward (bench.py's live roofline): runs `repeats` EAGER forwards at loop
+ * iteration `iter` with a HIP-event bracket around every launch and aggregates by op.  `calls`,
+ * `total_ms`, `flop` (algorithmic FLOPs: 2*M*N*K per contraction, 4*B*H*Sq*Skv*128 per attention) and
+ * `bytes` (operands + result, read/written once) are totals over all repeats.  *bracket_ms = elapsed
+ * time of an empty bracket (event-marker cost contained once per call in total_ms).  Replaces
+ * nothing in the reference: it is the measurement hook SURVEY 8(d) asks for. */
+typedef struct foley_prof_entry {
+  char label[80];
+  int32_t calls;
+  float total_ms;
+  double flop, bytes;
+} foley_prof_entry;
+int foley_profile_forward(foley_ctx* ctx, const float* latents, int iter, int repeats, foley_prof_entry* out,
+                          int cap, int* n_out, float* bracket_ms, void* stream);
 
 /* HIP-event time (ms) of the last foley_sample / foley_dac_decode / foley_dac_encode call on this context (syncs). */
 int foley_last_elapsed_ms(foley_ctx* ctx, float* ms);

@@ -125,9 +125,12 @@ def rope_positions(n: int) -> Tensor:
 
 
 def nearest_exact_index(out_len: int, in_len: int) -> Tensor:
-    """Source index of F.interpolate(mode='nearest-exact'): floor((i+0.5)*in/out)."""
-    i = torch.arange(out_len, dtype=torch.float64)
-    return torch.clamp(torch.floor((i + 0.5) * (in_len / out_len)).long(), max=in_len - 1)
+    """Source index of F.interpolate(x, size=out_len, mode='nearest-exact') as the reference calls it
+    (hifi_foley.py:44,58,761): obtained from the op itself on an index ramp, so ATen's float32
+    evaluation of floor((i+0.5)*in/out) is reproduced exactly (a float64 formula differs for ~5 % of
+    the durations the sampler widget allows)."""
+    src = torch.arange(in_len, dtype=torch.float32).view(1, 1, in_len)
+    return F.interpolate(src, size=out_len, mode="nearest-exact").view(-1).long()
 
 
 def interleaved_positions(la: int, lv: int) -> Tuple[Tensor, Tensor]:
@@ -298,9 +301,9 @@ def dit_forward(sd: SD, heads: int, x: Tensor, t: Tensor, cond: Tensor, clip_fea
     H = heads
     B, _, La = x.shape
     if n_triple is None:
-        n_triple = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("triple_blocks."))
+        n_triple = 1 + max((int(k.split(".")[1]) for k in sd if k.startswith("triple_blocks.")), default=-1)
     if n_single is None:
-        n_single = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("single_blocks."))
+        n_single = 1 + max((int(k.split(".")[1]) for k in sd if k.startswith("single_blocks.")), default=-1)
     D = sd["time_in.mlp.2.weight"].shape[0]
     hd = D // H
     # time embedding (:744, embed_layers.py:104-136)

@@ -172,6 +172,30 @@ def test_rope_and_position_tables_match_golden():
     assert rel_err(tb["t_feat"], O.timestep_embedding(tb["timesteps"])) == 0.0
 
 
+def test_nearest_exact_index_matches_interpolate_for_every_widget_duration():
+    """F.interpolate(mode='nearest-exact') evaluates floor((i+0.5)*in/out) in float32 (hifi_foley.py:44,
+    58,761); a float64 formula picks a neighbouring row for 29 of the 591 durations the sampler widget
+    allows (1.0 .. 60.0 s, step 0.1).  The host's float32 emulation must agree with the op itself for
+    all of them, and the interleaved RoPE must stay a pure re-indexing."""
+    def aten(out_len, in_len):
+        src = torch.arange(in_len, dtype=torch.float32).view(1, 1, in_len)
+        return F.interpolate(src, size=out_len, mode="nearest-exact").view(-1).long()
+    n_f64_differs = 0
+    for k in range(10, 601):
+        d = k / 10
+        la, lv, ls = C.lengths(d)
+        for out_len, in_len in ((la, ls), (la, lv), (lv, la)):
+            ref = aten(out_len, in_len)
+            assert torch.equal(tables.nearest_exact_index(out_len, in_len), ref), (d, out_len, in_len)
+            assert torch.equal(O.nearest_exact_index(out_len, in_len), ref)
+            i = torch.arange(out_len, dtype=torch.float64)
+            f64 = torch.clamp(torch.floor((i + 0.5) * (in_len / out_len)).long(), max=in_len - 1)
+            n_f64_differs += int(not torch.equal(f64, ref))
+        pa, pv = tables.interleaved_positions(la, lv)      # raises if not a pure re-indexing
+        assert pv.shape == (lv,) and int(pv.max()) < 2 * la
+    assert n_f64_differs > 0    # the sweep does cover the durations where the precision matters
+
+
 def test_lengths_rule():
     assert C.lengths(5.0) == (250, 40, 112) and C.lengths(1.0) == (50, 8, 16) and C.lengths(30.0) == (1500, 240, 736)
     assert C.XXL.conv_hidden == 4096 and C.XL.conv_hidden == 3840 and C.TINY.conv_hidden == 768
@@ -186,7 +210,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(rt.EXPORTED_SYMBOLS), declared ^ set(rt.EXPORTED_SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.foley_abi_version() == 2
+    assert lib.foley_abi_version() == rt.ABI_VERSION == 3
 
 
 def test_no_cpu_fallback():

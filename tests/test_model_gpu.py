@@ -294,6 +294,52 @@ def test_full_size_properties(dev):
     assert max(errs) < 5e-2
 
 
+def test_c5_full_size_properties(dev):
+    """BASELINE config C5 as a whole: xxl + fp8_e4m3fn weight storage + 30 s (La=1500, Lv=240, Ls=736)
+    + negative-prompt CFG 4.5, through the loader's own entry point.  The oracle needs ~10 min per
+    forward at this size, so the run is pinned by size-independent properties:
+    (1) clips of a batch are independent (identical noise rows -> bit-identical latents);
+    (2) hipGraph replay == eager launches, bit for bit;
+    (3) the fp8-rounded weights are really in use (differs from the un-quantised model) and the
+        delta stays at fp8-rounding scale after a few steps;
+    (4) the waveform has the 30 s length and is finite."""
+    from foley_amd import nodes
+    cfg = C.XXL
+    sd = synth.synth_dit_state_dict(cfg, device=dev)
+    cond = synth.synth_conditioning(cfg, 30.0, t2a=True, sd=sd, device=dev)
+    assert cond["clip"].shape[1] == 240 and cond["sync"].shape[1] == 736
+    visual = {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]}
+    text = {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]}
+    m8 = nodes.HunyuanModelLoader.pack_state_dict(sd, "bf16", "fp8_e4m3fn", device=dev, cfg=cfg)
+    assert m8.quantization == "fp8_e4m3fn"
+    La, steps = 1500, 3
+    n1 = torch.randn(1, 128, La, generator=torch.Generator().manual_seed(21))
+    n2 = torch.randn(1, 128, La, generator=torch.Generator().manual_seed(22))
+
+    def run(m, noise, graph):
+        plan = sampler.build_plan(m, visual, text, La, 4.5, steps, noise.shape[0], "euler")
+        m.ctx.prepare(plan)
+        lat = noise.clone().to(dev).contiguous()
+        m.ctx.sample(lat, use_graph=graph)
+        return lat.cpu()
+
+    b3 = run(m8, torch.cat([n1, n2, n1]), True)
+    assert torch.isfinite(b3).all()
+    assert torch.equal(b3[0], b3[2]) and not torch.equal(b3[0], b3[1])                  # (1)
+    s1 = run(m8, n1, True)
+    assert torch.equal(run(m8, n1, False), s1)                                           # (2)
+    assert rel_err(s1[0], b3[0]) < 5e-2
+    dac = sampler.FoleyDAC(synth.synth_dac_state_dict(C.DAC48K, device=dev), dev)
+    m8.attach_dac(dac)
+    wave = m8.ctx.dac_decode(s1.to(dev))
+    assert wave.shape == (1, 1, 30 * 48000) and bool(torch.isfinite(wave).all())        # (4)
+    del m8
+    m16 = nodes.HunyuanModelLoader.pack_state_dict(sd, "bf16", "none", device=dev, cfg=cfg)
+    d = rel_err(run(m16, n1, True), s1)
+    print("C5: fp8_e4m3fn vs unquantised bf16 after %d steps: %.3e" % (steps, d))
+    assert 1e-4 < d < 0.2                                                                # (3)
+
+
 def test_xl_dimensions_forward(dev):
     """The xl model family (D=1408, 11 heads: N/K not multiples of 128/256) at depth 1+1 against the
     oracle - exercises the N-edge masking of every GEMM tile and the 11-head split."""
@@ -369,8 +415,139 @@ def test_sampler_node_end_to_end(dev):
     assert first["sample_rate"] == 48000 and first["waveform"].shape == (1, 1, 48000)
     assert batch["waveform"].shape == (2, 1, 48000) and batch["waveform"].dtype == torch.float32
     assert batch["waveform"].device.type == "cpu" and torch.equal(first["waveform"][0], batch["waveform"][0])
+    # the node's waveform against the CPU oracle on the same seed: generator -> noise -> loop -> decode
+    noise = torch.randn((2, 128, 50), generator=torch.Generator("cpu").manual_seed(55574), dtype=torch.float32)
+    with torch.inference_mode():
+        ref = O.sample_waveform(sd, synth.synth_dac_state_dict(C.DAC_TINY), c.heads, noise, cond, 10, 4.5, "euler",
+                                rates=C.DAC_TINY.rates)
+    assert rel_err(batch["waveform"], ref) < 1e-3
     _f2, batch2 = node.generate_audio(model, deps, **kw)
     assert rel_err(batch2["waveform"], batch["waveform"]) < 1e-6
     kw["seed"] = 1
     _f3, batch3 = node.generate_audio(model, deps, **kw)
     assert rel_err(batch3["waveform"], batch["waveform"]) > 1e-2
+
+
+def test_progress_callback_path(tiny):
+    """What ComfyUI actually runs: the eager loop with a per-iteration progress callback (one stream
+    sync per iteration, foley_sample with cb != NULL).  Must report every iteration in order and give
+    the same latents as the callback-free graph replay, bit for bit."""
+    sd, dsd, model, dac = tiny
+    cond = synth.synth_conditioning(C.TINY, 1.0, t2a=False)
+    visual = {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]}
+    text = {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]}
+    seen = []
+    gen = torch.Generator("cpu").manual_seed(7)
+    a1, _sr, l1 = sampler.denoise_process_with_generator(visual, text, 1.0, model, dac, 4.5, 12, 2, "heun-2", generator=gen,
+                                                        use_graph=False, progress=lambda i, n: seen.append((i, n)),
+                                                        return_latents=True)
+    assert seen == [(i + 1, 12) for i in range(12)]
+    gen = torch.Generator("cpu").manual_seed(7)
+    a2, _sr, l2 = sampler.denoise_process_with_generator(visual, text, 1.0, model, dac, 4.5, 12, 2, "heun-2", generator=gen,
+                                                        use_graph=True, return_latents=True)
+    assert torch.equal(l1, l2) and torch.equal(a1, a2)
+
+
+def test_zero_depth_single_joins_side_stream(dev):
+    """depth_single == 0: the side stream forked by the forward must still be joined (graph capture
+    would fail otherwise, eager mode would race) - ADVICE r1."""
+    c = C.DiTConfig(name="triple-only", depth_triple=1, depth_single=0, hidden=256, heads=2)
+    sd = synth.synth_dit_state_dict(c)
+    model = sampler.FoleyModel(c, sd, torch.float32, dev, dac_cfg=C.DAC_TINY)
+    dac = sampler.FoleyDAC(synth.synth_dac_state_dict(C.DAC_TINY), dev, C.DAC_TINY)
+    cond = synth.synth_conditioning(c, 1.0, t2a=False)
+    visual = {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]}
+    text = {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]}
+    outs = []
+    for graph in (True, False):
+        gen = torch.Generator("cpu").manual_seed(3)
+        _a, _sr, lat = sampler.denoise_process_with_generator(visual, text, 1.0, model, dac, 4.5, 4, 1, "euler", generator=gen,
+                                                             use_graph=graph, return_latents=True)
+        outs.append(lat.cpu())
+    assert torch.equal(outs[0], outs[1])
+    noise = torch.randn((1, 128, 50), generator=torch.Generator("cpu").manual_seed(3))
+    with torch.inference_mode():
+        ref = O.sample_latents(sd, c.heads, noise, cond["text"], cond["uncond_text"], cond["clip"], cond["sync"], 4, 4.5,
+                               "euler")
+    assert rel_err(outs[0], ref) < 1e-4
+
+
+def test_profile_forward_brackets(tiny):
+    """foley_profile_forward (bench.py's per-kernel roofline source): every op of the forward is
+    bracketed, call counts follow the block structure, FLOPs add up to the algorithmic count."""
+    sd, dsd, model, dac = tiny
+    cond = synth.synth_conditioning(C.TINY, 1.0, t2a=False)
+    plan = sampler.build_plan(model, {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]},
+                              {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]}, 50, 4.5, 4, 1, "euler")
+    model.ctx.prepare(plan)
+    lat = torch.randn(1, 128, 50, device=model.device)
+    prof, bracket_us = model.ctx.profile_forward(lat, it=1, repeats=2)
+    by = {e["label"]: e for e in prof}
+    nt, ns = C.TINY.depth_triple, C.TINY.depth_single
+    assert by["single.qkv GEMM + RMSNorm/RoPE head split"]["calls_per_forward"] == ns
+    assert by["single.layernorm+modulate (+pending split-K sum)"]["calls_per_forward"] == 2 * ns
+    assert by["triple.layernorm+modulate (+pending split-K sum)"]["calls_per_forward"] == 3 * nt
+    assert by["triple.self attention"]["calls_per_forward"] == nt and by["final.linear"]["calls_per_forward"] == 1
+    assert all(e["avg_us"] > 0 for e in prof) and 0 <= bracket_us < 100
+    # bracketed FLOPs == the per-forward algorithmic count minus the step-invariant (hoisted) part
+    D, M, Mv, Lt, H = 256, 2 * 50, 2 * 8, 77, 2
+    lin = 2 * D * D * (nt * 14 * (M + Mv) + ns * 36 * M) + 2 * (M * 128 * D * 2) + 2 * M * D * ns * 6 * D
+    att = 4 * H * 128 * (nt * 2 * ((50 + 8) ** 2 + (50 + 8) * Lt) + ns * 2 * 50 * 50)
+    total = sum(e["flop_per_launch"] * e["calls_per_forward"] for e in prof)
+    assert abs(total - (lin + att)) / (lin + att) < 1e-6
+    # profiling must not disturb the regular path
+    y1 = model.ctx.dit_forward(lat, 1)
+    y2 = model.ctx.dit_forward(lat, 1)
+    assert torch.equal(y1, y2)
+
+
+def test_single_rank_nccl_bundle_adoption(tiny, dev):
+    """The data-parallel setup under the REAL `nccl` (= RCCL) backend with world_size 1 on this GPU:
+    bundle layout from the config, fill on rank 0, ONE broadcast, arenas adopted from the bundle -
+    latents bit-identical to the directly packed model."""
+    import socket
+    import torch.distributed as dist
+    from foley_amd.host import distributed as D, packers
+    sd, dsd, model, dac = tiny
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        spec = D.bundle_spec(C.TINY, C.DAC_TINY, torch.float32, 1.0)
+        bundle = D.Bundle(spec, dev)
+        cond = synth.synth_conditioning(C.TINY, 1.0, t2a=False)
+        bundle.fill(packers.pack_dit(sd, C.TINY, torch.float32), packers.pack_dac(dsd, C.DAC_TINY), cond)
+        secs = D.broadcast_bundle(bundle)
+        assert secs >= 0.0
+    finally:
+        dist.destroy_process_group()
+    m2 = sampler.FoleyModel.from_arena(C.TINY, bundle.dit_arena(), torch.float32, dev, dac_cfg=C.DAC_TINY)
+    d2 = sampler.FoleyDAC.from_arena(bundle.dac_arena(), dev, C.DAC_TINY)
+    cv = bundle.cond_views()
+    outs = []
+    for mm, dd, cc in ((model, dac, cond), (m2, d2, cv)):
+        gen = torch.Generator("cpu").manual_seed(99)
+        a, _sr, lat = sampler.denoise_process_with_generator(
+            {"siglip2_feat": cc["clip"], "syncformer_feat": cc["sync"]},
+            {"text_feat": cc["text"], "uncond_text_feat": cc["uncond_text"]}, 1.0, mm, dd, 4.5, 6, 2, "euler",
+            generator=gen, return_latents=True)
+        outs.append((a.cpu(), lat.cpu()))
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][0], outs[1][0])
+
+
+def test_bench_single_rank_forced_dist(dev):
+    """bench.py under a launcher-style environment (RANK/WORLD_SIZE set, nccl process group, the single
+    broadcast) on one GPU: exits 0 and prints the JSON line with the per-kernel roofline."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611",
+               FOLEY_BENCH_FORCE_DIST="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--model", "tiny", "--duration", "1",
+                        "--steps", "1", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["config"]["collectives"] == 1 and out["value"] > 0
+    assert out["roofline"]["kernels"] and out["roofline"]["frac"] > 0

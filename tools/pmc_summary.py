@@ -1,11 +1,29 @@
-"""Aggregate rocprofv3 --pmc results (rocpd sqlite) per kernel: sum of each counter + launches."""
+"""Aggregate rocprofv3 --pmc results (rocpd sqlite) per kernel: sum of each counter + launches.
+
+    pmc_summary.py [--traffic-json OUT --iters N --workload TAG] db [db ...]
+
+--traffic-json writes the HBM traffic per loop iteration that bench.py reports as `roofline.traffic`:
+(2 x FETCH_SIZE + WRITE_SIZE) KiB over the kernels of the sampler loop / N traced iterations.  The
+factor 2 is the gfx950 correction of MI355X_MICROARCH.md ("FETCH_SIZE reports exactly 1/2 of the bytes
+of a wide coalesced streaming read"); the file records the kernel-source hash it was measured on and
+bench.py refuses to reuse it for other sources."""
+import argparse
+import json
+import os
 import sqlite3
 import sys
 from collections import defaultdict
 
+ap = argparse.ArgumentParser()
+ap.add_argument("dbs", nargs="+")
+ap.add_argument("--traffic-json")
+ap.add_argument("--iters", type=int, default=2)
+ap.add_argument("--workload", default="c2/bs1/bf16/xxl")
+a = ap.parse_args()
+
 agg = defaultdict(lambda: defaultdict(float))
 cnt = defaultdict(int)
-for path in sys.argv[1:]:
+for path in a.dbs:
     db = sqlite3.connect(path)
     seen = set()
     for name, disp, cname, val in db.execute("select kernel_name, dispatch_id, counter_name, value from counters_collection"):
@@ -25,3 +43,17 @@ for k in sorted(agg, key=lambda k: -sum(agg[k].values())):
     for c in counters:
         tot[c] += agg[k].get(c, 0)
 print("| **total** | | " + " | ".join(f"{tot[c]:.4g}" for c in counters) + " |")
+
+if a.traffic_json:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    # prepare-time launches (fp32 GEMM tiles, casts, gathers of foley_prepare) are excluded: loop kernels only
+    loop = {k: v for k, v in agg.items() if not k.startswith(("cast_kernel", "add_periodic", "qkv_split_kernel", "gemm_kernel<float"))}
+    fetch = sum(v.get("FETCH_SIZE", 0.0) for v in loop.values()) * 1024.0
+    write = sum(v.get("WRITE_SIZE", 0.0) for v in loop.values()) * 1024.0
+    json.dump({"kernel_src_sha": bench.kernel_src_sha(), "workload": a.workload, "iterations_traced": a.iters,
+               "fetch_bytes_raw": fetch, "write_bytes": write,
+               "hbm_bytes_per_loop_iteration": (2.0 * fetch + write) / a.iters,
+               "correction": "2 x FETCH_SIZE (gfx950 half-count of 16 B/lane coalesced reads) + WRITE_SIZE, KiB -> bytes; "
+                             "memory-side (fabric) requests of the 8 L2s, Infinity-Cache hits included"},
+              open(a.traffic_json, "w"))
