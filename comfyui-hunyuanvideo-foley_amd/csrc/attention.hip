@@ -414,16 +414,16 @@ int launch_attention(const AttnArgs& a, int out_dtype, hipStream_t st) {
     // enough 128-query workgroups to cover the chip => the wide kernel (operands read once per 128 queries)
     const dim3 gw(((a.Sq + 127) / 128) * a.H * a.Bq);
     if ((long)gw.x >= 256) {
-      if (out_dtype == FOLEY_BF16) hipLaunchKernelGGL(attn_bf16_wide_kernel<bf16_t>, gw, dim3(256), 0, st, a);
-      else hipLaunchKernelGGL(attn_bf16_wide_kernel<float>, gw, dim3(256), 0, st, a);
-    } else if (out_dtype == FOLEY_BF16) hipLaunchKernelGGL(attn_bf16_kernel<bf16_t>, grid1, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(attn_bf16_kernel<float>, grid1, dim3(256), 0, st, a);
+      if (out_dtype == FOLEY_BF16) FOLEY_LAUNCH(attn_bf16_wide_kernel<bf16_t>, gw, dim3(256), 0, st, a);
+      else FOLEY_LAUNCH(attn_bf16_wide_kernel<float>, gw, dim3(256), 0, st, a);
+    } else if (out_dtype == FOLEY_BF16) FOLEY_LAUNCH(attn_bf16_kernel<bf16_t>, grid1, dim3(256), 0, st, a);
+    else FOLEY_LAUNCH(attn_bf16_kernel<float>, grid1, dim3(256), 0, st, a);
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) return foley_set_err(hipGetErrorString(e2), __FILE__, __LINE__);
     return 0;
   }
-  if (out_dtype == FOLEY_F32) hipLaunchKernelGGL(attn_kernel<float>, grid, block, 0, st, a);
-  else if (out_dtype == FOLEY_BF16) hipLaunchKernelGGL(attn_kernel<bf16_t>, grid, block, 0, st, a);
+  if (out_dtype == FOLEY_F32) FOLEY_LAUNCH(attn_kernel<float>, grid, block, 0, st, a);
+  else if (out_dtype == FOLEY_BF16) FOLEY_LAUNCH(attn_kernel<bf16_t>, grid, block, 0, st, a);
   else return foley_set_err("attention: bad output dtype", __FILE__, __LINE__);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);

@@ -1,6 +1,7 @@
 // Shared device/host helpers for the Foley HIP library (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -81,6 +82,23 @@ __device__ __forceinline__ const float* rb_row(const RowBcast& b, int r) {
   if (b.mode == 1) p += ((long)(r / b.rows_per_cfg) * b.L + (r % b.L)) * b.ld;
   return p;
 }
+
+// Launch hook of the per-kernel profile (foley_profile_forward): when armed, the next launch carries
+// the two events as the dispatch's own start / stop timestamps (hipExtLaunchKernelGGL) - the same
+// begin/end stamps rocprofv3's kernel trace reports, without marker-packet overhead.
+struct FoleyProfHook {
+  hipEvent_t e0, e1;
+};
+extern thread_local FoleyProfHook g_foley_prof;
+#define FOLEY_LAUNCH(kernel, grid, block, lds, st, ...)                                                          \
+  do {                                                                                                           \
+    if (g_foley_prof.e0) {                                                                                       \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, st, g_foley_prof.e0, g_foley_prof.e1, 0, __VA_ARGS__);     \
+      g_foley_prof.e0 = nullptr;                                                                                 \
+    } else {                                                                                                     \
+      hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                             \
+    }                                                                                                            \
+  } while (0)
 
 #define FOLEY_CHECK_HIP(expr)                                         \
   do {                                                                \

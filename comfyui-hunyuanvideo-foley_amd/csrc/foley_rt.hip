@@ -13,6 +13,8 @@
 #include <unordered_map>
 #include <vector>
 
+thread_local FoleyProfHook g_foley_prof = {nullptr, nullptr};
+
 // --------------------------------------------------------------------------- errors
 static thread_local std::string g_err;
 int foley_set_err(const char* msg, const char* file, int line) {
@@ -580,18 +582,22 @@ static RowBcast rb_tok(const float* base, long ld, int rows_per_cfg, int L) {
   return RowBcast{base, ld, 1, rows_per_cfg, L, nullptr, 0};
 }
 
-// Launch bracket of the per-kernel profile (foley_profile_forward): two events around one launch,
-// tagged with the op's algorithmic FLOPs / bytes.  Compiles to the bare call when profiling is off.
+// Per-kernel profile (foley_profile_forward): the op's kernel launch carries two events as its own
+// start / stop timestamps (common.h FOLEY_LAUNCH), tagged with the op's algorithmic FLOPs / bytes.
 static int prof_begin(foley_ctx* c, hipStream_t st, const char* label, double flop, double bytes) {
   if (!c->prof.on) return 0;
   ProfRec r{label, flop, bytes, c->prof.get(), c->prof.get()};
-  HIPTRY(hipEventRecord(r.e0, st));
   c->prof.recs.push_back(r);
+  g_foley_prof = FoleyProfHook{r.e0, r.e1};   // consumed by the op's (first) kernel launch
   return 0;
 }
 static int prof_end(foley_ctx* c, hipStream_t st) {
   if (!c->prof.on) return 0;
-  HIPTRY(hipEventRecord(c->prof.recs.back().e1, st));
+  if (g_foley_prof.e0) {   // the op launched nothing: keep the record well-formed with a plain (empty) bracket
+    g_foley_prof.e0 = nullptr;
+    HIPTRY(hipEventRecord(c->prof.recs.back().e0, st));
+    HIPTRY(hipEventRecord(c->prof.recs.back().e1, st));
+  }
   return 0;
 }
 #define PROF(label, flop, bytes, call)            \
@@ -818,10 +824,11 @@ extern "C" int foley_dit_forward(foley_ctx* c, const float* latents, int iter, f
 }
 
 // --------------------------------------------------------------------------- per-kernel profile
-// `repeats` eager forwards at loop iteration `iter` with a HIP-event bracket around every launch
-// (recorded on the launch stream), aggregated by op label.  bracket_ms = mean elapsed time of an
-// EMPTY bracket (two back-to-back event records): the marker-processing cost every entry's time
-// includes once per call - subtract calls * bracket_ms for the kernel time proper.
+// `repeats` eager forwards at loop iteration `iter`; every op's kernel is launched with start / stop
+// events attached to the dispatch itself (hipExtLaunchKernelGGL on the launch stream), aggregated by
+// op label - total_ms is kernel time proper, the quantity rocprofv3's kernel trace reports.
+// bracket_ms = mean elapsed time of an EMPTY event bracket (two back-to-back hipEventRecord), reported
+// for reference only: it is NOT contained in total_ms.
 extern "C" int foley_profile_forward(foley_ctx* c, const float* latents, int iter, int repeats, foley_prof_entry* out,
                                      int cap, int* n_out, float* bracket_ms, void* stream_v) {
   if (!c || !latents || !out || !n_out || cap < 1 || repeats < 1) return FAIL(FOLEY_ERR_INVALID, "bad argument");
@@ -1154,6 +1161,7 @@ extern "C" int foley_op_gemm(const foley_gemm_desc* d, void* stream) {
   g.alpha = d->alpha; g.alphaC = d->alphaC > 0 ? d->alphaC : 1;
   g.ksplit = d->ksplit;
   g.rstride = d->rstride;
+  g.ldw = d->ldw;
   if (d->partials) {
     if (d->partial_slabs < 1) return FAIL(FOLEY_ERR_INVALID, "partials need partial_slabs >= 1");
     g.partials = d->partials; g.partial_stride = (long)d->M * d->N; g.partial_cap = d->partial_slabs;

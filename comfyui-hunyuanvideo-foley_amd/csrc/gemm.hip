@@ -483,7 +483,7 @@ int launch_one(const GemmArgs& g, const GemmArgs* g1, hipStream_t st) {
       r_ = true;
     }
   }
-  hipLaunchKernelGGL(k, dim3(tiles), dim3(WM * WN * 64), lds, st, pr);
+  FOLEY_LAUNCH(k, dim3(tiles), dim3(WM * WN * 64), lds, st, pr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);
   return 0;
@@ -512,6 +512,7 @@ int launch_tile(const GemmArgs& g, const GemmArgs* g1, int epi, hipStream_t st) 
 
 long long* g_gemm_dbg = nullptr;
 int g_gemm_dbg_mode = 0;
+int g_gemm_pf_dist = 0;   // L2 prefetch distance of the wave-specialised mainloop (K-slices beyond the ring)
 
 template <typename T>
 int check_args(const GemmArgs& g) {
@@ -528,12 +529,16 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
   GemmArgs g = g_in;
   g.dbg = g_gemm_dbg;
   g.dbg_mode = g_gemm_dbg_mode;
+  g.pf_dist = g_gemm_pf_dist;
+  if (g.ldw <= 0) g.ldw = g.K;
   GemmArgs g1s;
   const GemmArgs* g1 = nullptr;
   if (g1_in) {
     if (int rc = check_args<T>(*g1_in)) return rc;
     g1s = *g1_in;
     g1s.dbg = nullptr;
+    g1s.pf_dist = g_gemm_pf_dist;
+    if (g1s.ldw <= 0) g1s.ldw = g1s.K;
     g1 = &g1s;
   }
   constexpr int BK = 8 * Frag<T>::EPC;
@@ -592,21 +597,21 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
       }
       if (al & 15) return foley_set_err("fused head split: operands must be 16-byte aligned", __FILE__, __LINE__);
     }
-    if (!(tile == 1 || tile == 2 || tile == 5 || tile == 7 || tile == 8 || tile == 9 || tile == 15 || tile == 19))
+    if (!(tile == 1 || tile == 2 || tile == 5 || tile == 7 || tile == 8 || tile == 9 || tile == 15 || tile == 19 || tile == 25 || tile == 29))
       tile = (long)((g.M + 127) / 128) * (g.N / 128) >= 24 ? (sizeof(T) == 2 ? 15 : 5) : 2;
   }
   if (epi != EPI_GATE_RES || g.ksplit == 1 || (g.ksplit == 0 && sizeof(T) == 4)) {
     g.ksplit = 1;   // fp32 (parity) mode keeps a fixed summation order
   } else if (g.ksplit == 0) {
     // fill ~3 workgroups per CU, keep >= 12 K-slices per range
-    static const int bm[20] = {0, 128, 64, 64, 128, 128, 64, 128, 64, 256, 0, 128, 0, 64, 0, 128, 0, 0, 0, 256};
-    static const int bn[20] = {0, 128, 128, 64, 64, 128, 64, 128, 128, 128, 0, 128, 0, 64, 0, 128, 0, 0, 0, 128};
-    if (tile < 0 || tile >= 20 || bm[tile] == 0) return foley_set_err("GEMM: unknown tile", __FILE__, __LINE__);
+    static const int bm[30] = {0, 128, 64, 64, 128, 128, 64, 128, 64, 256, 0, 128, 0, 64, 0, 128, 0, 0, 0, 256, 0, 0, 0, 0, 0, 128, 0, 0, 0, 256};
+    static const int bn[30] = {0, 128, 128, 64, 64, 128, 64, 128, 128, 128, 0, 128, 0, 64, 0, 128, 0, 0, 0, 128, 0, 0, 0, 0, 0, 128, 0, 0, 0, 128};
+    if (tile < 0 || tile >= 30 || bm[tile] == 0) return foley_set_err("GEMM: unknown tile", __FILE__, __LINE__);
     const long blocks = (long)((g.M + bm[tile] - 1) / bm[tile]) * ((g.N + bn[tile] - 1) / bn[tile]);
     const int nk = (tile == 11 || tile == 13) ? 3 * (g.tapC / BK) / 3 : g.K / BK;   // conv3 splits over channel chunks
     // small tiles want ~3 workgroups per CU; the large, efficient tiles only split when they
     // cannot even cover the chip once (the fp32 atomics are not free)
-    const long target = (tile == 1 || tile == 5 || tile == 7 || tile == 9 || tile == 11 || tile == 15 || tile == 19) ? 192 : (tile == 13 ? 512 : 768);
+    const long target = (tile == 1 || tile == 5 || tile == 7 || tile == 9 || tile == 11 || tile == 15 || tile == 19 || tile == 25 || tile == 29) ? 192 : (tile == 13 ? 512 : 768);
     long want = (target + blocks - 1) / blocks;
     if (want > nk / 12) want = nk / 12;
     if (deferred) {   // one resident round of workgroups: as many K ranges as fit on 256 CUs (>= 4 slices each)
@@ -630,7 +635,7 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     // the direct-to-LDS loop addresses its operands through 32-bit buffer offsets
     auto extent = [&](GemmArgs& q) {
       const long rows_src = (long)((q.M + q.segV - 1) / q.segV) * q.segS;
-      const long ab = rows_src * q.lda * (long)sizeof(T), wb = (long)q.N * q.K * (long)sizeof(T);
+      const long ab = rows_src * q.lda * (long)sizeof(T), wb = (long)q.N * q.ldw * (long)sizeof(T);
       if (ab >= 0x7fff0000L || wb >= 0x7fff0000L) return false;
       q.a_bytes = (unsigned)ab;
       q.w_bytes = (unsigned)wb;
@@ -638,15 +643,17 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     };
     bool ok = extent(g);
     if (g1) ok = extent(g1s) && ok;
-    if (!ok && ((tile >= 5 && tile <= 9) || tile == 15 || tile == 19)) tile = (tile == 6) ? 3 : (tile == 8 ? 2 : 1);   // register-staged twins
+    if (!ok && ((tile >= 5 && tile <= 9) || tile == 15 || tile == 19 || tile == 25 || tile == 29)) tile = (tile == 6) ? 3 : (tile == 8 ? 2 : 1);   // register-staged twins
   }
   g.vec_out = gemm_vec_out_ok<T>(g, epi) ? 1 : 0;
   if (g1) g1s.vec_out = gemm_vec_out_ok<T>(g1s, epi) ? 1 : 0;
+  if ((g.ldw != g.K || (g1 && g1s.ldw != g1s.K)) && !(tile == 15 || tile == 19 || tile == 25 || tile == 29))
+    return foley_set_err("GEMM: padded weight rows (ldw != K) need a wave-specialised tile", __FILE__, __LINE__);
   if (tile == 11 || tile == 13) {
     if (g1) return foley_set_err("conv3 kernel has no two-problem form", __FILE__, __LINE__);
     return launch_gemm_conv3(g, sizeof(T) == 2 ? FOLEY_BF16 : FOLEY_F32, epi, tile == 11 ? 1 : 3, st);
   }
-  if (tile == 15 || tile == 19) {
+  if (tile == 15 || tile == 19 || tile == 25 || tile == 29) {
     if constexpr (sizeof(T) == 2) return launch_gemm_ws(g, g1, epi, tile, st);
     else return foley_set_err("GEMM: wave-specialised tiles are bf16 only", __FILE__, __LINE__);
   }
@@ -689,6 +696,8 @@ int launch_gemm_pair(const GemmArgs& g0, const GemmArgs& g1, int dtype, int epi,
 
 // Debug hook for tools/gemm_timeline.py (not part of include/foley_hip.h): every following GEMM
 // launch writes 4 wall-clock stamps per workgroup to `p` (device memory, 4 * grid * 8 bytes).
+extern "C" void foley_debug_gemm_prefetch(int dist) { g_gemm_pf_dist = dist < 0 ? 0 : dist; }
+
 extern "C" void foley_debug_gemm_timeline(void* p, int mode) {
   g_gemm_dbg = (long long*)p;
   g_gemm_dbg_mode = mode;

@@ -212,7 +212,7 @@ int launch_c3(const GemmArgs& g, hipStream_t st) {
   pr.g[0] = g;
   pr.g[1] = g;
   pr.tiles0 = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * (EPI == EPI_GATE_RES ? g.ksplit : 1);
-  hipLaunchKernelGGL(k, dim3(pr.tiles0), dim3(WM * WN * 64), lds, st, pr);
+  FOLEY_LAUNCH(k, dim3(pr.tiles0), dim3(WM * WN * 64), lds, st, pr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);
   return 0;

@@ -19,6 +19,8 @@
 // ChannelLastConv1d (mlp_layers.py:104-110), see include/foley_hip.h foley_op_gemm.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "gemm_common.h"
 
@@ -30,6 +32,14 @@ namespace {
 __device__ __forceinline__ void buf_lds16(const void* base, unsigned bytes, unsigned char* lds_wave_base, int voff, int soff) {
   const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
+// L2 prefetch: one dword per lane into a pinned scratch register (see the consumer loop); out-of-range
+// lanes touch nothing.
+__device__ __forceinline__ void buf_prefetch4(const void* base, unsigned bytes, int voff, int soff, int& sink) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+  const int so = __builtin_amdgcn_readfirstlane(soff);
+  asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "+v"(sink) : "v"(voff), "s"(r), "s"(so) : "memory");
 }
 
 template <int BM, int BN, int WM, int WN, int NS, int LW, int EPI>
@@ -94,7 +104,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
     for (int i = 0; i < BI; ++i) {
       const int rl = (lw * BI + i) * 8 + lr;
       const int n = n0 + rl;
-      vW[i] = (n < g.N) ? (int)((unsigned)n * (unsigned)(g.K * ESZ) + (unsigned)((lp ^ ((rl >> 1) & 7)) * 16)) : OOB;
+      vW[i] = (n < g.N) ? (int)((unsigned)n * (unsigned)(g.ldw * ESZ) + (unsigned)((lp ^ ((rl >> 1) & 7)) * 16)) : OOB;
     }
     auto set_tap = [&](int toff) {   // per-lane offsets of the current tap (VALU, once per tap)
 #pragma unroll
@@ -131,13 +141,29 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
     for (int s = 0; s < NS - 1; ++s)
       if (s < nk) issue(s);
     int stage = 0;
+    // dbg_mode 2 (tools/gemm_timeline.py --waits): the first loader wave accounts where it waits - for
+    // memory (s_waitcnt: the oldest slice has not landed) or at the barrier (the consumers are not done)
+    const bool acct = g.dbg && (g.dbg_mode & 0xff) == 2 && lw == 0;
+    long long t_mem = 0, t_bar = 0, t_start = acct ? (long long)__builtin_readcyclecounter() : 0;
     for (int kt = 0; kt < nk; ++kt) {
+      const long long ta = acct ? (long long)__builtin_readcyclecounter() : 0;
       // slice kt has landed once at most the NS-2 younger slices are still in flight
       if (kt + NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (AI + BI)) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const long long tb = acct ? (long long)__builtin_readcyclecounter() : 0;
       __builtin_amdgcn_s_barrier();  // slice kt visible to the consumers; they are done with slice kt-1
+      if (acct) {
+        const long long tc = (long long)__builtin_readcyclecounter();
+        if (kt > 0) { t_mem += tb - ta; t_bar += tc - tb; }   // the ring fill (kt == 0) is the prologue, stamped separately
+      }
       if (kt + NS - 1 < nk) issue(stage == 0 ? NS - 1 : stage - 1);
       stage = stage + 1 == NS ? 0 : stage + 1;
+    }
+    if (acct && lane == 0) {
+      g.dbg[(long)blockIdx.x * 4 + 0] = t_mem;
+      g.dbg[(long)blockIdx.x * 4 + 1] = t_bar;
+      g.dbg[(long)blockIdx.x * 4 + 2] = (long long)__builtin_readcyclecounter() - t_start;
+      g.dbg[(long)blockIdx.x * 4 + 3] = nk;
     }
     return;   // loaders take no part in the epilogue (a finished wave leaves the barrier count)
   }
@@ -163,6 +189,92 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
     b_row[j] = (wn * TN + j * 32 + fi) * 128;
     b_sw[j] = ((wn * TN + j * 32 + fi) >> 1) & 7;
   }
+  // ---- L2 prefetch stream (GemmArgs::pf_dist > 0).  The direct-to-LDS ring can only keep NS-1 slices
+  // in flight (LDS capacity), so with weights arriving cold from HBM (~2 us under load) a loader moves
+  // bytes-in-flight / latency = ~64 GB/s per CU - that, not the LDS or the matrix pipe, bounds the K
+  // loop at M = 500.  The consumer waves (their vmcnt is otherwise idle) therefore touch one dword of
+  // every 128-byte row line `pf_dist` slices beyond the ring: the line is in this XCD's L2 when the
+  // ring asks for it.  The loaded dword is never used; the register is pinned ("+v") so that the
+  // asynchronous write-back cannot land in a live register.
+  const int PF = g.pf_dist;
+  int pf_a = OOB, pf_w = OOB, pf_sink = 0;   // every consumer wave covers BM/NW rows of A and BN/NW rows of W
+  if (PF > 0) {
+    constexpr int RA = BM / NW, RB = BN / NW;
+    static_assert(RA <= 64 && RB <= 64, "prefetch: one line per lane");
+    const int r = m0 + wave * RA + lane;
+    if (lane < RA && r < g.M) {
+      const int b = g.segV >= g.M ? 0 : r / g.segV, q = r - b * g.segV;
+      pf_a = (int)((unsigned)(b * g.segS + q * (g.rstride > 1 ? g.rstride : 1)) * (unsigned)(g.lda * ESZ));
+    }
+    const int n = n0 + wave * RB + lane;
+    if (lane < RB && n < g.N) pf_w = (int)((unsigned)n * (unsigned)(g.ldw * ESZ));
+  }
+  int pf_k0 = (kt_begin + NS - 1 + PF) * BK, pf_c0 = 0, pf_toff = g.tap0;
+  if (PF > 0) {
+    const int tap = pf_k0 / g.tapC;
+    pf_c0 = pf_k0 - tap * g.tapC;
+    pf_toff = g.tap0 + tap * g.dil;
+  }
+  const int pf_end = (kt_begin + nk) * BK;
+  auto prefetch = [&]() {   // row validity of conv taps is ignored on purpose: a neighbouring row is real memory,
+    if (PF > 0) {           // the array ends are range-checked by the buffer resource
+      if (pf_k0 < pf_end) {
+        buf_prefetch4(g.A, g.a_bytes, pf_a, (pf_toff * (int)g.lda + pf_c0) * ESZ, pf_sink);
+        buf_prefetch4(g.W, g.w_bytes, pf_w, pf_k0 * ESZ, pf_sink);
+      }
+      pf_k0 += BK;
+      pf_c0 += BK;
+      if (pf_c0 >= g.tapC) {
+        pf_c0 = 0;
+        pf_toff += g.dil;
+      }
+    }
+  };
+  if constexpr (NW == 4) {
+    // ---- one consumer wave per SIMD (wave tile TM x TN >= 64 x 64): fewer, larger wave tiles cut the
+    // LDS fragment traffic per MFMA (128x128 tile: 64 KiB of reads per K-slice instead of 96 KiB with
+    // eight 32x64 waves).  Without a second wave on the SIMD to fill the matrix pipe while fragments
+    // are in flight, the loop is software-pipelined by one k-step across the barrier: fragment reads
+    // of step s+1 are issued before the MFMAs of step s, and the MFMAs of a slice's last step run
+    // after the next barrier, under the first reads of the next slice.
+    bf16x8 fa[2][FM], fb[2][FN];
+    auto rd = [&](auto set, int s, const unsigned char* As, const unsigned char* Bs) {
+      constexpr int S = decltype(set)::value;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) fa[S][i] = *(const bf16x8*)(As + a_row[i] + (((s * 2 + kh) ^ a_sw[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < FN; ++j) fb[S][j] = *(const bf16x8*)(Bs + b_row[j] + (((s * 2 + kh) ^ b_sw[j]) << 4));
+    };
+    auto mm = [&](auto set) {
+      constexpr int S = decltype(set)::value;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][i], fb[S][j], acc[i][j], 0, 0, 0);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of slice kt-1 has returned: its stage may be refilled
+      __builtin_amdgcn_s_barrier();
+      if (kt == 0) tl_stamp(g, 1);
+      const unsigned char* As = lds + stage * STAGE;
+      const unsigned char* Bs = As + BM * 128;
+      rd(S0{}, 0, As, Bs);
+      if (kt > 0) mm(S1{});          // last k-step of the previous slice
+      rd(S1{}, 1, As, Bs);
+      mm(S0{});
+      prefetch();
+      rd(S0{}, 2, As, Bs);
+      mm(S1{});
+      rd(S1{}, 3, As, Bs);
+      mm(S0{});
+      stage = stage + 1 == NS ? 0 : stage + 1;
+    }
+    if (nk > 0) mm(S1{});
+  } else {
   // Ping-pong between the two consumer waves of a SIMD (waves w and w + NW/2): after each barrier
   // the early wave reads its fragments while the late wave multiplies the slice it read in the
   // previous iteration, then they swap pipes - the LDS and the matrix core are both busy instead of
@@ -185,6 +297,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
     if (late) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (kt == 0) tl_stamp(g, 1);
+    prefetch();
     if (late && kt > 0) mma();
     const unsigned char* As = lds + stage * STAGE;
     const unsigned char* Bs = As + BM * 128;
@@ -199,6 +312,8 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
     stage = stage + 1 == NS ? 0 : stage + 1;
   }
   if (late && nk > 0) mma();
+  }
+  if (PF > 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink)::"memory");   // every prefetch has written back: the register is free again
   tl_stamp(g, 2);
   if constexpr (EPI == EPI_QKV_SPLIT) {
     gemm_epilogue_qkv<T, BM, BN, WM, WN>(g, acc, lds, m0, n0);
@@ -227,7 +342,7 @@ int launch_ws_one(const GemmArgs& g, const GemmArgs* g1, hipStream_t st) {
     if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);
     raised = true;
   }
-  hipLaunchKernelGGL(k, dim3(tiles), dim3((WM * WN + LW) * 64), lds, st, pr);
+  FOLEY_LAUNCH(k, dim3(tiles), dim3((WM * WN + LW) * 64), lds, st, pr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);
   return 0;
@@ -251,12 +366,15 @@ int launch_ws_tile(const GemmArgs& g, const GemmArgs* g1, int epi, hipStream_t s
 
 }  // namespace
 
-// tile: 15 = 128x128 (8 consumer + 4 loader waves), 19 = 256x128 (8 + 4); g / g1 fully resolved
+// tile: 15 = 128x128 (8 consumer + 4 loader waves), 19 = 256x128 (8 + 4), 25 / 29 = the same tiles with 4
+// consumer waves (64x64 / 128x64 per wave); g / g1 fully resolved
 // (ksplit, vec_out, operand extents) by gemm.hip's launcher
 int launch_gemm_ws(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hipStream_t st) {
   switch (tile) {
     case 15: return launch_ws_tile<128, 128, 4, 2, 5, 4>(g, g1, epi, st);   // 5 x 32 KiB ring = all 160 KiB of LDS
     case 19: return launch_ws_tile<256, 128, 4, 2, 3, 4>(g, g1, epi, st);
+    case 25: return launch_ws_tile<128, 128, 2, 2, 5, 4>(g, g1, epi, st);   // 4 consumer waves of 64x64 (one per SIMD) + 4 loaders
+    case 29: return launch_ws_tile<256, 128, 2, 2, 3, 4>(g, g1, epi, st);   // 4 consumer waves of 128x64
   }
   return foley_set_err("wave-specialised GEMM: unknown tile", __FILE__, __LINE__);
 }

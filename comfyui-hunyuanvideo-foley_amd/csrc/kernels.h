@@ -44,6 +44,8 @@ struct GemmArgs {
   const float* bias;  // [N] or null
   int M, N, K;
   long lda;           // elements between source rows of A
+  long ldw;           // elements between rows of W (>= K; set by the launcher to K when 0) - padded rows spread the
+                      // 128-byte K-slice lines of consecutive rows over the L2 channels
   int segV, segS;     // virtual / source rows per segment
   int taps, tapC, dil, tap0;
   int rstride;        // source rows advanced per virtual row (strided conv: tap t of row q reads q*rstride + tap0 + t*dil); 0 = 1
@@ -71,6 +73,7 @@ struct GemmArgs {
   int partial_cap;
   QkvSplitArgs qs;    // EPI_QKV_SPLIT: destination / norm / rotation description (qs.qkv, qs.M unused)
   int vec_out;        // set by the launcher: the problem qualifies for the LDS-transposed vector epilogue
+  int pf_dist;        // wave-specialised mainloop: L2 prefetch distance in K-slices beyond the LDS ring (0 = off; set by the launcher)
   int dbg_mode;
   long long* dbg;     // tools/gemm_timeline.py: 4 wall-clock stamps per workgroup (entry, first slice
                       // landed, K loop done, epilogue done); null in production

@@ -462,11 +462,11 @@ int launch_ln_mod_pair(const LnArgs& a0, const LnArgs& a1, int D, float eps, int
 #define FOLEY_LN(V)                                                                                        \
   {                                                                                                        \
     if (pend) {                                                                                            \
-      if (f32o) hipLaunchKernelGGL((ln_mod_kernel<float, V, true>), grid, block, 0, st, pr, D, eps);       \
-      else hipLaunchKernelGGL((ln_mod_kernel<bf16_t, V, true>), grid, block, 0, st, pr, D, eps);           \
+      if (f32o) FOLEY_LAUNCH((ln_mod_kernel<float, V, true>), grid, block, 0, st, pr, D, eps);       \
+      else FOLEY_LAUNCH((ln_mod_kernel<bf16_t, V, true>), grid, block, 0, st, pr, D, eps);           \
     } else {                                                                                               \
-      if (f32o) hipLaunchKernelGGL((ln_mod_kernel<float, V, false>), grid, block, 0, st, pr, D, eps);      \
-      else hipLaunchKernelGGL((ln_mod_kernel<bf16_t, V, false>), grid, block, 0, st, pr, D, eps);          \
+      if (f32o) FOLEY_LAUNCH((ln_mod_kernel<float, V, false>), grid, block, 0, st, pr, D, eps);      \
+      else FOLEY_LAUNCH((ln_mod_kernel<bf16_t, V, false>), grid, block, 0, st, pr, D, eps);          \
     }                                                                                                      \
   }
   if (need <= 2) FOLEY_LN(2)
@@ -511,8 +511,8 @@ int launch_qkv_split_pair(const QkvSplitArgs& a0, const QkvSplitArgs& a1, hipStr
   pr.blocks0 = nblk(a0);
   dim3 grid((unsigned)(pr.blocks0 + nblk(a1))), block(256);
   if (grid.x == 0) return 0;
-  if (a0.out_dtype == FOLEY_BF16) hipLaunchKernelGGL(qkv_split_kernel<bf16_t>, grid, block, 0, st, pr);
-  else hipLaunchKernelGGL(qkv_split_kernel<float>, grid, block, 0, st, pr);
+  if (a0.out_dtype == FOLEY_BF16) FOLEY_LAUNCH(qkv_split_kernel<bf16_t>, grid, block, 0, st, pr);
+  else FOLEY_LAUNCH(qkv_split_kernel<float>, grid, block, 0, st, pr);
   FOLEY_LAUNCH_CHECK();
   return 0;
 }
@@ -527,9 +527,9 @@ int launch_rows_add_act(const float* a, const RowBcast& v, int R, int D, int act
                         hipStream_t st) {
   const long n = (long)R * D;
   if (out_dtype == FOLEY_F32)
-    hipLaunchKernelGGL(rows_add_act_kernel<float>, dim3(grid1d(n, 256)), dim3(256), 0, st, a, v, R, D, act_silu, (float*)out);
+    FOLEY_LAUNCH(rows_add_act_kernel<float>, dim3(grid1d(n, 256)), dim3(256), 0, st, a, v, R, D, act_silu, (float*)out);
   else if (out_dtype == FOLEY_BF16)
-    hipLaunchKernelGGL(rows_add_act_kernel<bf16_t>, dim3(grid1d(n, 256)), dim3(256), 0, st, a, v, R, D, act_silu, (bf16_t*)out);
+    FOLEY_LAUNCH(rows_add_act_kernel<bf16_t>, dim3(grid1d(n, 256)), dim3(256), 0, st, a, v, R, D, act_silu, (bf16_t*)out);
   else return foley_set_err("rows_add_act: bad dtype", __FILE__, __LINE__);
   FOLEY_LAUNCH_CHECK();
   return 0;
@@ -539,9 +539,9 @@ int launch_add_periodic(const float* x, const float* pos, int R, int D, int peri
                         hipStream_t st) {
   const long n = (long)R * D;
   if (out_dtype == FOLEY_F32)
-    hipLaunchKernelGGL(add_periodic_kernel<float>, dim3(grid1d(n, 256)), dim3(256), 0, st, x, pos, R, D, period, (float*)out);
+    FOLEY_LAUNCH(add_periodic_kernel<float>, dim3(grid1d(n, 256)), dim3(256), 0, st, x, pos, R, D, period, (float*)out);
   else if (out_dtype == FOLEY_BF16)
-    hipLaunchKernelGGL(add_periodic_kernel<bf16_t>, dim3(grid1d(n, 256)), dim3(256), 0, st, x, pos, R, D, period, (bf16_t*)out);
+    FOLEY_LAUNCH(add_periodic_kernel<bf16_t>, dim3(grid1d(n, 256)), dim3(256), 0, st, x, pos, R, D, period, (bf16_t*)out);
   else return foley_set_err("add_periodic: bad dtype", __FILE__, __LINE__);
   FOLEY_LAUNCH_CHECK();
   return 0;
@@ -550,7 +550,7 @@ int launch_add_periodic(const float* x, const float* pos, int R, int D, int peri
 int launch_gather_rows(const float* src, const int* idx, int n_idx, int groups, int src_rows, int D, float* out,
                        hipStream_t st) {
   const long n = (long)groups * n_idx * D;
-  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid1d(n, 256)), dim3(256), 0, st, src, idx, n_idx, groups, src_rows, D, out);
+  FOLEY_LAUNCH(gather_rows_kernel, dim3(grid1d(n, 256)), dim3(256), 0, st, src, idx, n_idx, groups, src_rows, D, out);
   FOLEY_LAUNCH_CHECK();
   return 0;
 }
@@ -558,11 +558,11 @@ int launch_gather_rows(const float* src, const int* idx, int n_idx, int groups, 
 int launch_cast(const void* src, int sd, void* dst, int dd, long n, hipStream_t st) {
   dim3 g(grid1d(n, 256)), b(256);
   if (sd == FOLEY_F32 && dd == FOLEY_BF16)
-    hipLaunchKernelGGL((cast_kernel<float, bf16_t>), g, b, 0, st, (const float*)src, (bf16_t*)dst, n);
+    FOLEY_LAUNCH((cast_kernel<float, bf16_t>), g, b, 0, st, (const float*)src, (bf16_t*)dst, n);
   else if (sd == FOLEY_BF16 && dd == FOLEY_F32)
-    hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g, b, 0, st, (const bf16_t*)src, (float*)dst, n);
+    FOLEY_LAUNCH((cast_kernel<bf16_t, float>), g, b, 0, st, (const bf16_t*)src, (float*)dst, n);
   else if (sd == FOLEY_F32 && dd == FOLEY_F32)
-    hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, st, (const float*)src, (float*)dst, n);
+    FOLEY_LAUNCH((cast_kernel<float, float>), g, b, 0, st, (const float*)src, (float*)dst, n);
   else return foley_set_err("cast: unsupported dtype pair", __FILE__, __LINE__);
   FOLEY_LAUNCH_CHECK();
   return 0;
@@ -571,9 +571,9 @@ int launch_cast(const void* src, int sd, void* dst, int dd, long n, hipStream_t 
 int launch_latent_rows(const float* x, int clips, int C, int L, int ncfg, void* out, int out_dtype, hipStream_t st) {
   dim3 grid((L + 31) / 32, (C + 31) / 32, clips), block(256);
   if (out_dtype == FOLEY_F32)
-    hipLaunchKernelGGL(latent_rows_kernel<float>, grid, block, 0, st, x, clips, C, L, ncfg, (float*)out);
+    FOLEY_LAUNCH(latent_rows_kernel<float>, grid, block, 0, st, x, clips, C, L, ncfg, (float*)out);
   else if (out_dtype == FOLEY_BF16)
-    hipLaunchKernelGGL(latent_rows_kernel<bf16_t>, grid, block, 0, st, x, clips, C, L, ncfg, (bf16_t*)out);
+    FOLEY_LAUNCH(latent_rows_kernel<bf16_t>, grid, block, 0, st, x, clips, C, L, ncfg, (bf16_t*)out);
   else return foley_set_err("latent_rows: bad dtype", __FILE__, __LINE__);
   FOLEY_LAUNCH_CHECK();
   return 0;
@@ -581,10 +581,10 @@ int launch_latent_rows(const float* x, int clips, int C, int L, int ncfg, void* 
 
 int launch_solver_step(const StepArgs& a, hipStream_t st) {
   dim3 grid((a.L + 31) / 32, (a.C + 31) / 32, a.clips), block(256);
-  if (a.rows_dtype == FOLEY_BF16) hipLaunchKernelGGL(solver_step_kernel<bf16_t>, grid, block, 0, st, a);
-  else hipLaunchKernelGGL(solver_step_kernel<float>, grid, block, 0, st, a);
+  if (a.rows_dtype == FOLEY_BF16) FOLEY_LAUNCH(solver_step_kernel<bf16_t>, grid, block, 0, st, a);
+  else FOLEY_LAUNCH(solver_step_kernel<float>, grid, block, 0, st, a);
   FOLEY_LAUNCH_CHECK();
-  hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, st, a.step_ptr);
+  FOLEY_LAUNCH(step_increment_kernel, dim3(1), dim3(1), 0, st, a.step_ptr);
   FOLEY_LAUNCH_CHECK();
   return 0;
 }
@@ -592,14 +592,14 @@ int launch_solver_step(const StepArgs& a, hipStream_t st) {
 int launch_dac_in(const float* x, const float* w, const float* bias, const float* alpha, int B, int T, int C,
                   float* out0, float* out1, hipStream_t st) {
   if (C % 4) return foley_set_err("dac_in: channel count must be a multiple of 4", __FILE__, __LINE__);
-  hipLaunchKernelGGL(dac_in_kernel, dim3(grid1d((long)B * T * (C / 4), 256)), dim3(256), 0, st, x, w, bias, alpha, B, T, C,
+  FOLEY_LAUNCH(dac_in_kernel, dim3(grid1d((long)B * T * (C / 4), 256)), dim3(256), 0, st, x, w, bias, alpha, B, T, C,
                      out0, out1);
   FOLEY_LAUNCH_CHECK();
   return 0;
 }
 
 int launch_rows_to_planes(const float* rows, int B, int T, int C, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(rows_to_planes_kernel, dim3(grid1d((long)B * T * C, 256)), dim3(256), 0, st, rows, B, T, C, out);
+  FOLEY_LAUNCH(rows_to_planes_kernel, dim3(grid1d((long)B * T * C, 256)), dim3(256), 0, st, rows, B, T, C, out);
   FOLEY_LAUNCH_CHECK();
   return 0;
 }
@@ -608,7 +608,7 @@ int launch_dac_out(const float* s, const float* w, const float* bias, int B, int
                    hipStream_t st) {
   if (C % 4 || C > 256) return foley_set_err("dac_out: unsupported channel count", __FILE__, __LINE__);
   const size_t sh = (70 * (C + 1) + 7 * C) * sizeof(float);
-  hipLaunchKernelGGL(dac_out_kernel, dim3((T + 63) / 64, B), dim3(256), sh, st, s, w, bias, T, C, out);
+  FOLEY_LAUNCH(dac_out_kernel, dim3((T + 63) / 64, B), dim3(256), sh, st, s, w, bias, T, C, out);
   FOLEY_LAUNCH_CHECK();
   return 0;
 }

@@ -69,7 +69,7 @@ class GemmDescC(C.Structure):
         ("rb", RowBcastC), ("res", C.c_void_p), ("alpha", C.c_void_p), ("alphaC", C.c_int32),
         ("dtype", C.c_int32), ("epilogue", C.c_int32), ("tile", C.c_int32), ("ksplit", C.c_int32),
         ("partials", C.c_void_p), ("partial_slabs", C.c_int32), ("ksplit_used", C.POINTER(C.c_int32)),
-        ("qkv", C.POINTER(QkvSplitDescC)), ("rstride", C.c_int32),
+        ("qkv", C.POINTER(QkvSplitDescC)), ("rstride", C.c_int32), ("ldw", C.c_int64),
     ]
 
 
@@ -282,8 +282,8 @@ class FoleyContext:
         return out
 
     def profile_forward(self, latents: torch.Tensor, it: int = 0, repeats: int = 2):
-        """Per-op HIP-event profile of the eager DiT forward: list of dicts (label, calls_per_forward, avg_us
-        with the empty-bracket cost removed, flop / bytes per launch) + the bracket cost in us."""
+        """Per-op HIP-event profile of the eager DiT forward: list of dicts (label, calls_per_forward, avg_us =
+        the dispatch's own start->stop time, flop / bytes per launch) + the cost of an empty event bracket in us."""
         cap = 64
         arr = (ProfEntryC * cap)()
         n, br = C.c_int(0), C.c_float(0.0)
@@ -294,7 +294,7 @@ class FoleyContext:
         for e in arr[:n.value]:
             calls = max(e.calls, 1)
             out.append({"label": e.label.decode(), "calls_per_forward": e.calls / repeats,
-                        "avg_us": max(1e3 * e.total_ms / calls - 1e3 * br.value, 0.0),
+                        "avg_us": 1e3 * e.total_ms / calls,
                         "flop_per_launch": e.flop / calls, "bytes_per_launch": e.bytes / calls})
         return out, 1e3 * br.value
 
@@ -319,14 +319,15 @@ def rowbcast(t: Optional[torch.Tensor], mode: int = 0, rows_per_cfg: int = 1, L:
 
 def op_gemm(A, W, bias=None, *, M=None, epilogue=EPI_STORE_F32, out0=None, out1=None, ldc=None, conv=None,
             convT=None, rb: Optional[RowBcastC] = None, res=None, alpha=None, alphaC=1, tile=0, ksplit=0,
-            partials=None, qkv: Optional["QkvSplitDescC"] = None, sconv=None) -> int:
+            partials=None, qkv: Optional["QkvSplitDescC"] = None, sconv=None, lda: Optional[int] = None,
+            ldw: Optional[int] = None, NK=None) -> int:
     """Thin wrapper over foley_op_gemm.  conv=(seg, C, taps, dil) ; convT=(Tin, Cin, stride, Cout) ;
     sconv=(Tin, Cin, stride): strided conv k=2*stride, pad ceil(stride/2) over clips of Tin rows.
     partials: fp32 [slabs, M, N] workspace for the deferred split-K of the gated-residual epilogue.
     Returns the K split the launcher used."""
     lib = load_library()
     d = GemmDescC()
-    N, K = W.shape
+    N, K = NK if NK is not None else W.shape      # NK: logical shape when W / A are row-padded storage (lda / ldw)
     d.A, d.W, d.bias = _ptr(A), _ptr(W), _ptr(bias) if bias is not None else None
     d.N, d.K = N, K
     d.dtype, d.epilogue, d.tile, d.ksplit = dt_of(W), epilogue, tile, ksplit
@@ -358,6 +359,10 @@ def op_gemm(A, W, bias=None, *, M=None, epilogue=EPI_STORE_F32, out0=None, out1=
         d.osegV, d.out_seg, d.out_row, d.out_shift, d.out_check = d.M, 0, (ldc or N), 0, 0
     if epilogue == EPI_SILUGATE_T and ldc is None and convT is None:
         d.out_row = N // 2
+    if lda is not None:
+        d.lda = lda
+    if ldw is not None:
+        d.ldw = ldw
     d.out0, d.out1 = _ptr(out0) if out0 is not None else None, _ptr(out1) if out1 is not None else None
     if rb is not None:
         d.rb = rb

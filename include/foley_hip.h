@@ -121,11 +121,12 @@ int foley_dac_encode(foley_ctx* ctx, const float* wave, int clips, int T, int en
                      int n_rates, float* params, void* stream);
 
 /* Per-kernel profile of the DiT forward (bench.py's live roofline): runs `repeats` EAGER forwards at loop
- * iteration `iter` with a HIP-event bracket around every launch and aggregates by op.  `calls`,
- * `total_ms`, `flop` (algorithmic FLOPs: 2*M*N*K per contraction, 4*B*H*Sq*Skv*128 per attention) and
- * `bytes` (operands + result, read/written once) are totals over all repeats.  *bracket_ms = elapsed
- * time of an empty bracket (event-marker cost contained once per call in total_ms).  Replaces
- * nothing in the reference: it is the measurement hook SURVEY 8(d) asks for. */
+ * iteration `iter`, every op's kernel launched with start / stop events attached to the dispatch itself
+ * (hipExtLaunchKernelGGL on `stream`), and aggregates by op.  `calls`, `total_ms` (kernel time proper),
+ * `flop` (algorithmic FLOPs: 2*M*N*K per contraction, 4*B*H*Sq*Skv*128 per attention) and `bytes`
+ * (operands + result, read/written once) are totals over all repeats.  *bracket_ms = elapsed time of
+ * an empty hipEventRecord bracket, for reference (not contained in total_ms).  Replaces nothing in
+ * the reference: it is the measurement hook SURVEY 8(d) asks for. */
 typedef struct foley_prof_entry {
   char label[80];
   int32_t calls;
@@ -182,6 +183,7 @@ typedef struct foley_gemm_desc {
   /* epilogue 7 (fused head split): N = nK*H*128, out0 unused, results go to qkv->dst[] */
   const foley_qkv_split_desc* qkv;
   int32_t rstride; /* source rows advanced per virtual row (strided conv, dac.py:55-61); 0 or 1 = dense */
+  int64_t ldw;     /* elements between rows of W (0 = K); > K for row-padded weight storage (wave-specialised tiles) */
 } foley_gemm_desc;
 
 int foley_op_gemm(const foley_gemm_desc* d, void* stream);

@@ -26,11 +26,18 @@ ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--check", action="store_true")
 ap.add_argument("--conv", action="store_true", help="treat K as 3*C of a channels-last conv k=3 over clips of 250 tokens")
+ap.add_argument("--pf", default="0", help="comma list of L2 prefetch distances (K-slices beyond the ring) for the wave-specialised tiles")
+ap.add_argument("--pad", default="0", help="comma list: row padding (elements) of BOTH operands' storage (lda = C + pad, ldw = K + pad)")
 ap.add_argument("--ksplits", default="", help="comma list: benchmark the gated-residual epilogue with these K splits")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 tiles = [int(t) for t in a.tiles.split(",")]
+import ctypes as _C
+_lib = rt.load_library()
+_lib.foley_debug_gemm_prefetch.argtypes = [_C.c_int]
+_lib.foley_debug_gemm_prefetch.restype = None
+pfs = [int(v) for v in a.pf.split(",")]
 print(f"M={a.m} dtype={a.dtype}")
 for name in a.shapes.split(","):
     N, K = SHAPES[name]
@@ -68,9 +75,22 @@ for name in a.shapes.split(","):
                 line += f" t{t}k{ksp}:{us:6.1f}us {2 * a.m * N * K / us / 1e6:4.0f}TF |"
         print(line, flush=True)
         continue
-    for t in tiles:
+    for t, pf, pad in [(t, pf, pad) for t in tiles for pf in pfs for pad in [int(v) for v in a.pad.split(",")]]:
+        _lib.foley_debug_gemm_prefetch(pf)
+        if pad:      # row-padded copies of the same operands
+            Ca = A.shape[1]
+            Ap = torch.zeros(a.m, Ca + pad, device=dev, dtype=dt)
+            Ap[:, :Ca] = A
+            Wps = []
+            for W in Ws:
+                Wp = torch.zeros(N, K + pad, device=dev, dtype=dt)
+                Wp[:, :K] = W
+                Wps.append(Wp)
+            run = lambda i: rt.op_gemm(Ap, Wps[i % ncopy], None, out0=out, tile=t, lda=Ca + pad, ldw=K + pad, NK=(N, K), M=a.m, **ckw)
+        else:
+            run = lambda i: rt.op_gemm(A, Ws[i % ncopy], None, out0=out, tile=t, **ckw)
         try:
-            rt.op_gemm(A, Ws[0], None, out0=out, tile=t, **ckw)
+            run(0)
             torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001
             line += f" t{t}: ERR({str(e)[-40:]})"
@@ -81,10 +101,12 @@ for name in a.shapes.split(","):
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.reps)]
         for i, (e0, e1) in enumerate(evs):
             e0.record()
-            rt.op_gemm(A, Ws[i % ncopy], None, out0=out, tile=t, **ckw)
+            run(i)
             e1.record()
         torch.cuda.synchronize()
         ts = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
         us = ts[len(ts) // 2] * 1e3
-        line += f" t{t}:{us:7.1f}us {2 * a.m * N * K / us / 1e6:6.0f}TF{err} |"
+        line += f" t{t}p{pf}d{pad}:{us:6.1f}us {2 * a.m * N * K / us / 1e6:5.0f}TF{err} |"
+        if pad:
+            del Wps, Ap
     print(line, flush=True)

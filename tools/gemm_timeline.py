@@ -30,6 +30,7 @@ ap.add_argument("--brief", action="store_true")
 ap.add_argument("--fused-qkv", action="store_true", help="fused head-split epilogue (shape qkv: 3 x 12 heads, clips of 250 tokens)")
 ap.add_argument("--ablate", type=int, default=0, help="debug bits: 1 no MFMA, 2 no fragment reads, 4 no global->LDS loads (glds kernels)")
 ap.add_argument("--conv", action="store_true")
+ap.add_argument("--waits", action="store_true", help="wave-specialised tiles: where the first loader wave of every workgroup waits (memory vs consumers)")
 ap.add_argument("--warm", action="store_true", help="measure with the weight matrix just used (L2 / Infinity-Cache warm)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -82,6 +83,19 @@ for tile in [int(v) for v in a.tile.split(",")]:
         for W in Ws[:3]:
             run(W, tile, ksplit)
         torch.cuda.synchronize()
+        if a.waits:
+            dbg = torch.zeros(8192 * 4, dtype=torch.int64, device=dev)
+            lib.foley_debug_gemm_timeline(C.c_void_p(dbg.data_ptr()), 2)
+            run(Ws[3 % len(Ws)], tile, ksplit)
+            torch.cuda.synchronize()
+            lib.foley_debug_gemm_timeline(None, 0)
+            t = dbg.view(-1, 4).cpu().double()
+            t = t[t[:, 3] > 0]
+            per = t[:, :3] / (t[:, 3:4] - 1).clamp(min=1)
+            print(f"{a.shape:5s} t{tile}k{ksplit}: wgs {len(t):4d} slices {int(t[0, 3])} | per slice (cycles): loader waits for memory p50 "
+                  f"{float(per[:, 0].median()):6.0f} (max {float(per[:, 0].max()):6.0f}), at the barrier for the consumers p50 "
+                  f"{float(per[:, 1].median()):6.0f} (max {float(per[:, 1].max()):6.0f}); loop p50 {float(per[:, 2].median()):6.0f} cycles/slice", flush=True)
+            continue
         spans = []
         for rep in range(5):
             dbg = torch.zeros(8192 * 4, dtype=torch.int64, device=dev)
