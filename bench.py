@@ -349,12 +349,12 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
                                "unit": "bytes per loop iteration (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes on these kernel sources)"}
         except Exception:
             pass
-        dom = kernels[0] if kernels else None
+        dom = next((k for k in kernels if k["gflop_per_launch"] > 0), None)   # largest time per iteration among the MFMA kernels
         roof = {"bound": "mfma", "peak": peak, "unit": "TFLOP/s",
                 "achieved": dom["tflops"] if dom else loop_tf, "frac": dom["frac"] if dom else loop_tf / peak,
                 "kernel": dom["name"] if dom else "whole sampler loop",
-                "launch": ("dominant kernel of the loop (largest time per iteration): algorithmic FLOPs of one launch / its HIP-event "
-                           "bracket on the launch stream, eager forward at iteration 25, after the timed region"),
+                "launch": ("dominant kernel of the loop (largest time per iteration): algorithmic FLOPs of one launch / the dispatch's own "
+                           "start->stop HIP events on the launch stream (hipExtLaunchKernelGGL), eager forward at iteration 25, after the timed region"),
                 "traffic": traffic, "traffic_source": traffic_src,
                 "loop_frac": loop_tf / peak, "loop_achieved": loop_tf, "loop_ms": loop_ms, "dac_decode_ms": dac_ms,
                 "algorithmic_tflop_per_clip": f_clip / 1e12, "event_bracket_us": bracket_us, "kernels": kernels}

@@ -20,6 +20,7 @@ import os
 import torch
 
 from .host import config as _cfg
+from .host import encoders as _enc
 from .host import sampler as _sampler
 
 log = logging.getLogger("HunyuanVideo-Foley[MI355X]")
@@ -209,9 +210,11 @@ class HunyuanDependenciesLoader:
         deps = AttributeDict()
         deps["dac_model"] = _sampler.FoleyDAC(_load_state_dict(fp.get_full_path("foley", vae_name)), device)
         deps["synchformer_path"] = fp.get_full_path("foley", synchformer_name)
-        # Conditioning encoders (CLAP text, SigLIP2, Synchformer) are outside the HIP hot path
-        # (SURVEY §8f N2); they stay on PyTorch-ROCm and are created on first use.
-        deps["syncformer_model"] = None
+        # Conditioning encoders stay on PyTorch-ROCm and are created on first use: the
+        # Synchformer visual extractor is this repo's functional restatement over the checkpoint's
+        # tensors (host/encoders.py), SigLIP2 and CLAP come from `transformers` like in the reference
+        # (nodes.py:198-201).
+        deps["syncformer_model"] = None      # state dict of the visual extractor once loaded
         deps["siglip2_model"] = None
         deps["clap_tokenizer"] = None
         deps["clap_model"] = None
@@ -219,36 +222,48 @@ class HunyuanDependenciesLoader:
         return (deps,)
 
 
+SIGLIP2_REPO, CLAP_REPO = "google/siglip2-base-patch16-512", "laion/larger_clap_general"
+
+
 def _ensure_text_encoder(deps):
     if deps.get("clap_model") is None:
         from transformers import AutoTokenizer, ClapTextModelWithProjection
-        deps["clap_tokenizer"] = AutoTokenizer.from_pretrained("laion/larger_clap_general")
-        deps["clap_model"] = ClapTextModelWithProjection.from_pretrained("laion/larger_clap_general").eval()
+        deps["clap_tokenizer"] = AutoTokenizer.from_pretrained(CLAP_REPO)
+        deps["clap_model"] = ClapTextModelWithProjection.from_pretrained(CLAP_REPO).eval()
+    return deps
+
+
+def _ensure_visual_encoders(deps, device, dtype):
+    """SigLIP2 through transformers, Synchformer from the file the Dependencies Loader resolved.  Both
+    live on the GPU in the model's dtype like in the reference sampler (nodes.py:283-284)."""
+    if deps.get("siglip2_model") is None:
+        from transformers import AutoModel
+        deps["siglip2_model"] = AutoModel.from_pretrained(SIGLIP2_REPO).eval()
+    deps["siglip2_model"].to(device=device, dtype=dtype)
+    sync = deps.get("syncformer_model")
+    if sync is None:
+        path = deps.get("synchformer_path")
+        if not path:
+            raise RuntimeError("HUNYUAN_DEPS carries no Synchformer checkpoint (synchformer_path)")
+        sync = _load_state_dict(path)
+    if not isinstance(sync, dict):
+        raise RuntimeError("HUNYUAN_DEPS['syncformer_model'] must be the Synchformer state dict")
+    first = next(iter(sync.values()))
+    if first.device != torch.device(device) or first.dtype != dtype or any(not k.startswith("vfeat_extractor.") for k in sync):
+        sync = _enc.load_synchformer_state(sync, device, dtype)
+    deps["syncformer_model"] = sync
     return deps
 
 
 @torch.inference_mode()
-def encode_text_feat(prompts, deps, device):
+def encode_text_feat(prompts, deps, device, dtype=None):
     """CLAP last_hidden_state for [negative, positive] (feature_utils.py:133-138)."""
     _ensure_text_encoder(deps)
-    deps["clap_model"].to(device)
-    inputs = deps["clap_tokenizer"](prompts, padding=True, return_tensors="pt").to(device)
-    out = deps["clap_model"](**inputs, output_hidden_states=True, return_dict=True)
-    return out.last_hidden_state
+    deps["clap_model"].to(device=device, dtype=dtype) if dtype is not None else deps["clap_model"].to(device)
+    return _enc.encode_text_feat(deps["clap_tokenizer"], deps["clap_model"], prompts, device)
 
 
-def select_frames(image, duration, frame_rate):
-    """IMAGE [N,H,W,C] float 0-1 -> uint8 [T,C,H,W] frames at 8 fps and 25 fps (nodes.py:293-317)."""
-    total = image.shape[0]
-    n = int(duration * frame_rate)
-    if n > total:
-        image = torch.cat((image, image[-1:].repeat(n - total, 1, 1, 1)), dim=0)
-    else:
-        image = image[:n]
-    frames = (image * 255.0).byte().permute(0, 3, 1, 2)
-    i8 = torch.linspace(0, n - 1, int(duration * 8)).long()
-    i25 = torch.linspace(0, n - 1, int(duration * 25)).long()
-    return frames.index_select(0, i8), frames.index_select(0, i25)
+select_frames = _enc.select_frames
 
 
 # ----------------------------------------------------------------------------- NODE 3: sampler
@@ -299,14 +314,14 @@ class HunyuanFoleySampler:
             audio_len_in_s = features.get("audio_len_in_s", duration)
         elif image is not None:
             visual, text, audio_len_in_s = self._video_features(image, duration, frame_rate, prompt,
-                                                                negative_prompt, deps, device)
+                                                                negative_prompt, deps, device, model.dtype)
         else:
             # text-to-audio: learned "empty" visual rows (nodes.py:326-333)
             clip_len = int(duration * 8)
             sync_len = int(((int(duration * 25) - 16) // 8 + 1) * 8)
             visual = {"siglip2_feat": model.get_empty_clip_sequence(bs=1, len=clip_len),
                       "syncformer_feat": model.get_empty_sync_sequence(bs=1, len=sync_len)}
-            res = encode_text_feat([negative_prompt, prompt], deps, device)
+            res = encode_text_feat([negative_prompt, prompt], deps, device, model.dtype)
             text = {"text_feat": res[1:], "uncond_text_feat": res[:1]}
         pbar = None
         try:
@@ -323,10 +338,17 @@ class HunyuanFoleySampler:
         return (first, {"waveform": waveform_batch, "sample_rate": sr})
 
     @staticmethod
-    def _video_features(image, duration, frame_rate, prompt, negative_prompt, deps, device):
-        raise NotImplementedError(
-            "Video-to-audio conditioning needs the SigLIP2 and Synchformer encoders (SURVEY §8f N2); "
-            "pass precomputed features via `features=` or run text-to-audio.")
+    @torch.inference_mode()
+    def _video_features(image, duration, frame_rate, prompt, negative_prompt, deps, device, dtype=torch.float32):
+        """Video-to-Audio conditioning (nodes.py:290-320 + utils.py:262-292): resample the IMAGE batch to
+        8 fps / 25 fps, run SigLIP2 and the Synchformer visual extractor, CLAP for the two prompts.  The
+        audio length follows the sync stream: len(frames_25fps) / 25."""
+        _ensure_visual_encoders(deps, device, dtype)
+        f8, f25 = _enc.select_frames(image, duration, frame_rate)
+        visual, audio_len_in_s = _enc.video_features(f8, f25, deps["siglip2_model"], deps["syncformer_model"], device,
+                                                     model_dtype=dtype)
+        res = encode_text_feat([negative_prompt, prompt], deps, device, dtype)
+        return visual, {"text_feat": res[1:], "uncond_text_feat": res[:1]}, audio_len_in_s
 
 
 # ----------------------------------------------------------------------------- compat nodes

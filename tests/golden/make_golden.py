@@ -455,7 +455,41 @@ def g10():
     save("g10_dac_encode", **out)
 
 
-ALL = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10}
+def g11():
+    """Video-to-Audio conditioning: the reference's Synchformer visual extractor, built exactly as
+    Synchformer.__init__ builds it (synchformer.py:22-28: divided space-time MotionFormer + spatial
+    aggregation layer, Identity over time), loaded with synthesised weights and run as Synchformer.forward
+    runs it (:44-50) on two overlapping 16-frame segments - pins host/encoders.py::synchformer_segments;
+    plus the frame-index selection of nodes.py:293-317 for a few (clip length, duration, fps) cases."""
+    from foley_amd.host import encoders as E
+    mf = ref_harness.load_motionformer()
+    schema = E.synchformer_schema()
+    sd = synth.materialize(schema)
+    own = mf.state_dict()
+    p = "vfeat_extractor."
+    missing = [k for k in own if p + k not in sd and not k.startswith("patch_embed.proj")]
+    assert not missing, missing                      # the schema covers every tensor the forward touches
+    assert all(tuple(own[k[len(p):]].shape) == tuple(v.shape) for k, v in sd.items())
+    mf.load_state_dict({k[len(p):]: v for k, v in sd.items()}, strict=False)
+    frames = synth.synth_tensor("g11.frames", (24, 3, 224, 224), 0.55)          # pre-processed frames in ~[-1, 1]
+    segs = torch.stack([frames[0:16], frames[8:24]]).unsqueeze(0)                 # [B=1, S=2, T=16, C, H, W]
+    with torch.inference_mode():
+        vis = segs.permute(0, 1, 3, 2, 4, 5)                                      # Synchformer.forward (synchformer.py:46)
+        ref = mf(vis)                                                             # [1, 2, 8, 768]
+        mine = E.synchformer_segments(sd, segs[0])
+        feat = E.encode_video_with_sync(sd, frames)
+    check("synchformer segments", mine, ref[0], tol=2e-5)
+    check("encode_video_with_sync", feat, ref.reshape(1, 16, 768), tol=2e-5)
+    out = {"sync_feat": ref.reshape(1, 16, 768)}
+    for tag, (total, dur, fps) in {"a": (120, 5.0, 24.0), "b": (60, 5.0, 24.0), "c": (300, 10.0, 30.0), "d": (17, 1.0, 16.0)}.items():
+        n = int(dur * fps)                                                        # nodes.py:296-317, restated with the reference's expressions
+        out[f"idx8_{tag}"] = torch.linspace(0, n - 1, int(dur * 8)).long()
+        out[f"idx25_{tag}"] = torch.linspace(0, n - 1, int(dur * 25)).long()
+        out[f"case_{tag}"] = torch.tensor([total, dur, fps], dtype=torch.float64)
+    save("g11_v2a", **out)
+
+
+ALL = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11}
 
 
 def main():

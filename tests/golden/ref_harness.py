@@ -212,6 +212,83 @@ def load_reference():
     return ns
 
 
+def _install_synchformer_stubs() -> None:
+    """Third-party modules the reference's MotionFormer imports and this image lacks: omegaconf (a YAML
+    -> attribute-dict loader is all it uses) and timm's two helpers.  The reference's own files
+    (motionformer.py, video_model_builder.py, vit_helper.py, the YAML config) are executed as they are."""
+    import itertools
+
+    import torch
+    import yaml
+
+    if "omegaconf" not in sys.modules:
+        oc = _mod("omegaconf")
+
+        class _Node(dict):
+            def __getattr__(self, k):
+                try:
+                    return self[k]
+                except KeyError:
+                    raise AttributeError(k)
+
+            def __setattr__(self, k, v):
+                self[k] = v
+
+        def _wrap(o):
+            if isinstance(o, dict):
+                return _Node({k: _wrap(v) for k, v in o.items()})
+            if isinstance(o, list):
+                return [_wrap(v) for v in o]
+            return o
+
+        class OmegaConf:
+            @staticmethod
+            def load(path):
+                with open(path, "r", encoding="utf-8") as f:
+                    return _wrap(yaml.safe_load(f))
+
+        oc.OmegaConf = OmegaConf
+    if "timm" not in sys.modules:
+        timm = _mod("timm")
+        tl = _mod("timm.layers")
+        tml = _mod("timm.models")
+        tmll = _mod("timm.models.layers")
+
+        def trunc_normal_(t, mean=0.0, std=1.0, a=-2.0, b=2.0):
+            return torch.nn.init.trunc_normal_(t, mean=mean, std=std, a=a, b=b)
+
+        def to_2tuple(x):
+            return tuple(x) if isinstance(x, (tuple, list)) else tuple(itertools.repeat(x, 2))
+
+        for m in (tl, tmll):
+            m.trunc_normal_ = trunc_normal_
+            m.to_2tuple = to_2tuple
+        timm.layers, timm.models, tml.layers = tl, tml, tmll
+    if "requests" not in sys.modules:      # synchformer/utils.py imports it for its (unused) downloader
+        _mod("requests")
+
+
+def load_motionformer():
+    """The reference's Synchformer visual extractor, constructed exactly as Synchformer.__init__ does
+    (synchformer.py:22-28).  The package's __init__ pulls in torchaudio / the audio branch, so the
+    sub-package is registered by path and only motionformer.py (+ what IT imports) is executed."""
+    if "mf" in _CACHE:
+        return _CACHE["mf"]
+    load_reference()
+    _install_synchformer_stubs()
+    pkg_name = "hunyuanvideo_foley.models.synchformer"
+    pkg_dir = os.path.join(REFERENCE_ROOT, "hunyuanvideo_foley", "models", "synchformer")
+    if pkg_name not in sys.modules:
+        pkg = types.ModuleType(pkg_name)
+        pkg.__path__ = [pkg_dir]
+        sys.modules[pkg_name] = pkg
+    mf = importlib.import_module(pkg_name + ".motionformer")
+    model = mf.MotionFormer(extract_features=True, factorize_space_time=True, agg_space_module="TransformerEncoderLayer",
+                            agg_time_module="torch.nn.Identity", add_global_repr=False)
+    _CACHE["mf"] = model.eval()
+    return _CACHE["mf"]
+
+
 if __name__ == "__main__":
     ns = load_reference()
     print("reference imported:", ns.hifi.HunyuanVideoFoley, ns.dac.DAC,

@@ -552,3 +552,46 @@ def test_bench_single_rank_forced_dist(dev):
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["config"]["collectives"] == 1 and out["value"] > 0
     assert out["roofline"]["kernels"] and out["roofline"]["frac"] > 0
+
+
+def test_v2a_node_with_image_input(dev):
+    """The reference's example workflow wires a VHS IMAGE batch into the sampler (link 114): the node
+    must EXECUTE with an IMAGE input - frame resampling, SigLIP2 / Synchformer / CLAP on the GPU, then the
+    HIP sampler + DAC.  Encoders are small stand-ins / synthesised weights (no checkpoints in the image);
+    the result is checked against the CPU oracle fed with features computed on the CPU in fp32."""
+    from foley_amd import nodes
+    from foley_amd.host import encoders as E
+    from test_v2a_cpu import tiny_clap, tiny_siglip
+    c = C.TINY
+    sd = synth.synth_dit_state_dict(c)
+    dsd = synth.synth_dac_state_dict(C.DAC_TINY)
+    model = sampler.FoleyModel(c, sd, torch.float32, dev, dac_cfg=C.DAC_TINY)
+    tok, clap = tiny_clap()
+    sync_sd = synth.materialize(E.synchformer_schema())
+    deps = nodes.AttributeDict(dac_model=sampler.FoleyDAC(dsd, dev, C.DAC_TINY), siglip2_model=tiny_siglip(),
+                               syncformer_model={k: v.clone() for k, v in sync_sd.items()}, clap_tokenizer=tok, clap_model=clap)
+    g = torch.Generator().manual_seed(5)
+    image = torch.rand(30, 90, 120, 3, generator=g)                     # IMAGE [N,H,W,C] float 0-1: 30 frames at 24 fps
+    kw = dict(frame_rate=24.0, duration=2.0, prompt="rain on a tin roof", negative_prompt="noisy, harsh", cfg_scale=4.5,
+              steps=10, sampler="euler", batch_size=1, seed=55574, force_offload=False,
+              torch_compile_cfg={"backend": "inductor"}, block_swap_args={"blocks_to_swap": 30}, image=image)
+    first, batch = nodes.HunyuanFoleySampler().generate_audio(model, deps, **kw)
+    assert batch["waveform"].shape == (1, 1, 2 * 48000) and first["sample_rate"] == 48000
+    assert torch.isfinite(batch["waveform"]).all()
+    # features as the node computed them (GPU, Synchformer under fp16 autocast) vs an fp32 CPU evaluation
+    cpu_deps = nodes.AttributeDict(siglip2_model=tiny_siglip(), syncformer_model=sync_sd, clap_tokenizer=tok, clap_model=tiny_clap()[1])
+    vis_c, txt_c, alen = nodes.HunyuanFoleySampler._video_features(image, 2.0, 24.0, kw["prompt"], kw["negative_prompt"],
+                                                                   cpu_deps, torch.device("cpu"), torch.float32)
+    vis_g, txt_g, alen_g = nodes.HunyuanFoleySampler._video_features(image, 2.0, 24.0, kw["prompt"], kw["negative_prompt"],
+                                                                     deps, dev, torch.float32)
+    assert alen == alen_g == 2.0 and vis_g["siglip2_feat"].shape == (1, 16, 768) and vis_g["syncformer_feat"].shape == (1, 40, 768)
+    assert rel_err(vis_g["siglip2_feat"], vis_c["siglip2_feat"]) < 1e-3
+    assert rel_err(vis_g["syncformer_feat"], vis_c["syncformer_feat"]) < 2e-2      # fp16 autocast, like the reference
+    assert rel_err(txt_g["text_feat"], txt_c["text_feat"]) < 1e-3
+    # the whole node against the oracle on the node's own (GPU) features: isolates the HIP sampler from encoder precision
+    noise = torch.randn((1, 128, 100), generator=torch.Generator("cpu").manual_seed(55574), dtype=torch.float32)
+    cond = {"text": txt_g["text_feat"].float().cpu(), "uncond_text": txt_g["uncond_text_feat"].float().cpu(),
+            "clip": vis_g["siglip2_feat"].float().cpu(), "sync": vis_g["syncformer_feat"].float().cpu()}
+    with torch.inference_mode():
+        ref = O.sample_waveform(sd, dsd, c.heads, noise, cond, 10, 4.5, "euler", rates=C.DAC_TINY.rates)
+    assert rel_err(batch["waveform"], ref) < 1e-3
