@@ -101,6 +101,22 @@ def fp8_round_state_dict(state_dict, qmode: str, autocast: bool = True, param_dt
     return out
 
 
+def round_params(state_dict, param_dtype):
+    """The reference loads the checkpoint into parameters of the requested precision
+    (`foley_model.to(dtype)`, nodes.py:96-106): EVERY floating tensor - biases, norm gains, the sync
+    position table, the learned empty-feature rows - is rounded to bf16 / fp16, not only the matrices.
+    The packed arena keeps those small tensors in fp32 storage, so the rounding is applied to their
+    values here (exact for fp8 / already-rounded checkpoints)."""
+    if param_dtype == torch.float32:
+        return state_dict
+    out = {}
+    for k, v in state_dict.items():
+        if v.is_floating_point() and v.dtype not in (torch.float8_e4m3fn, torch.float8_e5m2):
+            v = v.to(param_dtype).to(torch.float32)
+        out[k] = v
+    return out
+
+
 def resolve_quantization(quantization: str, detected):
     """Reference nodes.py:109-122: 'auto' honours fp8 tensors found in the checkpoint, else e4m3fn
     (its e5m2 fallback is for compute capability < 9; gfx950 reports 9.x and implements OCP e4m3fn /
@@ -164,7 +180,7 @@ class HunyuanModelLoader:
     CATEGORY = "audio/HunyuanFoley"
 
     @staticmethod
-    def pack_state_dict(state_dict, precision="bf16", quantization="auto", device=None, cfg=None):
+    def pack_state_dict(state_dict, precision="bf16", quantization="auto", device=None, cfg=None, dac_cfg=None):
         """state dict -> FoleyModel.  fp16 is served by the bf16 kernels (same MFMA rate, fp32 accumulate)."""
         cfg = cfg or _cfg.load_yaml_config(os.path.join(_PKG_DIR, "configs", "hunyuanvideo-foley-xxl.yaml"))
         dtype = {"bf16": torch.bfloat16, "fp16": torch.bfloat16, "fp32": torch.float32}.get(precision)
@@ -174,8 +190,10 @@ class HunyuanModelLoader:
             dtype = torch.float32 if major == torch.float32 else torch.bfloat16
         qmode = resolve_quantization(quantization, detected)
         param_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}.get(precision, dtype)
-        sd = fp8_round_state_dict(state_dict, qmode, autocast=dtype != torch.float32, param_dtype=param_dtype)
-        return _sampler.FoleyModel(cfg, sd, dtype, device or _torch_device(), quantization=qmode)
+        sd = round_params(state_dict, param_dtype)
+        sd = fp8_round_state_dict(sd, qmode, autocast=dtype != torch.float32, param_dtype=param_dtype)
+        return _sampler.FoleyModel(cfg, sd, dtype, device or _torch_device(), dac_cfg=dac_cfg or _cfg.DAC48K,
+                                   quantization=qmode)
 
     def build_model(self, model_name, precision, quantization):
         fp = _folder_paths()

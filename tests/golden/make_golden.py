@@ -108,6 +108,27 @@ class ModelDict(dict):
             raise AttributeError(k)
 
 
+def run_ref_sampler(md, c, cond, dur, g, steps, bs, solver, gen):
+    """The reference's denoise_process_with_generator (utils.py:125-258) + its final latents, captured by
+    spying on FlowMatchDiscreteScheduler.step (the function only returns the decoded audio)."""
+    trace = []
+    orig_step = NS.sched.FlowMatchDiscreteScheduler.step
+
+    def spy(self, *a, **k):
+        r = orig_step(self, *a, **k)
+        trace.append(r[0])
+        return r
+    NS.sched.FlowMatchDiscreteScheduler.step = spy
+    try:
+        audio, _sr = NS.utils.denoise_process_with_generator(
+            {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]},
+            {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]},
+            dur, md, ref_cfg(c), g, steps, bs, solver, generator=gen)
+    finally:
+        NS.sched.FlowMatchDiscreteScheduler.step = orig_step
+    return audio, trace[-1].float().clone()
+
+
 # ----------------------------------------------------------------------------- G1
 def g1():
     out = {}
@@ -354,18 +375,16 @@ def g7():
             del m._text_len_fixed
         gen = torch.Generator("cpu").manual_seed(1234)
         with torch.inference_mode():
-            audio, _ = NS.utils.denoise_process_with_generator(
-                {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]},
-                {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]},
-                dur, md, ref_cfg(c), g, steps, bs, solver, generator=gen)
+            audio, ref_lat = run_ref_sampler(md, c, cond, dur, g, steps, bs, solver, gen)
         gen = torch.Generator("cpu").manual_seed(1234)
         noise = torch.randn((bs, 128, int(dur * 50)), generator=gen, dtype=torch.float32)
         with torch.inference_mode():
             lat = O.sample_latents(sd, c.heads, noise, cond["text"], cond["uncond_text"], cond["clip"],
                                    cond["sync"], steps, g, solver)
             wav = O.dac_decode(dsd, lat)
+        check(f"sampler {tag} latents", lat, ref_lat, 3e-5)
         check(f"sampler {tag}", wav, audio, 3e-5)
-        out[tag + "_noise"], out[tag + "_latents"] = noise, lat
+        out[tag + "_noise"], out[tag + "_latents"] = noise, ref_lat     # the REFERENCE's final latents (scheduler spy)
         out[tag + "_wave_s5"] = audio[..., ::5]   # subsampled waveform keeps the fixture small
     save("g7_sampler", **out)
 
@@ -489,7 +508,83 @@ def g11():
     save("g11_v2a", **out)
 
 
-ALL = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11}
+def g12():
+    """The BENCHMARKED precision pinned to the reference itself (not to the oracle on rounded weights): the
+    reference run exactly as its sampler runs a bf16 model - parameters `.to(bfloat16)`, inputs cast to the
+    parameter dtype, `torch.autocast(bfloat16)` (utils.py:222-234) - on this container's CPU:
+      fwd_*      one tiny-config forward on golden g5's inputs: bf16 output next to the fp32 output;
+      cfg_*      the 10-step CFG 4.5 Euler run of g7 ('cfg_euler', bs 2): final latents + waveform in
+                 bf16 next to the fp32 run (noise drawn in the MODEL dtype like the reference does);
+      c5_*       config C5's structure at reduced width: bf16 model wrapped by the reference's own
+                 `_wrap_fp8_inplace(fp8_e4m3fn)`, ONE forward at the 30 s shapes (La 1500, Lv 240,
+                 Ls 736, negative-prompt CFG pair = batch 2)."""
+    c = C.TINY
+    sd = synth.synth_dit_state_dict(c)
+    dsd = synth.synth_dac_state_dict(C.DAC_TINY)
+    out = {}
+    m32 = build_ref_dit(c, sd)
+    m16 = build_ref_dit(c, sd).to(torch.bfloat16)
+    bf = lambda t: t.to(torch.bfloat16)
+    # ---- single forward
+    g = torch.Generator().manual_seed(5)
+    La, Lv, Ls = C.lengths(1.0, c)
+    x = torch.randn(2, 128, La, generator=g)
+    t = torch.tensor([980.0, 980.0])
+    cond = torch.randn(2, 77, 768, generator=g)
+    clip = torch.randn(2, Lv, 768, generator=g)
+    sync = torch.randn(2, Ls, 768, generator=g)
+    with torch.inference_mode():
+        y32 = m32(x=x, t=t, cond=cond, clip_feat=clip, sync_feat=sync)["x"]
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            y16 = m16(x=bf(x), t=t, cond=bf(cond), clip_feat=bf(clip), sync_feat=bf(sync))["x"]
+    print(f"    forward: reference bf16 vs its own fp32: rel {rel(y16.float(), y32):.3e}")
+    out["fwd_y32"], out["fwd_y16"] = y32, y16.float()      # inputs = golden g5's a_* tensors (same generator seed / order)
+    # ---- 10-step CFG run, fp32 and bf16
+    dac = build_ref_dac(C.DAC_TINY, dsd)
+    cnd = synth.synth_conditioning(c, 1.0, t2a=False, sd=sd)
+    gen = torch.Generator("cpu").manual_seed(1234)
+    noise16 = torch.randn((2, 128, 50), generator=gen, dtype=torch.bfloat16)      # the bf16 draw of utils.py:114-121
+    orig_prep = NS.utils.prepare_latents_with_generator
+    for tag, m in (("b16", m16), ("f32", m32)):
+        if hasattr(m, "_text_len_fixed"):
+            del m._text_len_fixed
+        md = ModelDict(foley_model=m, dac_model=dac, device=torch.device("cpu"))
+        gen = torch.Generator("cpu").manual_seed(1234)
+        if tag == "f32":     # the fp32 model on the SAME (bf16-drawn) noise: the two runs differ by arithmetic only
+            NS.utils.prepare_latents_with_generator = lambda *a, **k: noise16.float().clone()
+        try:
+            with torch.inference_mode():
+                audio, lat = run_ref_sampler(md, c, cnd, 1.0, 4.5, 10, 2, "euler", gen)
+        finally:
+            NS.utils.prepare_latents_with_generator = orig_prep
+        out[f"cfg_{tag}_latents"], out[f"cfg_{tag}_wave_s5"] = lat, audio.float()[..., ::5]
+    out["cfg_noise_b16"] = noise16.float()
+    print(f"    10-step CFG on the same noise: reference bf16 vs fp32: latents rel {rel(out['cfg_b16_latents'], out['cfg_f32_latents']):.3e}, "
+          f"waveform rel {rel(out['cfg_b16_wave_s5'], out['cfg_f32_wave_s5']):.3e}")
+    # ---- C5 structure: bf16 + the reference's fp8 wrapper, 30 s shapes, one forward
+    La, Lv, Ls = C.lengths(30.0, c)
+    g = torch.Generator().manual_seed(55)
+    x5 = torch.randn(1, 128, La, generator=g).repeat(2, 1, 1)                      # CFG pair shares the latents
+    t5 = torch.tensor([620.0, 620.0])
+    cn5 = synth.synth_conditioning(c, 30.0, t2a=True, sd=sd)
+    pad = lambda a: F.pad(a, (0, 0, 0, 77 - a.shape[1]))
+    text5 = torch.cat([pad(cn5["uncond_text"]), pad(cn5["text"])])
+    clip5, sync5 = cn5["clip"].repeat(2, 1, 1), cn5["sync"].repeat(2, 1, 1)
+    m8 = build_ref_dit(c, sd).to(torch.bfloat16)
+    NS.utils._wrap_fp8_inplace(m8, quantization="fp8_e4m3fn", state_dict=None)
+    with torch.inference_mode():
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            y8 = m8(x=bf(x5), t=t5, cond=bf(text5), clip_feat=bf(clip5), sync_feat=bf(sync5))["x"]
+            y16b = m16(x=bf(x5), t=t5, cond=bf(text5), clip_feat=bf(clip5), sync_feat=bf(sync5))["x"]
+        y32b = m32(x=x5, t=t5, cond=text5, clip_feat=clip5, sync_feat=sync5)["x"]
+    print(f"    C5 shapes (La={La}, Lv={Lv}, Ls={Ls}): fp8-wrapped bf16 vs fp32 rel {rel(y8.float(), y32b):.3e}, "
+          f"plain bf16 vs fp32 {rel(y16b.float(), y32b):.3e}")
+    out["c5_t"] = t5                                          # x: torch.Generator().manual_seed(55) -> randn(1,128,1500)
+    out["c5_y8"], out["c5_y16"], out["c5_y32"] = y8.float()[1:, :, ::8], y16b.float()[1:, :, ::8], y32b[1:, :, ::8]   # cond half, every 8th frame
+    save("g12_bf16_ref", **out)
+
+
+ALL = {"g12": g12, "g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11}
 
 
 def main():
