@@ -219,7 +219,8 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
         return 2
 
     # ---- setup (untimed): rank 0 synthesises + packs INTO the bundle, ONE broadcast ships it
-    spec = D.bundle_spec(cfg, dac_cfg, dtype, duration)
+    store = packers.FP8_DTYPES.get(quant)          # fp8 weight storage stays fp8 in the arena (and in the broadcast)
+    spec = D.bundle_spec(cfg, dac_cfg, dtype, duration, weight_store=store)
     bundle = D.Bundle(spec, dev)
     sd = dsd = None
     if rank == 0:
@@ -228,7 +229,7 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
         dsd = synth.synth_dac_state_dict(dac_cfg, device=dev)
         cond = synth.synth_conditioning(cfg, duration, t2a=conf["t2a"], sd=sd, device=dev, seed=1)
         sdq = nodes.fp8_round_state_dict(sd, quant, autocast=True, param_dtype=dtype) if quant != "none" else sd
-        bundle.fill(packers.pack_dit(sdq, cfg, dtype), packers.pack_dac(dsd, dac_cfg), cond)
+        bundle.fill(packers.pack_dit(sdq, cfg, dtype, weight_store=store), packers.pack_dac(dsd, dac_cfg), cond)
         del sdq
     bcast_s = D.broadcast_bundle(bundle) if use_dist else 0.0
     cond = {k: v.clone() for k, v in bundle.cond_views().items()}
@@ -273,6 +274,8 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
             dist.barrier()
             torch.cuda.synchronize()
 
+    pieces = {}
+
     def measure(bs: int, noise_cpu: torch.Tensor, steps: int, warmup: int):
         """Host-to-host passes: pinned CPU noise in, CPU waveform out."""
         noise_cpu = noise_cpu.pin_memory()
@@ -288,11 +291,21 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
+            tq = time.perf_counter()
             audio = one_pass()
+            if os.environ.get("FOLEY_BENCH_TRACE"):      # per-pass host times (audio.cpu() has synchronised)
+                print(f"bench.py: pass {1e3 * (time.perf_counter() - tq):.1f} ms", file=sys.stderr)
         barrier()
         dt = time.perf_counter() - t0
-        # event-timed pieces of one more pass (loop / decode; recorded by the library on the launch stream)
+        # pieces of one more pass: precompute (host clock around a synchronised call), loop / decode (HIP events
+        # recorded by the library on the launch stream)
         lat = noise_cpu.to(dev).float().contiguous()
+        plan = sampler.build_plan(model, visual, text, la, GUIDANCE, STEPS_PER_CLIP, bs, "euler")
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        model.ctx.prepare(plan)
+        torch.cuda.synchronize()
+        pieces["prepare_ms"] = 1e3 * (time.perf_counter() - tp)
         model.ctx.sample(lat, use_graph=graph)
         torch.cuda.synchronize()
         loop_ms = model.ctx.last_elapsed_ms()
@@ -307,6 +320,7 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
         return dt, loop_ms, dac_ms
 
     dt, loop_ms, dac_ms = measure(bs_main, noise_all[lo:hi], a.steps, a.warmup)
+    prepare_ms = pieces.get("prepare_ms")
     f_clip = flops_clip(cfg, duration, STEPS_PER_CLIP, GUIDANCE)
     f_loop = f_clip - 2.30933e9 * la
     peak = PEAK_TFLOPS[a.precision]
@@ -356,7 +370,7 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
                 "launch": ("dominant kernel of the loop (largest time per iteration): algorithmic FLOPs of one launch / the dispatch's own "
                            "start->stop HIP events on the launch stream (hipExtLaunchKernelGGL), eager forward at iteration 25, after the timed region"),
                 "traffic": traffic, "traffic_source": traffic_src,
-                "loop_frac": loop_tf / peak, "loop_achieved": loop_tf, "loop_ms": loop_ms, "dac_decode_ms": dac_ms,
+                "loop_frac": loop_tf / peak, "loop_achieved": loop_tf, "loop_ms": loop_ms, "dac_decode_ms": dac_ms, "prepare_ms": prepare_ms,
                 "algorithmic_tflop_per_clip": f_clip / 1e12, "event_bracket_us": bracket_us, "kernels": kernels}
         out = {
             "metric": f"audio-sec/sec ({duration:g}s clip, 50-step Euler, CFG 4.5)",

@@ -11,7 +11,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;  // 16-byte stag
 typedef uint16_t bf16_t;  // storage type for bf16 in global/LDS memory
 
 // ---- dtype codes shared with include/foley_hip.h -------------------------------------------
-enum { FOLEY_F32 = 0, FOLEY_BF16 = 1, FOLEY_I32 = 2 };
+enum { FOLEY_F32 = 0, FOLEY_BF16 = 1, FOLEY_I32 = 2, FOLEY_F8E4M3 = 3, FOLEY_F8E5M2 = 4 };
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 // round-to-nearest-even, NaN preserved (matches torch .to(bfloat16))

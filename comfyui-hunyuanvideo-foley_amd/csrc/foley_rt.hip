@@ -58,6 +58,7 @@ struct Lin {  // a packed linear / conv-as-GEMM layer
   const void* w = nullptr;
   const float* b = nullptr;
   int N = 0, K = 0;
+  int wfmt = 0;   // 0: weights in the compute dtype; 1 / 2: stored fp8 e4m3fn / e5m2 (kernels.h GemmArgs::wfmt)
 };
 
 // Weights of the DiT forward resolved once per registration (foley_prepare) instead of ~600 string
@@ -161,7 +162,7 @@ struct foley_ctx {
   DevBuf dacP, dacQ, dacR, dacZ;
 };
 
-static size_t esize(int dtype) { return dtype == FOLEY_BF16 ? 2 : 4; }
+static size_t esize(int dtype) { return dtype == FOLEY_BF16 ? 2 : (dtype == FOLEY_F8E4M3 || dtype == FOLEY_F8E5M2) ? 1 : 4; }
 
 static int ctx_alloc(foley_ctx* c, size_t bytes, void** out) {
   void* p = nullptr;
@@ -252,7 +253,15 @@ constexpr int PART_CAP = 8;
 
 static int get_lin(foley_ctx* c, const std::string& name, int dtype, int N, int K, bool bias, Lin* out) {
   const void* w;
-  TRY(get_tensor(c, name + ".w", dtype, {N, K}, &w));
+  out->wfmt = 0;
+  auto it = c->tensors.find(name + ".w");
+  if (it != c->tensors.end() && dtype == FOLEY_BF16 && (it->second.dtype == FOLEY_F8E4M3 || it->second.dtype == FOLEY_F8E5M2)) {
+    // fp8 weight-only storage (reference FP8WeightWrapper): the GEMM widens in registers
+    out->wfmt = it->second.dtype == FOLEY_F8E4M3 ? 1 : 2;
+    TRY(get_tensor(c, name + ".w", it->second.dtype, {N, K}, &w));
+  } else {
+    TRY(get_tensor(c, name + ".w", dtype, {N, K}, &w));
+  }
   out->w = w;
   out->N = N;
   out->K = K;
@@ -270,6 +279,7 @@ static GemmArgs gemm_plain(const void* A, int M, const Lin& l, void* out, long l
   GemmArgs g{};
   g.A = A; g.W = l.w; g.bias = l.b;
   g.M = M; g.N = l.N; g.K = l.K; g.lda = l.K;
+  g.wfmt = l.wfmt;
   g.segV = M > 0 ? M : 1; g.segS = g.segV; g.taps = 1; g.tapC = l.K; g.dil = 1; g.tap0 = 0;
   g.out0 = out; g.out1 = nullptr;
   g.osegV = g.segV; g.out_seg = 0; g.out_row = ldc; g.out_shift = 0; g.out_check = 0;
@@ -1162,6 +1172,7 @@ extern "C" int foley_op_gemm(const foley_gemm_desc* d, void* stream) {
   g.ksplit = d->ksplit;
   g.rstride = d->rstride;
   g.ldw = d->ldw;
+  g.wfmt = d->wfmt;
   if (d->partials) {
     if (d->partial_slabs < 1) return FAIL(FOLEY_ERR_INVALID, "partials need partial_slabs >= 1");
     g.partials = d->partials; g.partial_stride = (long)d->M * d->N; g.partial_cap = d->partial_slabs;

@@ -42,7 +42,33 @@ __device__ __forceinline__ void buf_prefetch4(const void* base, unsigned bytes, 
   asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "+v"(sink) : "v"(voff), "s"(r), "s"(so) : "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int LW, int EPI>
+// fp8 -> bf16 (exact: every e4m3fn / e5m2 value is a bf16 value): 16 weights of one ds_read_b128 become
+// the B fragments of two consecutive k-steps.  v_cvt_scalef32_pk_bf16_{fp8,bf8} with scale 1.
+template <int WF>
+__device__ __forceinline__ void cvt_fp8x16(const u32x4 w, bf16x8& lo, bf16x8& hi) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  bf16x2 p[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if constexpr (WF == 1) {
+      p[2 * i] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)w[i], 1.0f, false);
+      p[2 * i + 1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)w[i], 1.0f, true);
+    } else {
+      p[2 * i] = __builtin_amdgcn_cvt_scalef32_pk_bf16_bf8((int)w[i], 1.0f, false);
+      p[2 * i + 1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_bf8((int)w[i], 1.0f, true);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    lo[2 * i] = p[i][0]; lo[2 * i + 1] = p[i][1];
+    hi[2 * i] = p[4 + i][0]; hi[2 * i + 1] = p[4 + i][1];
+  }
+}
+
+// WF: weight storage of the B operand - 0 bf16, 1 fp8 e4m3fn, 2 fp8 e5m2 (reference FP8WeightWrapper,
+// utils.py:316-366: storage fp8, `w.to(x.dtype)` per call, no scales).  fp8 rows are 64 bytes per K-slice:
+// the loaders move half the weight bytes (HBM -> L2 -> LDS) and the consumers widen to bf16 in registers.
+template <int BM, int BN, int WM, int WN, int NS, int LW, int EPI, int WF>
 __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const GemmPair pr) {
   using T = bf16_t;
   const int sel = (int)blockIdx.x >= pr.tiles0 ? 1 : 0;
@@ -50,9 +76,11 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
   constexpr int NW = WM * WN;
   constexpr int BK = 64, ESZ = 2, OOB = 0x7ffffff0;
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
-  constexpr int AI = BM / 8 / LW, BI = BN / 8 / LW;  // 1 KiB pieces per loader wave and K-slice
-  constexpr int STAGE = (BM + BN) * 128;
-  static_assert(BM % (8 * LW) == 0 && BN % (8 * LW) == 0, "bad tile");
+  constexpr int WSZ = WF ? 1 : 2;                    // bytes per weight element
+  constexpr int BROW = 64 * WSZ;                     // bytes of one W row per K-slice in LDS
+  constexpr int AI = BM / 8 / LW, BI = BN * BROW / 1024 / LW;  // 1 KiB pieces per loader wave and K-slice
+  constexpr int STAGE = BM * 128 + BN * BROW;
+  static_assert(BM % (8 * LW) == 0 && (BN * BROW) % (1024 * LW) == 0 && BI >= 1, "bad tile");
   static_assert((NS - 1) * (AI + BI) < 64, "vmcnt is a 6-bit counter");
   static_assert(EPI != EPI_SILUGATE_T || (FN % 2 == 0), "gated epilogue needs fragment pairs");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -102,9 +130,15 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
     int vW[BI];
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      const int rl = (lw * BI + i) * 8 + lr;
-      const int n = n0 + rl;
-      vW[i] = (n < g.N) ? (int)((unsigned)n * (unsigned)(g.ldw * ESZ) + (unsigned)((lp ^ ((rl >> 1) & 7)) * 16)) : OOB;
+      if constexpr (WF == 0) {
+        const int rl = (lw * BI + i) * 8 + lr;
+        const int n = n0 + rl;
+        vW[i] = (n < g.N) ? (int)((unsigned)n * (unsigned)(g.ldw * ESZ) + (unsigned)((lp ^ ((rl >> 1) & 7)) * 16)) : OOB;
+      } else {   // fp8: a 1 KiB piece is 16 rows of 64 bytes (4 chunks); same source-side XOR swizzle, 2 bits
+        const int rl = (lw * BI + i) * 16 + (lane >> 2);
+        const int n = n0 + rl;
+        vW[i] = (n < g.N) ? (int)((unsigned)n * (unsigned)g.ldw + (unsigned)(((lane & 3) ^ ((rl >> 2) & 3)) * 16)) : OOB;
+      }
     }
     auto set_tap = [&](int toff) {   // per-lane offsets of the current tap (VALU, once per tap)
 #pragma unroll
@@ -124,7 +158,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
     auto issue = [&](int stage) {
       unsigned char* As = lds + stage * STAGE;
       unsigned char* Bs = As + BM * 128;
-      const int sA = ld_c0 * ESZ, sW = ld_k0 * ESZ;   // scalar K offsets: no VALU on the issue path
+      const int sA = ld_c0 * ESZ, sW = ld_k0 * WSZ;   // scalar K offsets: no VALU on the issue path
 #pragma unroll
       for (int i = 0; i < AI; ++i) buf_lds16(g.A, g.a_bytes, As + (lw * AI + i) * 1024, vA[i], sA);
 #pragma unroll
@@ -186,9 +220,15 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
   }
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
-    b_row[j] = (wn * TN + j * 32 + fi) * 128;
-    b_sw[j] = ((wn * TN + j * 32 + fi) >> 1) & 7;
+    b_row[j] = (wn * TN + j * 32 + fi) * BROW;
+    b_sw[j] = WF ? ((wn * TN + j * 32 + fi) >> 2) & 3 : ((wn * TN + j * 32 + fi) >> 1) & 7;   // 64-bank LDS: 2 bf16 rows / 4 fp8 rows per bank row
   }
+  // K permutation inside a slice, shared by both operands (any consistent one is a valid contraction
+  // order): MFMA k-step s = 2t+u takes, for lane half kh, the 8 elements [32t + 16kh + 8u, +8) - so the 16
+  // fp8 weights a lane gets from ONE ds_read_b128 (chunk 2t+kh of its 64-byte row) feed k-steps 2t and
+  // 2t+1, and the bf16 operands read their 16-byte chunk 4t + 2kh + u.  The bf16-weight kernel uses the
+  // same order, which makes fp8 storage bit-identical to the same weights widened at load time.
+  auto a_chunk = [&](int s) { return 4 * (s >> 1) + 2 * kh + (s & 1); };
   // ---- L2 prefetch stream (GemmArgs::pf_dist > 0).  The direct-to-LDS ring can only keep NS-1 slices
   // in flight (LDS capacity), so with weights arriving cold from HBM (~2 us under load) a loader moves
   // bytes-in-flight / latency = ~64 GB/s per CU - that, not the LDS or the matrix pipe, bounds the K
@@ -238,12 +278,27 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
     // of step s+1 are issued before the MFMAs of step s, and the MFMAs of a slice's last step run
     // after the next barrier, under the first reads of the next slice.
     bf16x8 fa[2][FM], fb[2][FN];
-    auto rd = [&](auto set, int s, const unsigned char* As, const unsigned char* Bs) {
+    u32x4 rawb[FN];   // fp8 weights: the 16 values of one step pair, widened by cvtb()
+    auto rda = [&](auto set, int s, const unsigned char* As) {
       constexpr int S = decltype(set)::value;
 #pragma unroll
-      for (int i = 0; i < FM; ++i) fa[S][i] = *(const bf16x8*)(As + a_row[i] + (((s * 2 + kh) ^ a_sw[i]) << 4));
+      for (int i = 0; i < FM; ++i) fa[S][i] = *(const bf16x8*)(As + a_row[i] + ((a_chunk(s) ^ a_sw[i]) << 4));
+    };
+    auto rdb = [&](auto set, int s, const unsigned char* Bs) {   // bf16: the step's fragments; fp8: the pair's raw bytes (even s only)
+      constexpr int S = decltype(set)::value;
+      if constexpr (WF == 0) {
 #pragma unroll
-      for (int j = 0; j < FN; ++j) fb[S][j] = *(const bf16x8*)(Bs + b_row[j] + (((s * 2 + kh) ^ b_sw[j]) << 4));
+        for (int j = 0; j < FN; ++j) fb[S][j] = *(const bf16x8*)(Bs + b_row[j] + ((a_chunk(s) ^ b_sw[j]) << 4));
+      } else if (!(s & 1)) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) rawb[j] = *(const u32x4*)(Bs + b_row[j] + (((s + kh) ^ b_sw[j]) << 4));   // chunk 2t + kh, s = 2t
+      }
+    };
+    auto cvtb = [&]() {
+      if constexpr (WF != 0) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) cvt_fp8x16<WF>(rawb[j], fb[0][j], fb[1][j]);
+      }
     };
     auto mm = [&](auto set) {
       constexpr int S = decltype(set)::value;
@@ -262,14 +317,20 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
       if (kt == 0) tl_stamp(g, 1);
       const unsigned char* As = lds + stage * STAGE;
       const unsigned char* Bs = As + BM * 128;
-      rd(S0{}, 0, As, Bs);
+      rda(S0{}, 0, As);
+      rdb(S0{}, 0, Bs);
       if (kt > 0) mm(S1{});          // last k-step of the previous slice
-      rd(S1{}, 1, As, Bs);
+      cvtb();                        // fp8: steps 0 and 1 (after the last reader of both fragment sets was issued)
+      rda(S1{}, 1, As);
+      rdb(S1{}, 1, Bs);
       mm(S0{});
       prefetch();
-      rd(S0{}, 2, As, Bs);
+      rda(S0{}, 2, As);
+      rdb(S0{}, 2, Bs);
       mm(S1{});
-      rd(S1{}, 3, As, Bs);
+      cvtb();                        // fp8: steps 2 and 3
+      rda(S1{}, 3, As);
+      rdb(S1{}, 3, Bs);
       mm(S0{});
       stage = stage + 1 == NS ? 0 : stage + 1;
     }
@@ -283,6 +344,15 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
   constexpr bool PP = NW == 8;
   const bool late = PP && wave >= NW / 2;
   bf16x8 fa[4][FM], fb[4][FN];
+  u32x4 rawb[2][FN];   // fp8 weights: raw bytes of the two step pairs, widened right before the MFMAs
+  auto cvtb = [&]() {
+    if constexpr (WF != 0) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) cvt_fp8x16<WF>(rawb[t][j], fb[2 * t][j], fb[2 * t + 1][j]);
+    }
+  };
   auto mma = [&]() {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -298,19 +368,31 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
     __builtin_amdgcn_s_barrier();
     if (kt == 0) tl_stamp(g, 1);
     prefetch();
-    if (late && kt > 0) mma();
+    if (late && kt > 0) {
+      cvtb();
+      mma();
+    }
     const unsigned char* As = lds + stage * STAGE;
     const unsigned char* Bs = As + BM * 128;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
-      for (int i = 0; i < FM; ++i) fa[s][i] = *(const bf16x8*)(As + a_row[i] + (((s * 2 + kh) ^ a_sw[i]) << 4));
+      for (int i = 0; i < FM; ++i) fa[s][i] = *(const bf16x8*)(As + a_row[i] + ((a_chunk(s) ^ a_sw[i]) << 4));
+      if constexpr (WF == 0) {
 #pragma unroll
-      for (int j = 0; j < FN; ++j) fb[s][j] = *(const bf16x8*)(Bs + b_row[j] + (((s * 2 + kh) ^ b_sw[j]) << 4));
+        for (int j = 0; j < FN; ++j) fb[s][j] = *(const bf16x8*)(Bs + b_row[j] + ((a_chunk(s) ^ b_sw[j]) << 4));
+      } else if (!(s & 1)) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) rawb[s >> 1][j] = *(const u32x4*)(Bs + b_row[j] + (((s + kh) ^ b_sw[j]) << 4));
+      }
     }
-    if (!late) mma();
+    if (!late) {
+      cvtb();
+      mma();
+    }
     stage = stage + 1 == NS ? 0 : stage + 1;
   }
+  if (late && nk > 0) cvtb();
   if (late && nk > 0) mma();
   }
   if (PF > 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink)::"memory");   // every prefetch has written back: the register is free again
@@ -324,7 +406,257 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
   tl_stamp(g, 3);
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int LW, int EPI>
+// ---------------------------------------------------------------------------------------------
+// Wave-specialised, TAP-FUSED channels-last conv k=3 (pad 1): ChannelLastConv1d of the single-stream
+// blocks (mlp_layers.py:104-110: linear1, ConvMLP w1/w3, w2 - two thirds of the model's FLOPs).
+//
+// At M = 500 the K loop of the generic mainloop is bound by the bytes the 256 CUs pull out of the
+// L2s (~15 TB/s, tools/gemm_timeline.py --waits), and half of those bytes are the activation tile,
+// streamed once PER TAP.  Here K is walked channel-chunk major: the BM+2 activation rows of a
+// 64-channel chunk are staged ONCE (A buffers, 3 deep) and serve all three taps - the tap is a row
+// offset 0/1/2 into the staged rows - while the weights of the three taps stream through a ring
+// of 16 KiB (fp8: 8 KiB) slices.  Per MFMA a third fewer bytes leave the L2.  Rows whose neighbour
+// lies outside their clip read a zero row instead (the conv's padding).  Loader / consumer roles,
+// barrier protocol, K permutation, fp8 weight widening and epilogues are those of gemm_ws_kernel.
+template <int BM, int BN, int WM, int WN, int NSB, int LW, int EPI, int WF>
+__global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_conv3_kernel(const GemmPair pr) {
+  using T = bf16_t;
+  const GemmArgs& g = pr.g[0];
+  constexpr int NW = WM * WN;
+  constexpr int BK = 64, ESZ = 2, OOB = 0x7ffffff0;
+  constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
+  constexpr int WSZ = WF ? 1 : 2, BROW = 64 * WSZ;
+  constexpr int APC = (BM + 2 + 7) / 8;                 // 1 KiB pieces of an activation chunk (BM+2 rows)
+  constexpr int AI = (APC + LW - 1) / LW;               // per loader wave (the last wave's surplus pieces stay out of range)
+  constexpr int ABUF = AI * LW * 1024, NAB = 3;         // bytes per activation buffer, buffers
+  constexpr int BI = BN * BROW / 1024 / LW;             // weight pieces per loader wave and tap slice
+  constexpr int BSL = BN * BROW;                        // bytes per weight slice
+  constexpr int ZOFF = NAB * ABUF + NSB * BSL;          // 128 zero bytes
+  static_assert(NW == 8 && (BN * BROW) % (1024 * LW) == 0 && BI >= 1, "bad tile");
+  static_assert(NSB == 6, "the vmcnt schedule below is written for a 6-slice weight ring");
+  static_assert(4 * BI + 2 * AI < 64, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  const int tiles_m = (g.M + BM - 1) / BM;
+  const int tiles_n = (g.N + BN - 1) / BN;
+  int bid = (int)blockIdx.x;
+  {  // bijective XCD remap (see gemm_ws_kernel)
+    const int nwg = tiles_m * tiles_n * (EPI == EPI_GATE_RES ? g.ksplit : 1);
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  int ks = 0;
+  if constexpr (EPI == EPI_GATE_RES) {
+    ks = bid % g.ksplit;
+    bid /= g.ksplit;
+  }
+  const int tm = bid % tiles_m, tn = bid / tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  tl_stamp(g, 0);
+  const int C = g.tapC;
+  int kc_begin = 0, nkc = C / BK;   // channel chunks; K ranges of a split are chunk ranges
+  if constexpr (EPI == EPI_GATE_RES) {
+    const int tot = nkc;
+    kc_begin = (int)((long)tot * ks / g.ksplit);
+    nkc = (int)((long)tot * (ks + 1) / g.ksplit) - kc_begin;
+  }
+  const int nk = 3 * nkc;           // tap slices: slice kt = (chunk kt / 3, tap kt % 3)
+
+  if (wave >= NW) {
+    // ------------------------------------------------------------------ loader wave
+    const int lw = wave - NW;
+    const int lr = lane >> 3, lp = lane & 7;
+    int vA[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int j = (lw * AI + i) * 8 + lr;     // staged row j <-> activation row m0 - 1 + j
+      const int r = m0 - 1 + j;
+      vA[i] = (j < BM + 2 && r >= 0 && r < g.M) ? (int)((unsigned)r * (unsigned)(g.lda * ESZ) + (unsigned)((lp ^ ((j >> 1) & 7)) * 16)) : OOB;
+    }
+    int vW[BI];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      if constexpr (WF == 0) {
+        const int rl = (lw * BI + i) * 8 + lr;
+        const int n = n0 + rl;
+        vW[i] = (n < g.N) ? (int)((unsigned)n * (unsigned)(g.ldw * ESZ) + (unsigned)((lp ^ ((rl >> 1) & 7)) * 16)) : OOB;
+      } else {
+        const int rl = (lw * BI + i) * 16 + (lane >> 2);
+        const int n = n0 + rl;
+        vW[i] = (n < g.N) ? (int)((unsigned)n * (unsigned)g.ldw + (unsigned)(((lane & 3) ^ ((rl >> 2) & 3)) * 16)) : OOB;
+      }
+    }
+    // issue slice `sl` (local index): its weight slice, and - for tap 0 - the activation chunk
+    auto issue = [&](int sl) {
+      const int c = sl / 3, tap = sl - 3 * c;
+      const int ch = (kc_begin + c) * BK;
+      if (tap == 0) {
+        unsigned char* Ab = lds + (c % NAB) * ABUF;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) buf_lds16(g.A, g.a_bytes, Ab + (lw * AI + i) * 1024, vA[i], ch * ESZ);
+      }
+      unsigned char* Bs = lds + NAB * ABUF + (sl % NSB) * BSL;
+      const int sW = (tap * C + ch) * WSZ;
+#pragma unroll
+      for (int i = 0; i < BI; ++i) buf_lds16(g.W, g.w_bytes, Bs + (lw * BI + i) * 1024, vW[i], sW);
+    };
+#pragma unroll
+    for (int sl = 0; sl < NSB - 1; ++sl)
+      if (sl < nk) issue(sl);
+    // slice kt has landed once only the loads of the 4 younger slices kt+1 .. kt+4 are in flight: 4 weight
+    // groups + one activation chunk, or two when both kt+1 and kt+4 start a chunk (kt % 3 == 2)
+    for (int kt0 = 0; kt0 < nk; kt0 += 3) {
+#pragma unroll
+      for (int tap = 0; tap < 3; ++tap) {
+        const int kt = kt0 + tap;
+        if (kt + NSB - 2 < nk) {
+          if (tap == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * BI + 2 * AI) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * BI + AI) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (kt + NSB - 1 < nk) issue(kt + NSB - 1);
+      }
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumer wave
+  const int wm = wave / WN, wn = wave % WN;
+  const int fi = lane & 31, kh = lane >> 5;
+  if (tid < 8) *(u32x4*)(lds + ZOFF + tid * 16) = u32x4{0u, 0u, 0u, 0u};   // the zero row (visible after the first barrier)
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // staged row of fragment row i at tap t is j = tile row + t; taps that leave the clip read the zero row
+  int a_off[3][FM], a_swz[3][FM];
+  bool a_ok[3][FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int tr = wm * TM + i * 32 + fi;
+    const int q = (m0 + tr) % g.segV;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      a_ok[t][i] = !((t == 0 && q == 0) || (t == 2 && q == g.segV - 1));
+      a_off[t][i] = (tr + t) * 128;
+      a_swz[t][i] = ((tr + t) >> 1) & 7;
+    }
+  }
+  int b_row[FN], b_sw[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    b_row[j] = (wn * TN + j * 32 + fi) * BROW;
+    b_sw[j] = WF ? ((wn * TN + j * 32 + fi) >> 2) & 3 : ((wn * TN + j * 32 + fi) >> 1) & 7;   // 64-bank LDS: 2 bf16 rows / 4 fp8 rows per bank row
+  }
+  auto a_chunk = [&](int s) { return 4 * (s >> 1) + 2 * kh + (s & 1); };   // K permutation of gemm_ws_kernel
+  const bool late = wave >= NW / 2;
+  bf16x8 fa[4][FM], fb[4][FN];
+  u32x4 rawb[2][FN];
+  auto cvtb = [&]() {
+    if constexpr (WF != 0) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) cvt_fp8x16<WF>(rawb[t][j], fb[2 * t][j], fb[2 * t + 1][j]);
+    }
+  };
+  auto mma = [&]() {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
+  };
+  const unsigned char* zrow = lds + ZOFF;
+  for (int kt0 = 0; kt0 < nk; kt0 += 3) {
+    const unsigned char* Ab = lds + ((kt0 / 3) % NAB) * ABUF;
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) {
+      const int kt = kt0 + tap;
+      if (late) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt == 0) tl_stamp(g, 1);
+      if (late && kt > 0) {
+        cvtb();
+        mma();
+      }
+      const unsigned char* Bs = lds + NAB * ABUF + (kt % NSB) * BSL;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          const unsigned char* src = a_ok[tap][i] ? Ab + a_off[tap][i] + ((a_chunk(s) ^ a_swz[tap][i]) << 4) : zrow;
+          fa[s][i] = *(const bf16x8*)src;
+        }
+        if constexpr (WF == 0) {
+#pragma unroll
+          for (int j = 0; j < FN; ++j) fb[s][j] = *(const bf16x8*)(Bs + b_row[j] + ((a_chunk(s) ^ b_sw[j]) << 4));
+        } else if (!(s & 1)) {
+#pragma unroll
+          for (int j = 0; j < FN; ++j) rawb[s >> 1][j] = *(const u32x4*)(Bs + b_row[j] + (((s + kh) ^ b_sw[j]) << 4));
+        }
+      }
+      if (!late) {
+        cvtb();
+        mma();
+      }
+    }
+  }
+  if (late && nk > 0) {
+    cvtb();
+    mma();
+  }
+  tl_stamp(g, 2);
+  if (g.vec_out) gemm_epilogue_lds<T, EPI, BM, BN, WM, WN>(g, acc, lds, m0, n0, ks);
+  else gemm_epilogue<T, EPI, FM, FN, TM, TN>(g, acc, m0, n0, wm, wn, fi, kh, ks);
+  tl_stamp(g, 3);
+}
+
+template <int EPI, int WF>
+int launch_ws_conv3_one(const GemmArgs& g, hipStream_t st) {
+  constexpr int BM = 128, BN = 128, WM = 4, WN = 2, NSB = 6, LW = 4;
+  constexpr size_t ai = ((BM + 2 + 7) / 8 + LW - 1) / LW;
+  constexpr size_t lds_ring = 3 * ai * LW * 1024 + (size_t)NSB * BN * (WF ? 64 : 128) + 128;
+  constexpr size_t lds_epi = (size_t)BM * BN * 4;
+  constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  GemmPair pr;
+  pr.g[0] = g;
+  pr.g[1] = g;
+  pr.tiles0 = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * (EPI == EPI_GATE_RES ? g.ksplit : 1);
+  auto k = gemm_ws_conv3_kernel<BM, BN, WM, WN, NSB, LW, EPI, WF>;
+  static bool raised = false;
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);
+    raised = true;
+  }
+  FOLEY_LAUNCH(k, dim3(pr.tiles0), dim3((WM * WN + LW) * 64), lds, st, pr);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);
+  return 0;
+}
+
+template <int WF>
+int launch_ws_conv3_fmt(const GemmArgs& g, int epi, hipStream_t st) {
+  switch (epi) {
+    case EPI_STORE_F32: return launch_ws_conv3_one<EPI_STORE_F32, WF>(g, st);
+    case EPI_GATE_RES: return launch_ws_conv3_one<EPI_GATE_RES, WF>(g, st);
+    case EPI_SILUGATE_T: return launch_ws_conv3_one<EPI_SILUGATE_T, WF>(g, st);
+  }
+  return foley_set_err("wave-specialised conv3: unsupported epilogue", __FILE__, __LINE__);
+}
+
+template <int BM, int BN, int WM, int WN, int NS, int LW, int EPI, int WF>
 int launch_ws_one(const GemmArgs& g, const GemmArgs* g1, hipStream_t st) {
   auto ntiles = [](const GemmArgs& q) {
     return ((q.M + BM - 1) / BM) * ((q.N + BN - 1) / BN) * (EPI == EPI_GATE_RES ? q.ksplit : 1);
@@ -334,8 +666,10 @@ int launch_ws_one(const GemmArgs& g, const GemmArgs* g1, hipStream_t st) {
   pr.g[1] = g1 ? *g1 : g;
   pr.tiles0 = ntiles(g);
   const int tiles = pr.tiles0 + (g1 ? ntiles(*g1) : 0);
-  constexpr size_t lds = (size_t)NS * (BM + BN) * 128;
-  auto k = gemm_ws_kernel<BM, BN, WM, WN, NS, LW, EPI>;
+  constexpr size_t lds_ring = (size_t)NS * (BM * 128 + BN * (WF ? 64 : 128));
+  constexpr size_t lds_epi = (size_t)BM * BN * 4;            // the epilogues transpose the accumulator tile through LDS
+  constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
+  auto k = gemm_ws_kernel<BM, BN, WM, WN, NS, LW, EPI, WF>;
   static bool raised = false;
   if (!raised) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -348,33 +682,57 @@ int launch_ws_one(const GemmArgs& g, const GemmArgs* g1, hipStream_t st) {
   return 0;
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int LW>
+template <int BM, int BN, int WM, int WN, int NS, int LW, int WF>
 int launch_ws_tile(const GemmArgs& g, const GemmArgs* g1, int epi, hipStream_t st) {
   switch (epi) {
-    case EPI_STORE_F32: return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_STORE_F32>(g, g1, st);
-    case EPI_STORE_T: return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_STORE_T>(g, g1, st);
-    case EPI_SILU_T: return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_SILU_T>(g, g1, st);
-    case EPI_GELU_T: return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_GELU_T>(g, g1, st);
-    case EPI_GATE_RES: return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_GATE_RES>(g, g1, st);
-    case EPI_QKV_SPLIT: return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_QKV_SPLIT>(g, g1, st);
+    case EPI_STORE_F32: return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_STORE_F32, WF>(g, g1, st);
+    case EPI_GELU_T: return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_GELU_T, WF>(g, g1, st);
+    case EPI_GATE_RES: return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_GATE_RES, WF>(g, g1, st);
+    case EPI_QKV_SPLIT: return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_QKV_SPLIT, WF>(g, g1, st);
     case EPI_SILUGATE_T:
-      if constexpr ((BN / WN) % 64 == 0) return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_SILUGATE_T>(g, g1, st);
+      if constexpr ((BN / WN) % 64 == 0) return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_SILUGATE_T, WF>(g, g1, st);
       else return foley_set_err("gated epilogue needs a 64-wide wave tile", __FILE__, __LINE__);
   }
-  return foley_set_err("wave-specialised GEMM: unsupported epilogue", __FILE__, __LINE__);
+  if constexpr (WF == 0) {   // epilogues only the bf16-weight embedders use
+    switch (epi) {
+      case EPI_STORE_T: return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_STORE_T, 0>(g, g1, st);
+      case EPI_SILU_T: return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_SILU_T, 0>(g, g1, st);
+    }
+  }
+  return foley_set_err("wave-specialised GEMM: unsupported epilogue for this weight format", __FILE__, __LINE__);
 }
 
 }  // namespace
 
-// tile: 15 = 128x128 (8 consumer + 4 loader waves), 19 = 256x128 (8 + 4), 25 / 29 = the same tiles with 4
+// tile: 21 = tap-fused conv k=3 (128x128, 8 consumer + 4 loader waves); 15 = 128x128 (8 consumer + 4 loader waves), 19 = 256x128 (8 + 4), 25 / 29 = the same tiles with 4
 // consumer waves (64x64 / 128x64 per wave); g / g1 fully resolved
 // (ksplit, vec_out, operand extents) by gemm.hip's launcher
 int launch_gemm_ws(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hipStream_t st) {
-  switch (tile) {
-    case 15: return launch_ws_tile<128, 128, 4, 2, 5, 4>(g, g1, epi, st);   // 5 x 32 KiB ring = all 160 KiB of LDS
-    case 19: return launch_ws_tile<256, 128, 4, 2, 3, 4>(g, g1, epi, st);
-    case 25: return launch_ws_tile<128, 128, 2, 2, 5, 4>(g, g1, epi, st);   // 4 consumer waves of 64x64 (one per SIMD) + 4 loaders
-    case 29: return launch_ws_tile<256, 128, 2, 2, 3, 4>(g, g1, epi, st);   // 4 consumer waves of 128x64
+  if (g.wfmt < 0 || g.wfmt > 2 || (g1 && g1->wfmt != g.wfmt))
+    return foley_set_err("wave-specialised GEMM: bad / mixed weight formats", __FILE__, __LINE__);
+  if (tile == 21) {   // tap-fused conv k=3 (the launcher has checked the conv shape)
+    if (g1) return foley_set_err("wave-specialised conv3 has no two-problem form", __FILE__, __LINE__);
+    if (g.wfmt == 0) return launch_ws_conv3_fmt<0>(g, epi, st);
+    if (g.wfmt == 1) return launch_ws_conv3_fmt<1>(g, epi, st);
+    return launch_ws_conv3_fmt<2>(g, epi, st);
   }
-  return foley_set_err("wave-specialised GEMM: unknown tile", __FILE__, __LINE__);
+  if (g.wfmt == 0) {
+    switch (tile) {
+      case 15: return launch_ws_tile<128, 128, 4, 2, 5, 4, 0>(g, g1, epi, st);   // 5 x 32 KiB ring = all 160 KiB of LDS
+      case 19: return launch_ws_tile<256, 128, 4, 2, 3, 4, 0>(g, g1, epi, st);
+      case 25: return launch_ws_tile<128, 128, 2, 2, 5, 4, 0>(g, g1, epi, st);   // 4 consumer waves of 64x64 (one per SIMD) + 4 loaders
+      case 29: return launch_ws_tile<256, 128, 2, 2, 3, 4, 0>(g, g1, epi, st);   // 4 consumer waves of 128x64
+    }
+  } else if (g.wfmt == 1) {   // fp8 e4m3fn weights: 24 / 40 KiB stages
+    switch (tile) {
+      case 15: return launch_ws_tile<128, 128, 4, 2, 6, 4, 1>(g, g1, epi, st);
+      case 19: return launch_ws_tile<256, 128, 4, 2, 4, 4, 1>(g, g1, epi, st);
+    }
+  } else {
+    switch (tile) {
+      case 15: return launch_ws_tile<128, 128, 4, 2, 6, 4, 2>(g, g1, epi, st);
+      case 19: return launch_ws_tile<256, 128, 4, 2, 4, 4, 2>(g, g1, epi, st);
+    }
+  }
+  return foley_set_err("wave-specialised GEMM: unknown tile for this weight format", __FILE__, __LINE__);
 }

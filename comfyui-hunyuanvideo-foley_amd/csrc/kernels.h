@@ -73,6 +73,8 @@ struct GemmArgs {
   int partial_cap;
   QkvSplitArgs qs;    // EPI_QKV_SPLIT: destination / norm / rotation description (qs.qkv, qs.M unused)
   int vec_out;        // set by the launcher: the problem qualifies for the LDS-transposed vector epilogue
+  int wfmt;           // storage of W: 0 = the operand dtype, 1 = fp8 e4m3fn, 2 = fp8 e5m2 (bf16 activations; wave-specialised
+                      // tiles only - widened to bf16 in registers, reference FP8WeightWrapper utils.py:316-366)
   int pf_dist;        // wave-specialised mainloop: L2 prefetch distance in K-slices beyond the LDS ring (0 = off; set by the launcher)
   int dbg_mode;
   long long* dbg;     // tools/gemm_timeline.py: 4 wall-clock stamps per workgroup (entry, first slice

@@ -54,10 +54,10 @@ class BundleSpec:
 
 
 def bundle_spec(cfg: DiTConfig, dac_cfg: DACConfig, dtype: torch.dtype, duration_s: float,
-                lv: Optional[int] = None, ls: Optional[int] = None) -> BundleSpec:
+                lv: Optional[int] = None, ls: Optional[int] = None, weight_store: torch.dtype = None) -> BundleSpec:
     """Deterministic on every rank.  Text rows are carried zero-padded to `cfg.text_len` (what
     `_pad_or_trim_time` makes of them anyway, utils.py:103-111), so all shapes are fixed."""
-    dit_bytes, dit_table = packers.dit_arena_layout(cfg, dtype)
+    dit_bytes, dit_table = packers.dit_arena_layout(cfg, dtype, weight_store)
     dac_bytes, dac_table = packers.dac_arena_layout(dac_cfg)
     _la, lv0, ls0 = lengths(duration_s, cfg)
     lv, ls = lv or lv0, ls or ls0

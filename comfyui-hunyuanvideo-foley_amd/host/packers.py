@@ -74,19 +74,40 @@ def _f32(t: Tensor) -> Tensor:
     return t.detach().to(torch.float32).contiguous()
 
 
-def pack_dit(sd: Dict[str, Tensor], cfg: DiTConfig, dtype: torch.dtype) -> "OrderedDict[str, Tensor]":
-    """Reference DiT state dict -> packed tensors (CPU or wherever `sd` lives)."""
+FP8_DTYPES = {"fp8_e4m3fn": torch.float8_e4m3fn, "fp8_e5m2": torch.float8_e5m2}
+
+
+def pack_dit(sd: Dict[str, Tensor], cfg: DiTConfig, dtype: torch.dtype,
+             weight_store: torch.dtype = None) -> "OrderedDict[str, Tensor]":
+    """Reference DiT state dict -> packed tensors (CPU or wherever `sd` lives).
+
+    weight_store (torch.float8_e4m3fn / float8_e5m2, bf16 compute only): the matrices of the 54 blocks and the
+    fused single-block modulation - 99.7 % of the bytes - STAY in fp8 in the arena (the reference's
+    FP8WeightWrapper storage, utils.py:316-366; the GEMM widens them in registers).  `sd` must already hold
+    fp8-representable values (nodes.fp8_round_state_dict), so the cast is exact.  The small embedders keep
+    the compute dtype."""
     out: "OrderedDict[str, Tensor]" = OrderedDict()
     H = cfg.heads
+    if weight_store is not None and dtype != torch.bfloat16:
+        raise ValueError("fp8 weight storage needs bf16 compute (the reference cannot run it in fp32 either)")
+    in_block = [False]
 
     def mat(name: str, w: Tensor):
-        out[name + ".w"] = w.detach().to(torch.float32).to(dtype).contiguous()
+        w = w.detach().to(torch.float32)
+        if weight_store is not None and in_block[0]:
+            w8 = w.to(weight_store)
+            if not torch.equal(w8.to(torch.float32), w):
+                raise ValueError(f"{name}: values are not representable in {weight_store} (round the state dict first)")
+            out[name + ".w"] = w8.contiguous()
+        else:
+            out[name + ".w"] = w.to(dtype).contiguous()
 
     def lin(name: str, ref: str, bias: bool = True):
         mat(name, sd[ref + ".weight"])
         if bias:
             out[name + ".b"] = _f32(sd[ref + ".bias"])
 
+    in_block[0] = True
     for b in range(cfg.depth_triple):
         p, r = f"t{b}.", f"triple_blocks.{b}."
         for n, m in _TRIPLE_LINEARS:
@@ -111,6 +132,7 @@ def pack_dit(sd: Dict[str, Tensor], cfg: DiTConfig, dtype: torch.dtype) -> "Orde
         mat(p + "w13", interleave_gate(conv_to_gemm(sd[r + "linear2.w1.weight"].float()),
                                        conv_to_gemm(sd[r + "linear2.w3.weight"].float())))
         mat(p + "w2", conv_to_gemm(sd[r + "linear2.w2.weight"].float()))
+    in_block[0] = False
     mat("audio_in", sd["audio_embedder.proj.weight"].float().squeeze(-1))
     out["audio_in.b"] = _f32(sd["audio_embedder.proj.bias"])
     mat("vis.w13", interleave_gate(sd["visual_proj.w1.weight"].float(), sd["visual_proj.w3.weight"].float()))
@@ -268,12 +290,21 @@ def _meta_state(schema) -> Dict[str, Tensor]:
     return {k: torch.empty(shape, device="meta") for k, (shape, _std, _mean) in schema.items()}
 
 
-def dit_arena_layout(cfg: DiTConfig, dtype: torch.dtype):
+def dit_arena_layout(cfg: DiTConfig, dtype: torch.dtype, weight_store: torch.dtype = None):
     """(total bytes, table) of the packed DiT arena, derived from the config alone (the packers run on
     meta tensors of the reference state-dict schema): every rank of a multi-GPU job can lay out the
     arena it is about to receive without a metadata exchange."""
     from . import synth
-    return arena_layout(pack_dit(_meta_state(synth.dit_schema(cfg)), cfg, dtype))
+    return arena_layout(_pack_dit_meta(synth.dit_schema(cfg), cfg, dtype, weight_store))
+
+
+def _pack_dit_meta(schema, cfg, dtype, weight_store):
+    """pack_dit on meta tensors (layout only): the representability check is skipped."""
+    packed = pack_dit(_meta_state(schema), cfg, dtype)
+    if weight_store is None:
+        return packed
+    blocks = lambda k: k.endswith(".w") and (k[0] in "ts" and k[1].isdigit() or k.startswith("smod_all"))
+    return OrderedDict((k, torch.empty(v.shape, dtype=weight_store, device="meta") if blocks(k) else v) for k, v in packed.items())
 
 
 def dac_arena_layout(cfg: DACConfig):

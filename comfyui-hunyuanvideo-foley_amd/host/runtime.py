@@ -15,8 +15,9 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libfoley_hip.so")
 
-DT_F32, DT_BF16, DT_I32 = 0, 1, 2
-_TORCH2DT = {torch.float32: DT_F32, torch.bfloat16: DT_BF16, torch.int32: DT_I32}
+DT_F32, DT_BF16, DT_I32, DT_F8E4M3, DT_F8E5M2 = 0, 1, 2, 3, 4
+_TORCH2DT = {torch.float32: DT_F32, torch.bfloat16: DT_BF16, torch.int32: DT_I32, torch.float8_e4m3fn: DT_F8E4M3,
+             torch.float8_e5m2: DT_F8E5M2}
 
 EPI_STORE_F32, EPI_STORE_T, EPI_SILU_T, EPI_GELU_T, EPI_SILUGATE_T, EPI_GATE_RES, EPI_DAC = range(7)
 
@@ -69,7 +70,7 @@ class GemmDescC(C.Structure):
         ("rb", RowBcastC), ("res", C.c_void_p), ("alpha", C.c_void_p), ("alphaC", C.c_int32),
         ("dtype", C.c_int32), ("epilogue", C.c_int32), ("tile", C.c_int32), ("ksplit", C.c_int32),
         ("partials", C.c_void_p), ("partial_slabs", C.c_int32), ("ksplit_used", C.POINTER(C.c_int32)),
-        ("qkv", C.POINTER(QkvSplitDescC)), ("rstride", C.c_int32), ("ldw", C.c_int64),
+        ("qkv", C.POINTER(QkvSplitDescC)), ("rstride", C.c_int32), ("ldw", C.c_int64), ("wfmt", C.c_int32),
     ]
 
 
@@ -79,7 +80,7 @@ class ProfEntryC(C.Structure):
 
 
 PROGRESS_CB = C.CFUNCTYPE(None, C.c_int32, C.c_int32, C.c_void_p)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _SIGNATURES = {
     "foley_abi_version": (C.c_uint32, []),
@@ -330,7 +331,11 @@ def op_gemm(A, W, bias=None, *, M=None, epilogue=EPI_STORE_F32, out0=None, out1=
     N, K = NK if NK is not None else W.shape      # NK: logical shape when W / A are row-padded storage (lda / ldw)
     d.A, d.W, d.bias = _ptr(A), _ptr(W), _ptr(bias) if bias is not None else None
     d.N, d.K = N, K
-    d.dtype, d.epilogue, d.tile, d.ksplit = dt_of(W), epilogue, tile, ksplit
+    if W.dtype in (torch.float8_e4m3fn, torch.float8_e5m2):      # fp8 weight storage, bf16 activations
+        d.dtype, d.wfmt = DT_BF16, (1 if W.dtype == torch.float8_e4m3fn else 2)
+    else:
+        d.dtype = dt_of(W)
+    d.epilogue, d.tile, d.ksplit = epilogue, tile, ksplit
     if convT is not None:
         Tin, Cin, s, Cout = convT
         clips = A.numel() // (Tin * Cin)

@@ -30,7 +30,9 @@ class FoleyModel:
         self.dtype = compute_dtype
         self.device = torch.device(device)
         self.quantization = quantization
-        packed = packers.pack_dit(dit_state, cfg, compute_dtype)
+        # fp8 weight-only storage stays fp8 in HBM (bf16 compute); `dit_state` then holds fp8-rounded values
+        store = packers.FP8_DTYPES.get(quantization) if compute_dtype == torch.bfloat16 else None
+        packed = packers.pack_dit(dit_state, cfg, compute_dtype, weight_store=store)
         self.arena = packers.Arena.from_packed(packed, self.device)
         self._finish_init()
 

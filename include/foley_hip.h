@@ -35,9 +35,13 @@
 extern "C" {
 #endif
 
-#define FOLEY_ABI_VERSION 3   /* 3: foley_profile_forward; 2: foley_gemm_desc gained partials / qkv / rstride; foley_op_ln_mod_pending, foley_dac_encode */
+#define FOLEY_ABI_VERSION 4   /* 4: fp8 weight storage (dtype codes 3/4, foley_gemm_desc.ldw/.wfmt); 3: foley_profile_forward; 2: foley_gemm_desc gained partials / qkv / rstride; foley_op_ln_mod_pending, foley_dac_encode */
 
-enum foley_dtype { FOLEY_DT_F32 = 0, FOLEY_DT_BF16 = 1, FOLEY_DT_I32 = 2 };
+enum foley_dtype {
+  FOLEY_DT_F32 = 0, FOLEY_DT_BF16 = 1, FOLEY_DT_I32 = 2,
+  FOLEY_DT_F8E4M3 = 3,  /* OCP e4m3fn, weight storage only (reference FP8WeightWrapper, utils.py:316-366: plain cast, no scales) */
+  FOLEY_DT_F8E5M2 = 4   /* OCP e5m2,   weight storage only */
+};
 
 enum foley_status {
   FOLEY_OK = 0,
@@ -184,6 +188,8 @@ typedef struct foley_gemm_desc {
   const foley_qkv_split_desc* qkv;
   int32_t rstride; /* source rows advanced per virtual row (strided conv, dac.py:55-61); 0 or 1 = dense */
   int64_t ldw;     /* elements between rows of W (0 = K); > K for row-padded weight storage (wave-specialised tiles) */
+  int32_t wfmt;    /* storage of W: 0 = `dtype`; 1 = fp8 e4m3fn, 2 = fp8 e5m2 with bf16 activations - widened to bf16
+                    * in registers by the wave-specialised tiles (15, 19), bit-identical to widening at load time */
 } foley_gemm_desc;
 
 int foley_op_gemm(const foley_gemm_desc* d, void* stream);

@@ -384,6 +384,14 @@ def test_fp8_weight_only_loader(dev):
             ref_no_quirk = O.dit_forward(sdq, c.heads, xq, t, cond, clip, sync)
         assert rel_err(y, ref) < 4e-2, q
         assert rel_err(y, ref) < rel_err(y, ref_no_quirk), q    # the fp8-rounded time features are really in use
+        # the block weights STAY fp8 in HBM (39 matrices of the tiny config) and give what load-time widening gives
+        n8 = [k for k, v in model.arena.items() if v.dtype == qd]
+        assert len(n8) == 15 * c.depth_triple + 4 * c.depth_single + 1 and all(k.endswith(".w") for k in n8)
+        wide = sampler.FoleyModel(c, nodes.fp8_round_state_dict(nodes.round_params(sd, torch.bfloat16), q, autocast=True,
+                                                                param_dtype=torch.bfloat16), torch.bfloat16, dev)
+        wide.quantization = q                                   # same fp8-rounded time features, weights widened at load
+        assert model.arena.buffer.numel() < 0.62 * wide.arena.buffer.numel()
+        assert rel_err(y, _forward(wide, xq, t, cond, clip, sync)) < 5e-3, q
     # a checkpoint that already stores fp8 tensors is honoured by quantization="auto"
     sd8 = {k: (v.to(torch.float8_e4m3fn) if nodes.fp8_wrapped_key(k, v) else v) for k, v in sd.items()}
     m = nodes.HunyuanModelLoader.pack_state_dict(sd8, "bf16", "auto", device=dev, cfg=c)

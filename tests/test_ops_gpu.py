@@ -113,6 +113,75 @@ def test_gemm_epilogues(dev, dtype, epi, tile):
         assert rel_err(out, ref) < _tol(dtype)
 
 
+@pytest.mark.parametrize("fmt", [torch.float8_e4m3fn, torch.float8_e5m2])
+@pytest.mark.parametrize("tile", [15, 19, 21])
+@pytest.mark.parametrize("case", ["linear", "ragged", "conv3", "gelu", "silugate", "gate_res_split", "qkv_split"])
+def test_gemm_fp8_weight_storage(dev, fmt, tile, case):
+    """In-kernel fp8 weight storage (reference FP8WeightWrapper, utils.py:316-366: weight kept in fp8, plain
+    cast, `w.to(x.dtype)` per call): the loaders move 64-byte fp8 K-slices, the consumers widen to bf16 in
+    registers.  Widening is exact and both kernels use the same K order, so the result must be BIT-IDENTICAL
+    to the same GEMM on the weights widened to bf16 at load time - and therefore as close to the fp32
+    statement on fp8-rounded weights as the bf16 path is."""
+    if tile == 21 and case not in ("conv3", "gate_res_split"):
+        pytest.skip("tile 21 is the tap-fused conv k=3 kernel")
+    M, N, K = {"linear": (500, 1536, 1536), "ragged": (257, 1408, 320), "conv3": (500, 512, 3 * 256), "gelu": (300, 512, 256),
+               "silugate": (300, 512, 256), "gate_res_split": (500, 1536, 3 * 512), "qkv_split": (500, 3 * 2 * 128, 256)}[case]
+    conv = (250, K // 3, 3, 1) if case in ("conv3", "gate_res_split") else None
+    A = _rand((M, K // 3 if conv else K), 21).to(dev, torch.bfloat16)
+    W8 = _rand((N, K), 22, 1 / math.sqrt(K)).to(fmt)
+    Wq = W8.to(torch.bfloat16)                       # exact: every fp8 value is a bf16 value
+    assert torch.equal(Wq.float(), W8.float())
+    b = _rand((N,), 23, 0.1).to(dev)
+    W8d, Wqd = W8.to(dev), Wq.to(dev)
+    kw = dict(conv=conv) if conv else {}
+
+    def run(W):
+        if case in ("linear", "ragged", "conv3"):
+            out = torch.full((M, N), float("nan"), device=dev)
+            rt.op_gemm(A, W, b, out0=out, tile=tile, **kw)
+            return out
+        if case == "gelu":
+            out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            rt.op_gemm(A, W, b, out0=out, epilogue=rt.EPI_GELU_T, tile=tile)
+            return out
+        if case == "silugate":
+            out = torch.empty(M, N // 2, device=dev, dtype=torch.bfloat16)
+            rt.op_gemm(A, W, None, out0=out, epilogue=rt.EPI_SILUGATE_T, tile=tile)
+            return out
+        if case == "gate_res_split":
+            x = _rand((M, N), 24).to(dev)
+            slabs = torch.zeros(8, M, N, device=dev)
+            gate = _rand((N,), 25).to(dev)
+            ks = rt.op_gemm(A, W, b, out0=x, epilogue=rt.EPI_GATE_RES, rb=rt.rowbcast(gate, 0), tile=tile, ksplit=0,
+                            partials=slabs, **kw)
+            return torch.cat([x, slabs[:ks].sum(0)])
+        H, L = 2, 250
+        dq, dk = (torch.zeros(M // L, H, L, 128, device=dev, dtype=torch.bfloat16) for _ in range(2))
+        dvt = torch.zeros(M // L, H, 128, 256, device=dev, dtype=torch.bfloat16)
+        cos, sin = (t.to(dev) for t in tables.rope_table(L + 1))
+        gq = (1 + 0.1 * _rand((128,), 26)).to(dev)
+        pos = torch.arange(L, dtype=torch.int32, device=dev)
+        desc = rt.qkv_split_desc(L, H, [gq, gq, None], [pos, pos, None], [dq, dk, dvt], L, 0, 1e-6, cos, sin, vt_pitch=256)
+        rt.op_gemm(A, W, b, epilogue=rt.EPI_QKV_SPLIT, qkv=desc, tile=tile)
+        return torch.cat([dq.flatten(), dk.flatten(), dvt.flatten()])
+
+    y8, yq = run(W8d), run(Wqd)
+    assert torch.isfinite(y8.float()).all() and torch.equal(y8, yq)
+    if case in ("linear", "ragged"):
+        assert rel_err(y8, F.linear(A.float().cpu(), W8.float(), b.cpu())) < BF16_TOL
+
+
+def test_gemm_fp8_rejects_unsupported(dev):
+    """fp8 weights exist only in the wave-specialised bf16 mainloop: other tiles / fp32 operands fail loudly."""
+    A = _rand((64, 128), 1).to(dev, torch.bfloat16)
+    W8 = _rand((128, 128), 2).to(torch.float8_e4m3fn).to(dev)
+    out = torch.empty(64, 128, device=dev)
+    with pytest.raises(rt.FoleyRuntimeError):
+        rt.op_gemm(A, W8, None, out0=out, tile=3)
+    rt.op_gemm(A, W8, None, out0=out, tile=0)        # auto -> a wave-specialised tile
+    assert rel_err(out, A.float() @ W8.float().t()) < BF16_TOL
+
+
 @pytest.mark.parametrize("ksplit", [0, 1, 2, 5])
 @pytest.mark.parametrize("conv", [False, True, 11, 13])
 def test_gemm_split_k(dev, ksplit, conv):
@@ -137,7 +206,7 @@ def test_gemm_split_k(dev, ksplit, conv):
 
 
 @pytest.mark.parametrize("ksplit", [0, 2, 3, 7])
-@pytest.mark.parametrize("conv", [False, True, 11, 13, 15, 19])
+@pytest.mark.parametrize("conv", [False, True, 11, 13, 15, 19, 21])
 @pytest.mark.parametrize("tok_gate", [False, True])
 def test_gemm_deferred_split_k(dev, ksplit, conv, tok_gate):
     """Deferred split-K: the gated-residual GEMM leaves raw partial products per K range, the next
@@ -158,7 +227,7 @@ def test_gemm_deferred_split_k(dev, ksplit, conv, tok_gate):
     if conv:
         y = O.conv1d_cl(_q(x, dt), _q(w, dt), b, 1).reshape(B * L, N)
         Wp, kw = packers.conv_to_gemm(w), dict(conv=(L, C, 3, 1))
-        if conv in (11, 13, 15, 19):
+        if conv in (11, 13, 15, 19, 21):
             kw["tile"] = conv    # tap-fused / wave-specialised conv addressing
     else:
         y = F.linear(_q(x, dt).reshape(B * L, C), _q(w[:, :, 0], dt), b)
@@ -185,10 +254,11 @@ def test_gemm_deferred_split_k(dev, ksplit, conv, tok_gate):
 
 # ----------------------------------------------------------------------------- GEMM: conv addressing
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("tile", [0, 3, 5, 6, 11, 13, 15, 19])
-@pytest.mark.parametrize("B,L,Cin,Cout", [(2, 50, 256, 384), (3, 7, 128, 64), (1, 250, 1536, 256), (5, 33, 128, 200)])
+@pytest.mark.parametrize("tile", [0, 3, 5, 6, 11, 13, 15, 19, 21])
+@pytest.mark.parametrize("B,L,Cin,Cout", [(2, 50, 256, 384), (3, 7, 128, 64), (1, 250, 1536, 256), (5, 33, 128, 200), (2, 250, 64, 128),
+                                          (4, 129, 192, 320)])
 def test_conv3_channels_last(dev, dtype, tile, B, L, Cin, Cout):
-    if tile in (15, 19) and dtype == torch.float32:
+    if tile in (15, 19, 21) and dtype == torch.float32:
         pytest.skip("wave-specialised tiles are bf16 only")
     """ChannelLastConv1d k=3 pad=1 (mlp_layers.py:104-110) as a GEMM over overlapping rows
     (register-staged and direct-to-LDS mainloops)."""
