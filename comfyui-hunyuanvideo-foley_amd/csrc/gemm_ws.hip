@@ -418,7 +418,15 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
 // of 16 KiB (fp8: 8 KiB) slices.  Per MFMA a third fewer bytes leave the L2.  Rows whose neighbour
 // lies outside their clip read a zero row instead (the conv's padding).  Loader / consumer roles,
 // barrier protocol, K permutation, fp8 weight widening and epilogues are those of gemm_ws_kernel.
-template <int BM, int BN, int WM, int WN, int NSB, int LW, int EPI, int WF>
+// loads of the younger slices kt+1 .. kt+NSB-2 that may still be in flight when slice kt must have landed:
+// one weight group each, plus an activation chunk for every one of them that starts a chunk (tap 0)
+constexpr int conv3_inflight(int nsb, int tap, int ai, int bi) {
+  int n = 0;
+  for (int j = 1; j <= nsb - 2; ++j) n += bi + (((tap + j) % 3 == 0) ? ai : 0);
+  return n;
+}
+
+template <int BM, int BN, int WM, int WN, int NSB, int NAB, int LW, int EPI, int WF>
 __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_conv3_kernel(const GemmPair pr) {
   using T = bf16_t;
   const GemmArgs& g = pr.g[0];
@@ -428,13 +436,14 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_conv3_kernel(cons
   constexpr int WSZ = WF ? 1 : 2, BROW = 64 * WSZ;
   constexpr int APC = (BM + 2 + 7) / 8;                 // 1 KiB pieces of an activation chunk (BM+2 rows)
   constexpr int AI = (APC + LW - 1) / LW;               // per loader wave (the last wave's surplus pieces stay out of range)
-  constexpr int ABUF = AI * LW * 1024, NAB = 3;         // bytes per activation buffer, buffers
+  constexpr int ABUF = AI * LW * 1024;                  // bytes per activation buffer
   constexpr int BI = BN * BROW / 1024 / LW;             // weight pieces per loader wave and tap slice
   constexpr int BSL = BN * BROW;                        // bytes per weight slice
   constexpr int ZOFF = NAB * ABUF + NSB * BSL;          // 128 zero bytes
   static_assert(NW == 8 && (BN * BROW) % (1024 * LW) == 0 && BI >= 1, "bad tile");
-  static_assert(NSB == 6, "the vmcnt schedule below is written for a 6-slice weight ring");
-  static_assert(4 * BI + 2 * AI < 64, "vmcnt is a 6-bit counter");
+  static_assert(3 * NAB >= NSB + 2, "an activation buffer would be refilled while its chunk is still being consumed");
+  static_assert(conv3_inflight(NSB, 0, AI, BI) < 64 && conv3_inflight(NSB, 1, AI, BI) < 64 && conv3_inflight(NSB, 2, AI, BI) < 64,
+                "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   const int tiles_m = (g.M + BM - 1) / BM;
@@ -505,15 +514,15 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_conv3_kernel(cons
 #pragma unroll
     for (int sl = 0; sl < NSB - 1; ++sl)
       if (sl < nk) issue(sl);
-    // slice kt has landed once only the loads of the 4 younger slices kt+1 .. kt+4 are in flight: 4 weight
-    // groups + one activation chunk, or two when both kt+1 and kt+4 start a chunk (kt % 3 == 2)
+    // slice kt has landed once only the loads of the NSB-2 younger slices are in flight (conv3_inflight)
     for (int kt0 = 0; kt0 < nk; kt0 += 3) {
 #pragma unroll
       for (int tap = 0; tap < 3; ++tap) {
         const int kt = kt0 + tap;
         if (kt + NSB - 2 < nk) {
-          if (tap == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * BI + 2 * AI) : "memory");
-          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * BI + AI) : "memory");
+          if (tap == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(conv3_inflight(NSB, 0, AI, BI)) : "memory");
+          else if (tap == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(conv3_inflight(NSB, 1, AI, BI)) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(conv3_inflight(NSB, 2, AI, BI)) : "memory");
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -621,11 +630,13 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_conv3_kernel(cons
   tl_stamp(g, 3);
 }
 
-template <int EPI, int WF>
+template <int BM, int EPI, int WF>
 int launch_ws_conv3_one(const GemmArgs& g, hipStream_t st) {
-  constexpr int BM = 128, BN = 128, WM = 4, WN = 2, NSB = 6, LW = 4;
+  // 128x128: activation chunks 3 deep + 6 weight slices; 256x128 (large grids): 2 + 4 (fp8 weights: 3 + 6)
+  constexpr int BN = 128, WM = 4, WN = 2, LW = 4;
+  constexpr int NSB = BM == 128 ? 6 : (WF ? 6 : 4), NAB = (NSB + 2 + 2) / 3;
   constexpr size_t ai = ((BM + 2 + 7) / 8 + LW - 1) / LW;
-  constexpr size_t lds_ring = 3 * ai * LW * 1024 + (size_t)NSB * BN * (WF ? 64 : 128) + 128;
+  constexpr size_t lds_ring = NAB * ai * LW * 1024 + (size_t)NSB * BN * (WF ? 64 : 128) + 128;
   constexpr size_t lds_epi = (size_t)BM * BN * 4;
   constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
   static_assert(lds <= 160 * 1024, "LDS budget");
@@ -633,7 +644,7 @@ int launch_ws_conv3_one(const GemmArgs& g, hipStream_t st) {
   pr.g[0] = g;
   pr.g[1] = g;
   pr.tiles0 = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * (EPI == EPI_GATE_RES ? g.ksplit : 1);
-  auto k = gemm_ws_conv3_kernel<BM, BN, WM, WN, NSB, LW, EPI, WF>;
+  auto k = gemm_ws_conv3_kernel<BM, BN, WM, WN, NSB, NAB, LW, EPI, WF>;
   static bool raised = false;
   if (!raised) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -646,12 +657,12 @@ int launch_ws_conv3_one(const GemmArgs& g, hipStream_t st) {
   return 0;
 }
 
-template <int WF>
+template <int BM, int WF>
 int launch_ws_conv3_fmt(const GemmArgs& g, int epi, hipStream_t st) {
   switch (epi) {
-    case EPI_STORE_F32: return launch_ws_conv3_one<EPI_STORE_F32, WF>(g, st);
-    case EPI_GATE_RES: return launch_ws_conv3_one<EPI_GATE_RES, WF>(g, st);
-    case EPI_SILUGATE_T: return launch_ws_conv3_one<EPI_SILUGATE_T, WF>(g, st);
+    case EPI_STORE_F32: return launch_ws_conv3_one<BM, EPI_STORE_F32, WF>(g, st);
+    case EPI_GATE_RES: return launch_ws_conv3_one<BM, EPI_GATE_RES, WF>(g, st);
+    case EPI_SILUGATE_T: return launch_ws_conv3_one<BM, EPI_SILUGATE_T, WF>(g, st);
   }
   return foley_set_err("wave-specialised conv3: unsupported epilogue", __FILE__, __LINE__);
 }
@@ -710,11 +721,16 @@ int launch_ws_tile(const GemmArgs& g, const GemmArgs* g1, int epi, hipStream_t s
 int launch_gemm_ws(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hipStream_t st) {
   if (g.wfmt < 0 || g.wfmt > 2 || (g1 && g1->wfmt != g.wfmt))
     return foley_set_err("wave-specialised GEMM: bad / mixed weight formats", __FILE__, __LINE__);
-  if (tile == 21) {   // tap-fused conv k=3 (the launcher has checked the conv shape)
+  if (tile == 21 || tile == 23) {   // tap-fused conv k=3, 128x128 / 256x128 (the launcher has checked the conv shape)
     if (g1) return foley_set_err("wave-specialised conv3 has no two-problem form", __FILE__, __LINE__);
-    if (g.wfmt == 0) return launch_ws_conv3_fmt<0>(g, epi, st);
-    if (g.wfmt == 1) return launch_ws_conv3_fmt<1>(g, epi, st);
-    return launch_ws_conv3_fmt<2>(g, epi, st);
+    if (tile == 21) {
+      if (g.wfmt == 0) return launch_ws_conv3_fmt<128, 0>(g, epi, st);
+      if (g.wfmt == 1) return launch_ws_conv3_fmt<128, 1>(g, epi, st);
+      return launch_ws_conv3_fmt<128, 2>(g, epi, st);
+    }
+    if (g.wfmt == 0) return launch_ws_conv3_fmt<256, 0>(g, epi, st);
+    if (g.wfmt == 1) return launch_ws_conv3_fmt<256, 1>(g, epi, st);
+    return launch_ws_conv3_fmt<256, 2>(g, epi, st);
   }
   if (g.wfmt == 0) {
     switch (tile) {

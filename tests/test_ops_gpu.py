@@ -114,7 +114,7 @@ def test_gemm_epilogues(dev, dtype, epi, tile):
 
 
 @pytest.mark.parametrize("fmt", [torch.float8_e4m3fn, torch.float8_e5m2])
-@pytest.mark.parametrize("tile", [15, 19, 21])
+@pytest.mark.parametrize("tile", [15, 19, 21, 23])
 @pytest.mark.parametrize("case", ["linear", "ragged", "conv3", "gelu", "silugate", "gate_res_split", "qkv_split"])
 def test_gemm_fp8_weight_storage(dev, fmt, tile, case):
     """In-kernel fp8 weight storage (reference FP8WeightWrapper, utils.py:316-366: weight kept in fp8, plain
@@ -122,8 +122,8 @@ def test_gemm_fp8_weight_storage(dev, fmt, tile, case):
     registers.  Widening is exact and both kernels use the same K order, so the result must be BIT-IDENTICAL
     to the same GEMM on the weights widened to bf16 at load time - and therefore as close to the fp32
     statement on fp8-rounded weights as the bf16 path is."""
-    if tile == 21 and case not in ("conv3", "gate_res_split"):
-        pytest.skip("tile 21 is the tap-fused conv k=3 kernel")
+    if tile in (21, 23) and case not in ("conv3", "gate_res_split"):
+        pytest.skip("tiles 21 / 23 are the tap-fused conv k=3 kernels")
     M, N, K = {"linear": (500, 1536, 1536), "ragged": (257, 1408, 320), "conv3": (500, 512, 3 * 256), "gelu": (300, 512, 256),
                "silugate": (300, 512, 256), "gate_res_split": (500, 1536, 3 * 512), "qkv_split": (500, 3 * 2 * 128, 256)}[case]
     conv = (250, K // 3, 3, 1) if case in ("conv3", "gate_res_split") else None
@@ -206,7 +206,7 @@ def test_gemm_split_k(dev, ksplit, conv):
 
 
 @pytest.mark.parametrize("ksplit", [0, 2, 3, 7])
-@pytest.mark.parametrize("conv", [False, True, 11, 13, 15, 19, 21])
+@pytest.mark.parametrize("conv", [False, True, 11, 13, 15, 19, 21, 23])
 @pytest.mark.parametrize("tok_gate", [False, True])
 def test_gemm_deferred_split_k(dev, ksplit, conv, tok_gate):
     """Deferred split-K: the gated-residual GEMM leaves raw partial products per K range, the next
@@ -227,7 +227,7 @@ def test_gemm_deferred_split_k(dev, ksplit, conv, tok_gate):
     if conv:
         y = O.conv1d_cl(_q(x, dt), _q(w, dt), b, 1).reshape(B * L, N)
         Wp, kw = packers.conv_to_gemm(w), dict(conv=(L, C, 3, 1))
-        if conv in (11, 13, 15, 19, 21):
+        if conv in (11, 13, 15, 19, 21, 23):
             kw["tile"] = conv    # tap-fused / wave-specialised conv addressing
     else:
         y = F.linear(_q(x, dt).reshape(B * L, C), _q(w[:, :, 0], dt), b)
@@ -254,11 +254,11 @@ def test_gemm_deferred_split_k(dev, ksplit, conv, tok_gate):
 
 # ----------------------------------------------------------------------------- GEMM: conv addressing
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("tile", [0, 3, 5, 6, 11, 13, 15, 19, 21])
+@pytest.mark.parametrize("tile", [0, 3, 5, 6, 11, 13, 15, 19, 21, 23])
 @pytest.mark.parametrize("B,L,Cin,Cout", [(2, 50, 256, 384), (3, 7, 128, 64), (1, 250, 1536, 256), (5, 33, 128, 200), (2, 250, 64, 128),
                                           (4, 129, 192, 320)])
 def test_conv3_channels_last(dev, dtype, tile, B, L, Cin, Cout):
-    if tile in (15, 19, 21) and dtype == torch.float32:
+    if tile in (15, 19, 21, 23) and dtype == torch.float32:
         pytest.skip("wave-specialised tiles are bf16 only")
     """ChannelLastConv1d k=3 pad=1 (mlp_layers.py:104-110) as a GEMM over overlapping rows
     (register-staged and direct-to-LDS mainloops)."""

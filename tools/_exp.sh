@@ -1,7 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for sh in lin1 w2; do
-python tools/gemm_timeline.py --shape $sh --m 3000 --tile 3,15,19,21 --ksplit 1,2,3 --partials --conv --brief
-done
-python tools/gemm_timeline.py --shape w13 --m 3000 --tile 15,19,21,29 --conv --brief
-python tools/gemm_timeline.py --shape fc2 --m 3480 --tile 3,15,19 --ksplit 1,2 --partials --brief
-python tools/gemm_timeline.py --shape qkv --m 3000 --tile 15,19,25,29 --brief
+python bench.py --steps 4 --warmup 2 --no-cpu-baseline > gpurun_out/r02_e_bench.json 2> gpurun_out/r02_e_bench.err; tail -c 300 gpurun_out/r02_e_bench.err
+python bench.py --config c5 --steps 2 --warmup 1 --no-cpu-baseline --no-extra > gpurun_out/r02_e_bench_c5.json 2> gpurun_out/r02_e_bench_c5.err
+python bench.py --config c5 --quantization none --steps 2 --warmup 1 --no-cpu-baseline --no-extra > gpurun_out/r02_e_bench_c5_noq.json 2>> gpurun_out/r02_e_bench_c5.err
+python -m pytest tests -m gpu -x -q 2>&1 | tail -4
