@@ -160,7 +160,16 @@ struct foley_ctx {
   bool timed = false;
   // DAC workspace (grown on demand)
   DevBuf dacP, dacQ, dacR, dacZ;
+  // reference-keyed weight store (weights.hip): ctx-owned packed arena
+  void* wstore = nullptr;
+  void (*wstore_free)(void*) = nullptr;
 };
+
+// internal hooks for weights.hip (not part of the C ABI)
+void** foley_ctx_wstore_slot(foley_ctx* c) { return &c->wstore; }
+void foley_ctx_set_wstore_free(foley_ctx* c, void (*fn)(void*)) { c->wstore_free = fn; }
+const foley_config* foley_ctx_config(foley_ctx* c) { return &c->cfg; }
+int foley_ctx_device(foley_ctx* c) { return c->device; }
 
 static size_t esize(int dtype) { return dtype == FOLEY_BF16 ? 2 : (dtype == FOLEY_F8E4M3 || dtype == FOLEY_F8E5M2) ? 1 : 4; }
 
@@ -337,6 +346,7 @@ extern "C" void foley_ctx_destroy(foley_ctx* c) {
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
   for (auto e : c->ev_mod) hipEventDestroy(e);
   for (auto e : c->prof.pool) hipEventDestroy(e);
+  if (c->wstore && c->wstore_free) c->wstore_free(c->wstore);
   delete c;
 }
 

@@ -15,9 +15,9 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libfoley_hip.so")
 
-DT_F32, DT_BF16, DT_I32, DT_F8E4M3, DT_F8E5M2 = 0, 1, 2, 3, 4
+DT_F32, DT_BF16, DT_I32, DT_F8E4M3, DT_F8E5M2, DT_F16 = 0, 1, 2, 3, 4, 5
 _TORCH2DT = {torch.float32: DT_F32, torch.bfloat16: DT_BF16, torch.int32: DT_I32, torch.float8_e4m3fn: DT_F8E4M3,
-             torch.float8_e5m2: DT_F8E5M2}
+             torch.float8_e5m2: DT_F8E5M2, torch.float16: DT_F16}
 
 EPI_STORE_F32, EPI_STORE_T, EPI_SILU_T, EPI_GELU_T, EPI_SILUGATE_T, EPI_GATE_RES, EPI_DAC = range(7)
 
@@ -80,7 +80,7 @@ class ProfEntryC(C.Structure):
 
 
 PROGRESS_CB = C.CFUNCTYPE(None, C.c_int32, C.c_int32, C.c_void_p)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _SIGNATURES = {
     "foley_abi_version": (C.c_uint32, []),
@@ -88,6 +88,12 @@ _SIGNATURES = {
     "foley_ctx_create": (C.c_int, [C.c_int, C.POINTER(FoleyConfigC), C.POINTER(C.c_void_p)]),
     "foley_ctx_destroy": (None, [C.c_void_p]),
     "foley_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "foley_weights_begin": (C.c_int, [C.c_void_p, C.c_int]),
+    "foley_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_void_p]),
+    "foley_weights_end": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "foley_weights_arena": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    "foley_weights_mark_received": (C.c_int, [C.c_void_p]),
+    "foley_bcast_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "foley_prepare": (C.c_int, [C.c_void_p, C.POINTER(FoleyPlanC), C.c_void_p]),
     "foley_dit_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "foley_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, PROGRESS_CB, C.c_void_p, C.c_void_p]),
@@ -219,6 +225,38 @@ class FoleyContext:
     def set_tensors(self, items):
         for k, t in items:
             self.set_tensor(k, t)
+
+    # ---- reference-keyed loading (the library packs on the device; weights.hip)
+    def load_reference_state(self, state_dicts, weight_format: int = 0) -> int:
+        """Pack reference state dict(s) (DiT and/or DAC, device or CPU tensors) through the C ABI.  Returns the number of
+        tensors the sampling path ignored (DAC encoder etc.)."""
+        _check(self.lib, self.lib.foley_weights_begin(self._h, int(weight_format)), "foley_weights_begin")
+        ignored = 0
+        with torch.cuda.device(self.device):
+            for sd in state_dicts:
+                for k, v in sd.items():
+                    if not isinstance(v, torch.Tensor) or not v.is_floating_point():
+                        continue
+                    t = v.detach().to(self.device).contiguous()
+                    shape = (C.c_int64 * t.dim())(*t.shape)
+                    rc = self.lib.foley_load_tensor(self._h, k.encode(), t.data_ptr(), dt_of(t), t.dim(), shape, _stream())
+                    if rc == 1:
+                        ignored += 1
+                    else:
+                        _check(self.lib, rc, f"foley_load_tensor({k})")
+                    torch.cuda.current_stream().synchronize()       # `t` is only borrowed for the call
+            _check(self.lib, self.lib.foley_weights_end(self._h, _stream()), "foley_weights_end")
+        return ignored
+
+    def weights_arena(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        _check(self.lib, self.lib.foley_weights_arena(self._h, C.byref(p), C.byref(n)), "foley_weights_arena")
+        return int(p.value), int(n.value)
+
+    def bcast_weights(self, nccl_comm: int, root: int = 0):
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.foley_bcast_weights(self._h, C.c_void_p(nccl_comm), int(root), _stream()),
+                   "foley_bcast_weights")
 
     # ---- run
     def prepare(self, plan: dict):

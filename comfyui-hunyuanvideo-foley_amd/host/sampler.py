@@ -47,6 +47,26 @@ class FoleyModel:
         self._finish_init()
         return self
 
+    @classmethod
+    def from_reference_state(cls, cfg: DiTConfig, dit_state: Dict[str, torch.Tensor], compute_dtype: torch.dtype, device,
+                             dac_state: Dict[str, torch.Tensor], dac_cfg: DACConfig = DAC48K,
+                             quantization: str = "none") -> "FoleyModel":
+        """Load through the C ABI's reference-keyed path (foley_load_tensor): the library packs the checkpoint
+        tensors on the device into its own arena - no host/packers.py involved.  `dit_state` is expected to hold
+        the parameter values the reference module would hold (nodes.round_params / fp8_round_state_dict)."""
+        self = cls.__new__(cls)
+        self.cfg, self.dac_cfg, self.dtype, self.device = cfg, dac_cfg, compute_dtype, torch.device(device)
+        self.quantization = quantization
+        self.arena = None
+        self.ctx = FoleyContext(cfg, dac_cfg, compute_dtype, self.device)
+        fmt = {"fp8_e4m3fn": 1, "fp8_e5m2": 2}.get(quantization, 0) if compute_dtype == torch.bfloat16 else 0
+        self.ctx.load_reference_state([dit_state, dac_state], fmt)
+        self.empty_clip_feat = dit_state["empty_clip_feat"].detach().to(self.device, torch.float32).reshape(1, -1)
+        self.empty_sync_feat = dit_state["empty_sync_feat"].detach().to(self.device, torch.float32).reshape(1, -1)
+        self._dac_arena = "ctx-owned"
+        self._text_len_fixed = None
+        return self
+
     def _finish_init(self):
         self.ctx = FoleyContext(self.cfg, self.dac_cfg, self.dtype, self.device)
         self.ctx.set_tensors((k, v) for k, v in self.arena.items() if not k.startswith("empty_"))
@@ -64,6 +84,10 @@ class FoleyModel:
         return e.expand(len, -1) if bs is None else e.unsqueeze(0).expand(bs, len, -1)
 
     def attach_dac(self, dac: "FoleyDAC"):
+        if dac is None:
+            if self._dac_arena != "ctx-owned":
+                raise FoleyRuntimeError("no DAC decoder: pass a FoleyDAC or load it by reference key")
+            return                                                 # decoder weights were loaded by reference key
         if self._dac_arena is not dac.arena:
             self.ctx.set_tensors(dac.arena.items())
             self._dac_arena = dac.arena
@@ -169,6 +193,7 @@ def denoise_process_with_generator(visual_feats, text_feats, audio_len_in_s, mod
     model.ctx.sample(latents, use_graph=use_graph, progress=progress)
     audio = model.ctx.dac_decode(latents)
     # (the reference's "trim to exact length" slices the size-1 channel axis: a no-op)
+    sr = dac.sample_rate if dac is not None else model.dac_cfg.sample_rate
     if return_latents:
-        return audio, dac.sample_rate, latents
-    return audio, dac.sample_rate
+        return audio, sr, latents
+    return audio, sr

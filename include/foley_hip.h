@@ -35,12 +35,13 @@
 extern "C" {
 #endif
 
-#define FOLEY_ABI_VERSION 4   /* 4: fp8 weight storage (dtype codes 3/4, foley_gemm_desc.ldw/.wfmt); 3: foley_profile_forward; 2: foley_gemm_desc gained partials / qkv / rstride; foley_op_ln_mod_pending, foley_dac_encode */
+#define FOLEY_ABI_VERSION 5   /* 5: reference-keyed loading (foley_weights_*, foley_load_tensor, foley_bcast_weights); 4: fp8 weight storage (dtype codes 3/4, foley_gemm_desc.ldw/.wfmt); 3: foley_profile_forward; 2: foley_gemm_desc gained partials / qkv / rstride; foley_op_ln_mod_pending, foley_dac_encode */
 
 enum foley_dtype {
   FOLEY_DT_F32 = 0, FOLEY_DT_BF16 = 1, FOLEY_DT_I32 = 2,
   FOLEY_DT_F8E4M3 = 3,  /* OCP e4m3fn, weight storage only (reference FP8WeightWrapper, utils.py:316-366: plain cast, no scales) */
-  FOLEY_DT_F8E5M2 = 4   /* OCP e5m2,   weight storage only */
+  FOLEY_DT_F8E5M2 = 4,  /* OCP e5m2,   weight storage only */
+  FOLEY_DT_F16 = 5      /* accepted by foley_load_tensor as a CHECKPOINT dtype only */
 };
 
 enum foley_status {
@@ -99,6 +100,31 @@ void foley_ctx_destroy(foley_ctx* ctx);
 /* Register one packed tensor (names and layouts: DESIGN.md "packed weight arena"). */
 int foley_set_tensor(foley_ctx* ctx, const char* name, const void* dev_ptr, int dtype, int ndim,
                      const int64_t* shape);
+
+/* ---- Reference-keyed loading (replaces HunyuanModelLoader.load_model nodes.py:72-133 + load_dac_any
+ * utils.py:61-87 for a caller that keeps the reference's checkpoints / loader): hand over the tensors under
+ * their STATE-DICT KEYS and the library packs them on the device into ONE ctx-owned arena (layouts of
+ * (K H D) q/k/v rows, tap-major convs, interleaved SwiGLU pairs, fused single-block
+ * modulation, folded weight-norm, transposed convs as phases x 2 taps) and registers the packed tensors.
+ *   foley_weights_begin(ctx, fmt)      allocate + register; fmt 0: block matrices in the compute dtype,
+ *                                      1 / 2: kept in fp8 e4m3fn / e5m2 (reference _wrap_fp8_inplace,
+ *                                      utils.py:408-485; bf16 compute only)
+ *   foley_load_tensor(ctx, key, ...)   one checkpoint tensor (f32 / bf16 / f16 / fp8, any order), borrowed for
+ *                                      the call; returns 1 for keys the sampling path does not use
+ *                                      (DAC encoder / quantizer, final_layer.adaLN_modulation)
+ *   foley_weights_end(ctx)             fails with FOLEY_ERR_MISSING if a packed tensor is incomplete
+ *   foley_weights_arena                the arena (device pointer, bytes): layout depends on the config only
+ *   foley_bcast_weights(ctx, comm, root, stream)   ONE ncclBroadcast (RCCL over xGMI) of the arena on the
+ *                                      caller's ncclComm_t; non-root ranks call foley_weights_begin first.
+ *                                      (A host that broadcasts the arena itself - e.g. torch.distributed on
+ *                                      the pointer - calls foley_weights_mark_received afterwards.) */
+int foley_weights_begin(foley_ctx* ctx, int weight_format);
+int foley_load_tensor(foley_ctx* ctx, const char* ref_key, const void* dev_ptr, int dtype, int ndim,
+                      const int64_t* shape, void* stream);
+int foley_weights_end(foley_ctx* ctx, void* stream);
+int foley_weights_arena(foley_ctx* ctx, void** dev_ptr, uint64_t* bytes);
+int foley_weights_mark_received(foley_ctx* ctx);
+int foley_bcast_weights(foley_ctx* ctx, void* nccl_comm, int root, void* stream);
 
 /* Step-invariant precompute for one run; allocates/reuses the context workspace. */
 int foley_prepare(foley_ctx* ctx, const foley_plan* plan, void* stream);

@@ -658,3 +658,103 @@ def test_bf16_mode_against_reference_bf16(dev):
           % (e8, d8, rel_err(y8, g12["c5_y32"])))
     assert e8 < 2.5e-2 and rel_err(y8, g12["c5_y32"]) < 1.5 * d8
     assert rel_err(y8, g12["c5_y16"]) > e8          # the fp8-rounded weights are really what runs
+
+
+def _legacy_wn(dsd):
+    """The same DAC checkpoint spelled with legacy weight_g / weight_v keys, and fully folded."""
+    g = {k.replace(".parametrizations.weight.original0", ".weight_g").replace(".parametrizations.weight.original1", ".weight_v"): v
+         for k, v in dsd.items()}
+    from foley_amd.host import packers
+    folded = {k: v for k, v in dsd.items() if ".parametrizations." not in k}
+    for k in dsd:
+        if k.endswith(".parametrizations.weight.original0"):
+            base = k[:-len(".parametrizations.weight.original0")]
+            folded[base + ".weight"] = packers.fold_weight_norm(dsd, base)
+    return g, folded
+
+
+def test_reference_keyed_loader_matches_python_packers(dev):
+    """foley_load_tensor (weights.hip): checkpoint tensors handed over under the REFERENCE's state-dict keys are packed
+    on the device by the library.  Same arena content as host/packers.py: DiT forward and sampler latents
+    bit-identical (fp32, bf16 and fp8-stored weights); DAC waveform to fp32 round-off (the weight-norm fold
+    reduces in a different order).  All three weight-norm spellings, arbitrary tensor order, missing tensors."""
+    from foley_amd import nodes
+    from foley_amd.host import runtime as rt
+    c = C.TINY
+    sd = synth.synth_dit_state_dict(c)
+    dsd = synth.synth_dac_state_dict(C.DAC_TINY, encoder=True)           # encoder keys must be ignored (returns 1)
+    cond = synth.synth_conditioning(c, 1.0, t2a=False)
+    visual = {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]}
+    text = {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]}
+
+    def run(model, dac):
+        gen = torch.Generator("cpu").manual_seed(77)
+        a, _sr, lat = sampler.denoise_process_with_generator(visual, text, 1.0, model, dac, 4.5, 6, 2, "heun-2", generator=gen,
+                                                           return_latents=True)
+        return a.cpu(), lat.cpu()
+
+    dsd_g, dsd_folded = _legacy_wn(dsd)
+    rev = lambda d: dict(reversed(list(d.items())))                       # loading order must not matter
+    for dtype, quant, dac_sd in ((torch.float32, "none", dsd), (torch.bfloat16, "none", rev(dsd_g)),
+                                 (torch.bfloat16, "fp8_e4m3fn", dsd_folded), (torch.bfloat16, "fp8_e5m2", dsd)):
+        sdq = nodes.round_params(sd, dtype)
+        if quant != "none":
+            sdq = nodes.fp8_round_state_dict(sdq, quant, autocast=True, param_dtype=dtype)
+        ref_model = sampler.FoleyModel(c, sdq, dtype, dev, dac_cfg=C.DAC_TINY, quantization=quant)
+        ref_dac = sampler.FoleyDAC(dsd, dev, C.DAC_TINY)
+        a0, l0 = run(ref_model, ref_dac)
+        m = sampler.FoleyModel.from_reference_state(c, rev(sdq) if quant == "none" else sdq, dtype, dev, dac_sd,
+                                                    dac_cfg=C.DAC_TINY, quantization=quant)
+        a1, l1 = run(m, None)
+        assert torch.equal(l0, l1), (dtype, quant)                          # identical packed DiT weights
+        assert rel_err(a1, a0) < 1e-5, (dtype, quant)                       # DAC: fold order only
+        ptr, nbytes = m.ctx.weights_arena()
+        assert ptr % 256 == 0 and nbytes > 0
+        if quant != "none":
+            assert nbytes < 0.62 * sampler.FoleyModel(c, sdq, dtype, dev, dac_cfg=C.DAC_TINY).arena.buffer.numel() + \
+                ref_dac.arena.buffer.numel()
+    # a missing tensor is reported by name, never silently zero
+    ctx = rt.FoleyContext(c, C.DAC_TINY, torch.float32, dev)
+    part = {k: v for k, v in sd.items() if k != "single_blocks.1.linear2.w3.weight"}
+    with pytest.raises(rt.FoleyRuntimeError, match="s1.w13"):
+        ctx.load_reference_state([part, dsd], 0)
+    bad = dict(sd)
+    bad["triple_blocks.0.audio_mlp.fc1.weight"] = torch.zeros(7, 5)
+    with pytest.raises(rt.FoleyRuntimeError, match="unexpected shape"):
+        rt.FoleyContext(c, C.DAC_TINY, torch.float32, dev).load_reference_state([bad, dsd], 0)
+
+
+def test_bcast_weights_on_a_real_rccl_communicator(dev):
+    """foley_bcast_weights: ONE ncclBroadcast of the ctx-owned arena on the caller's ncclComm_t (here a 1-rank RCCL
+    communicator created through the same librccl torch has loaded).  The arena is unchanged and usable."""
+    import ctypes as CT, os
+    c = C.TINY
+    sd = synth.synth_dit_state_dict(c)
+    dsd = synth.synth_dac_state_dict(C.DAC_TINY)
+    m = sampler.FoleyModel.from_reference_state(c, sd, torch.float32, dev, dsd, dac_cfg=C.DAC_TINY)
+    torch.zeros(1, device=dev)
+    rccl = CT.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), mode=CT.RTLD_GLOBAL)
+
+    class UID(CT.Structure):
+        _fields_ = [("internal", CT.c_char * 128)]
+    uid, comm = UID(), CT.c_void_p()
+    rccl.ncclGetUniqueId.argtypes = [CT.POINTER(UID)]
+    rccl.ncclCommInitRank.argtypes = [CT.POINTER(CT.c_void_p), CT.c_int, UID, CT.c_int]
+    rccl.ncclCommDestroy.argtypes = [CT.c_void_p]
+    assert rccl.ncclGetUniqueId(CT.byref(uid)) == 0
+    with torch.cuda.device(dev):
+        assert rccl.ncclCommInitRank(CT.byref(comm), 1, uid, 0) == 0
+    try:
+        ptr, nbytes = m.ctx.weights_arena()
+        before = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        CT.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(CT.c_void_p(before.data_ptr()), CT.c_void_p(ptr), CT.c_size_t(nbytes), 3)
+        m.ctx.bcast_weights(comm.value, root=0)
+        torch.cuda.synchronize()
+        after = torch.empty_like(before)
+        CT.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(CT.c_void_p(after.data_ptr()), CT.c_void_p(ptr), CT.c_size_t(nbytes), 3)
+        assert torch.equal(before, after)
+    finally:
+        rccl.ncclCommDestroy(comm)
+    g5 = golden("g5_dit_tiny")
+    x, t, cond, clip, sync = (g5["a_" + k] for k in ("x", "t", "cond", "clip", "sync"))
+    assert rel_err(_forward(m, x, t, cond, clip, sync), g5["a_y"]) < 2e-5
