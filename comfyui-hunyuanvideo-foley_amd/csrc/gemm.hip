@@ -8,6 +8,8 @@
 // LDS table).  A ring of NS register stages keeps NS-1 K-slices of global loads in flight behind
 // the MFMA block (one barrier per slice).  Workgroup ids are remapped so tiles that share a
 // weight panel run on one XCD (L2).
+#include <cstdlib>
+
 #include "gemm_common.h"
 
 namespace {
@@ -582,14 +584,19 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     else tile = 3;
   }
   if (sizeof(T) == 2 && tile_auto) {   // bf16: loader / consumer wave specialisation of the same tiles
-    if (tile == 5) tile = 15;
-    else if (tile == 9) tile = 19;
+    // Four consumer waves (64x64 / 128x64 wave tiles, a third less LDS fragment traffic) with the loader waves
+    // helping in the epilogue beat the eight-consumer form wherever the grid does not saturate the L2s
+    // (M = 500: q/k/v 22.7 -> 19.1 us, fc1 21.1 -> 16.2, cross-q 21.1 -> 16.5; tools/gemm_timeline.py); the
+    // big gated-residual GEMMs at large M keep eight consumers.  fp8 weights exist in the eight-consumer form.
+    static const bool ws4 = []() { const char* e = getenv("FOLEY_WS4"); return !(e && e[0] == '0'); }();   // A/B switch for tools/
+    if (tile == 5) tile = (g.wfmt || !ws4) ? 15 : 25;
+    else if (tile == 9) tile = (g.wfmt || epi == EPI_GATE_RES || !ws4) ? 19 : 29;
   }
   // channels-last conv k=3 on a 128x128-class grid: the tap-fused wave-specialised kernel stages the activation
   // chunk once for the three taps (a third fewer bytes out of the L2s: lin1 16.4 -> 12.1 us, w2 32.4 -> 23.2 us,
   // w1/w3 49.3 -> 40.0 us at M = 500; tools/gemm_timeline.py).  Large grids use its 256x128 form (tile 23).
-  if (tile_auto && ws_conv3_ok && (tile == 15 || tile == 11 || tile == 13 || tile == 5 || tile == 3 || tile == 2)) tile = 21;
-  if (tile_auto && ws_conv3_ok && (tile == 19 || tile == 9)) tile = 23;   // large grids: the 256x128 tap-fused form (w1/w3 at M = 4000: 329 -> 285 us)
+  if (tile_auto && ws_conv3_ok && (tile == 15 || tile == 25 || tile == 11 || tile == 13 || tile == 5 || tile == 3 || tile == 2)) tile = 21;
+  if (tile_auto && ws_conv3_ok && (tile == 19 || tile == 29 || tile == 9)) tile = 23;   // large grids: the 256x128 tap-fused form (w1/w3 at M = 4000: 329 -> 285 us)
   if (g.wfmt && tile != 15 && tile != 19 && tile != 21 && tile != 23) {   // fp8 weights exist only in the wave-specialised mainloops
     if (!tile_auto) return foley_set_err("GEMM: fp8 weights need tile 15, 19 or 21", __FILE__, __LINE__);
     tile = 15;
@@ -613,7 +620,7 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
       if (al & 15) return foley_set_err("fused head split: operands must be 16-byte aligned", __FILE__, __LINE__);
     }
     if (!(tile == 1 || tile == 2 || tile == 5 || tile == 7 || tile == 8 || tile == 9 || tile == 15 || tile == 19 || tile == 25 || tile == 29))
-      tile = (long)((g.M + 127) / 128) * (g.N / 128) >= 24 ? (sizeof(T) == 2 ? 15 : 5) : 2;
+      tile = (long)((g.M + 127) / 128) * (g.N / 128) >= 24 ? (sizeof(T) == 2 ? (g.wfmt ? 15 : 25) : 5) : 2;
   }
   if (epi != EPI_GATE_RES || g.ksplit == 1 || (g.ksplit == 0 && sizeof(T) == 4)) {
     g.ksplit = 1;   // fp32 (parity) mode keeps a fixed summation order

@@ -162,10 +162,12 @@ template <typename T> struct EpiOutT<T, EPI_STORE_F32> { using type = float; };
 template <typename T> struct EpiOutT<T, EPI_GATE_RES> { using type = float; };
 template <typename T> struct EpiOutT<T, EPI_DAC> { using type = float; };
 
-template <typename T, int EPI, int BM, int BN, int WM, int WN>
+// XW: helper waves (ids >= WM*WN, e.g. the loader waves of the wave-specialised mainloop once their job is
+// done) that hold no accumulators but take their share of the LDS -> global passes.
+template <typename T, int EPI, int BM, int BN, int WM, int WN, int XW = 0>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&acc)[BM / WM / 32][BN / WN / 32],
                                                   unsigned char* lds_raw, int m0, int n0, int ks) {
-  constexpr int NT = WM * WN * 64, TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
+  constexpr int NT = (WM * WN + XW) * 64, TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
   using OutT = typename EpiOutT<T, EPI>::type;
   constexpr int CP = VecStore<OutT>::CP;                    // output elements per lane and pass
   constexpr int OBN = EPI == EPI_SILUGATE_T ? BN / 2 : BN;  // output columns of the tile
@@ -175,13 +177,15 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, fi = lane & 31, kh = lane >> 5;
   __syncthreads();   // every wave is done reading the last K-slice
+  if (XW == 0 || wave < WM * WN) {
 #pragma unroll
-  for (int i = 0; i < FM; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < FN; ++j)
+      for (int j = 0; j < FN; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e)
-        tile[(wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh) * BN + wn * TN + j * 32 + fi] = acc[i][j][e];
+        for (int e = 0; e < 16; ++e)
+          tile[(wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh) * BN + wn * TN + j * 32 + fi] = acc[i][j][e];
+  }
   __syncthreads();
 
   const int tr = tid / TPR, tc = (tid % TPR) * CP;   // row inside a pass, output column inside the tile
@@ -294,23 +298,25 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
 // transposed [clip, H, 128, pitch] for the bf16 attention kernel, 8 tokens (16 bytes) per store on
 // destination-aligned groups.  Same math as qkv_split_kernel (rowops.hip), which stays for callers
 // that have the projection in memory.
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int XW = 0>
 __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&acc)[BM / WM / 32][BN / WN / 32],
                                                   unsigned char* lds_raw, int m0, int n0) {
   static_assert(BN == 128, "one head per tile");
-  constexpr int NT = WM * WN * 64, TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
+  constexpr int NT = (WM * WN + XW) * 64, TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
   const QkvSplitArgs& q = g.qs;
   float* tile = (float*)lds_raw;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, fi = lane & 31, kh = lane >> 5;
   __syncthreads();
+  if (XW == 0 || wave < WM * WN) {
 #pragma unroll
-  for (int i = 0; i < FM; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < FN; ++j)
+      for (int j = 0; j < FN; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e)
-        tile[(wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh) * BN + wn * TN + j * 32 + fi] = acc[i][j][e];
+        for (int e = 0; e < 16; ++e)
+          tile[(wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh) * BN + wn * TN + j * 32 + fi] = acc[i][j][e];
+  }
   __syncthreads();
   const int hidx = n0 >> 7;
   const int o = hidx / q.H, h = hidx - o * q.H;   // operand (q, k, v), head

@@ -199,7 +199,15 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
       g.dbg[(long)blockIdx.x * 4 + 2] = (long long)__builtin_readcyclecounter() - t_start;
       g.dbg[(long)blockIdx.x * 4 + 3] = nk;
     }
-    return;   // loaders take no part in the epilogue (a finished wave leaves the barrier count)
+    // Eight-consumer tiles: the loaders are done (a finished wave leaves the barrier count).  Four-consumer
+    // tiles: the epilogue's LDS -> global passes would run on half the threads, so the loaders stay and
+    // take their share of the rows (they hold no accumulators).
+    if constexpr (NW == 4) {
+      f32x16 none[FM][FN];
+      if constexpr (EPI == EPI_QKV_SPLIT) gemm_epilogue_qkv<T, BM, BN, WM, WN, LW>(g, none, lds, m0, n0);
+      else if (g.vec_out) gemm_epilogue_lds<T, EPI, BM, BN, WM, WN, LW>(g, none, lds, m0, n0, ks);
+    }
+    return;
   }
 
   // -------------------------------------------------------------------- consumer wave
@@ -397,10 +405,11 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
   }
   if (PF > 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink)::"memory");   // every prefetch has written back: the register is free again
   tl_stamp(g, 2);
+  constexpr int XW = NW == 4 ? LW : 0;   // helper waves of the epilogue (see the loader branch)
   if constexpr (EPI == EPI_QKV_SPLIT) {
-    gemm_epilogue_qkv<T, BM, BN, WM, WN>(g, acc, lds, m0, n0);
+    gemm_epilogue_qkv<T, BM, BN, WM, WN, XW>(g, acc, lds, m0, n0);
   } else {
-    if (g.vec_out) gemm_epilogue_lds<T, EPI, BM, BN, WM, WN>(g, acc, lds, m0, n0, ks);
+    if (g.vec_out) gemm_epilogue_lds<T, EPI, BM, BN, WM, WN, XW>(g, acc, lds, m0, n0, ks);
     else gemm_epilogue<T, EPI, FM, FN, TM, TN>(g, acc, m0, n0, wm, wn, fi, kh, ks);
   }
   tl_stamp(g, 3);

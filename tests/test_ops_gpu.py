@@ -45,9 +45,11 @@ def _q(t, dtype):   # round a CPU reference operand through the compute dtype
     # wave-specialised mainloop (bf16): 128x128 / 256x128 tiles, ragged M and N edges, K = one slice .. many
     (500, 1536, 1536, 15), (500, 1536, 1536, 19), (37, 200, 64, 15), (700, 640, 4608, 19), (1000, 136, 320, 15),
     (257, 129, 128, 19),
+    # four consumer waves (64x64 / 128x64 wave tiles) + loader waves helping in the epilogue
+    (500, 1536, 1536, 25), (500, 1536, 1536, 29), (37, 200, 64, 25), (700, 640, 4608, 29), (1000, 136, 320, 25), (257, 129, 128, 29),
 ])
 def test_gemm_linear(dev, dtype, M, N, K, tile):
-    if tile in (15, 19) and dtype == torch.float32:
+    if tile in (15, 19, 25, 29) and dtype == torch.float32:
         pytest.skip("wave-specialised tiles are bf16 only")
     A, W, b = _rand((M, K), 1), _rand((N, K), 2, 1 / math.sqrt(K)), _rand((N,), 3, 0.1)
     ref = F.linear(_q(A, dtype), _q(W, dtype), b)
@@ -70,7 +72,7 @@ def test_gemm_transpose_detecting(dev, dtype, tile):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("tile", [0, 15, 19])
+@pytest.mark.parametrize("tile", [0, 15, 19, 25, 29])
 @pytest.mark.parametrize("epi", ["store_t", "silu", "gelu", "silugate", "gate_res_vec", "gate_res_tok", "addend"])
 def test_gemm_epilogues(dev, dtype, epi, tile):
     if tile and dtype == torch.float32:
@@ -466,12 +468,12 @@ def test_qkv_split_bf16_transposed_v(dev):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,L,H,Lv,tile", [(2, 11, 3, 4, 0), (2, 250, 2, 40, 0), (3, 70, 2, 3, 5), (2, 250, 1, 40, 9),
-                                           (2, 250, 2, 40, 15), (3, 70, 1, 3, 19),
+                                           (2, 250, 2, 40, 15), (3, 70, 1, 3, 19), (2, 250, 2, 40, 25), (3, 70, 1, 3, 29),
                                            (4, 37, 2, 8, 2)])
 def test_gemm_fused_head_split(dev, dtype, B, L, H, Lv, tile):
     """q/k/v projection with the head split fused into the GEMM epilogue (RMSNorm + RoPE into
     [B, H, S, 128]; bf16: V transposed [B, H, 128, pitch]) vs the unfused oracle math."""
-    if tile in (9, 15, 19) and dtype == torch.float32:
+    if tile in (9, 15, 19, 25, 29) and dtype == torch.float32:
         pytest.skip("bf16-only tile")
     K = 256
     S = L + Lv
