@@ -1,6 +1,8 @@
 // HBM-bound row kernels of the Foley path: LayerNorm+modulate, RMSNorm+RoPE head split, small
 // elementwise helpers, the solver update and the DAC output convolution.  All arithmetic fp32;
 // one wavefront per row with 16-byte vector accesses and wave-level (DPP) reductions.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace {
@@ -124,6 +126,107 @@ __global__ __launch_bounds__(128) void ln_mod_kernel(const LnPair pr, int D, flo
       for (int u = 0; u < 4; ++u) y[u] = (v[i][u] - mean) * rstd * (1.0f + cv[i][u]) + hv[i][u];
       Pack4<OutT>::store(orow + c * 4, y);
     }
+  }
+}
+
+// Same operation with WPR waves cooperating on one row (D = 64 * WPR * MAXV float4): at M = 500 the
+// one-wave-per-row kernel puts 500 waves on 256 CUs, each walking a 6 KiB row (plus up to five partial
+// slabs) alone - latency bound, not bandwidth bound.  Splitting a row over WPR waves multiplies the
+// loads in flight; the two statistics cross the waves through LDS.
+template <typename OutT, int MAXV, bool PEND, int WPR>
+__global__ __launch_bounds__(128 * WPR) void ln_mod_wide_kernel(const LnPair pr, int D, float eps) {
+  __shared__ float red[2][2][WPR];   // [row of the block][statistic][wave of the row]
+  const int sel = (int)blockIdx.x >= pr.blocks0 ? 1 : 0;
+  const LnArgs& A = pr.a[sel];
+  const int M = A.M;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int rb = wave / WPR, part = wave % WPR;               // row of the block (0/1), column part
+  const int row_u = ((int)blockIdx.x - (sel ? pr.blocks0 : 0)) * 2 + rb;
+  const bool live = row_u < M;
+  const int row = live ? row_u : M - 1;                       // dead waves shadow the last row (no stores)
+  const int c0 = part * (MAXV * 64) + lane;                   // first float4 of this lane; stride 64
+  f32x4* xr = (f32x4*)(A.x + (long)row * D);
+  const f32x4* sh = A.shift.p ? (const f32x4*)rb_row(A.shift, row) : nullptr;
+  const f32x4* sc = A.scale.p ? (const f32x4*)rb_row(A.scale, row) : nullptr;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 v[MAXV], hv[MAXV], cv[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = c0 + i * 64;
+    v[i] = xr[c];
+    hv[i] = sh ? sh[c] : z4;
+    cv[i] = sc ? sc[c] : z4;
+  }
+  if (PEND && A.pend.partials) {
+    constexpr int SB = 6;
+    const LnPending& P = A.pend;
+    const f32x4* gp = (const f32x4*)rb_row(P.gate, row);
+    const f32x4* bp = (const f32x4*)P.bias;
+    f32x4 acc[MAXV], gt[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = c0 + i * 64;
+      gt[i] = gp[c];
+      acc[i] = bp ? bp[c] : z4;
+    }
+    for (int s0 = 0; s0 < P.k; s0 += SB) {
+      f32x4 t[SB][MAXV];
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        const int s = min(s0 + u, P.k - 1);
+        const f32x4* pr_ = (const f32x4*)(P.partials + s * P.stride + (long)row * D);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) t[u][i] = pr_[c0 + i * 64];
+      }
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        const float w = (s0 + u < P.k) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][e] += w * t[u][i][e];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[i][e] += gt[i][e] * acc[i][e];
+      if (live) xr[c0 + i * 64] = v[i];
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  s = wave_sum(s);
+  if (lane == 0) red[rb][0][part] = s;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < WPR; ++w) tot += red[rb][0][w];     // fixed order: every wave of the row gets the same mean
+  const float mean = tot / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float d = v[i][u] - mean;
+      q += d * d;
+    }
+  q = wave_sum(q);
+  if (lane == 0) red[rb][1][part] = q;
+  __syncthreads();
+  float qt = 0.f;
+#pragma unroll
+  for (int w = 0; w < WPR; ++w) qt += red[rb][1][w];
+  const float rstd = 1.0f / sqrtf(qt / (float)D + eps);
+  if (!live) return;
+  OutT* orow = (OutT*)A.out + (long)row * D;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    f32x4 y;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) y[u] = (v[i][u] - mean) * rstd * (1.0f + cv[i][u]) + hv[i][u];
+    Pack4<OutT>::store(orow + (c0 + i * 64) * 4, y);
   }
 }
 
@@ -469,6 +572,39 @@ int launch_ln_mod_pair(const LnArgs& a0, const LnArgs& a1, int D, float eps, int
       else FOLEY_LAUNCH((ln_mod_kernel<bf16_t, V, false>), grid, block, 0, st, pr, D, eps);          \
     }                                                                                                      \
   }
+  // rows that split evenly over 2 / 3 waves (D = 1536: 3 waves x 2 float4 per lane; 1408 / 256: one wave)
+  static const int wide = []() { const char* e = getenv("FOLEY_LN_WIDE"); return e ? atoi(e) : 3; }();   // A/B switch (0 = one wave per row)
+  const int total_rows = a0.M + a1.M;
+  if (wide && total_rows <= 4096 && D % (4 * 64 * 3) == 0 && D / (4 * 64 * 3) <= 4 && wide == 3) {
+#define FOLEY_LNW(V, W)                                                                                               \
+    {                                                                                                                  \
+      dim3 blk(128 * W);                                                                                               \
+      if (pend) {                                                                                                      \
+        if (f32o) FOLEY_LAUNCH((ln_mod_wide_kernel<float, V, true, W>), grid, blk, 0, st, pr, D, eps);                \
+        else FOLEY_LAUNCH((ln_mod_wide_kernel<bf16_t, V, true, W>), grid, blk, 0, st, pr, D, eps);                    \
+      } else {                                                                                                         \
+        if (f32o) FOLEY_LAUNCH((ln_mod_wide_kernel<float, V, false, W>), grid, blk, 0, st, pr, D, eps);               \
+        else FOLEY_LAUNCH((ln_mod_wide_kernel<bf16_t, V, false, W>), grid, blk, 0, st, pr, D, eps);                   \
+      }                                                                                                                \
+    }
+    const int v3 = D / (4 * 64 * 3);
+    if (v3 == 1) FOLEY_LNW(1, 3)
+    else if (v3 == 2) FOLEY_LNW(2, 3)
+    else if (v3 == 3) FOLEY_LNW(3, 3)
+    else FOLEY_LNW(4, 3)
+    FOLEY_LAUNCH_CHECK();
+    return 0;
+  }
+  if (wide == 2 && total_rows <= 4096 && D % (4 * 64 * 2) == 0 && D / (4 * 64 * 2) <= 4) {
+    const int v2 = D / (4 * 64 * 2);
+    if (v2 == 1) FOLEY_LNW(1, 2)
+    else if (v2 == 2) FOLEY_LNW(2, 2)
+    else if (v2 == 3) FOLEY_LNW(3, 2)
+    else FOLEY_LNW(4, 2)
+    FOLEY_LAUNCH_CHECK();
+    return 0;
+  }
+#undef FOLEY_LNW
   if (need <= 2) FOLEY_LN(2)
   else if (need <= 4) FOLEY_LN(4)
   else if (need <= 6) FOLEY_LN(6)
