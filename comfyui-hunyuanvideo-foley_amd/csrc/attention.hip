@@ -7,6 +7,8 @@
 // in the B-operand layout of the second MFMA (O^T += V^T P^T) - no LDS, no cross-lane shuffles.
 //   MFMA 32x32x2 operand layout: A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31],
 //   D[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31].
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace {
@@ -183,17 +185,13 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
   const int nt = (a.Skv + 31) >> 5;
   const int t0 = (nt * w) >> 2, t1 = (nt * (w + 1)) >> 2;
   const int pi = 16 * ((j >> 2) & 1) + (j & 3) + 4 * (j >> 3);  // A-row j carries key kt + pi
-  for (int t = t0; t < t1; ++t) {
-    const int kt = t * 32;
+  // one 32-key tile: scores (K fragments kf), online softmax, P V (V^T fragments vf)
+  auto tile = [&](int kt, const bf16x8 (&kf)[8], const bf16x8 (&vf)[2][4]) {
     f32x16 s;
 #pragma unroll
     for (int e = 0; e < 16; ++e) s[e] = 0.f;
-    {
-      const bf16_t* p = K + (long)min(kt + pi, a.Skv - 1) * HD + 8 * kh;
 #pragma unroll
-      for (int st = 0; st < 8; ++st)
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(p + 16 * st), qf[st], s, 0, 0, 0);
-    }
+    for (int st = 0; st < 8; ++st) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[st], qf[st], s, 0, 0, 0);
     // s[e] = score(key kt + 16*kh + e, query q0 + j)
     float mx = -INFINITY;
 #pragma unroll
@@ -222,10 +220,40 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const bf16x8 vf = *(const bf16x8*)(VT + (long)(d * 32 + j) * a.vt_pitch + kt + 16 * kh + 8 * u);
-        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[u], o[d], 0, 0, 0);
-      }
+      for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[u][d], pb[u], o[d], 0, 0, 0);
+  };
+  auto load_k = [&](int kt, bf16x8 (&kf)[8]) {
+    const bf16_t* p = K + (long)min(kt + pi, a.Skv - 1) * HD + 8 * kh;
+#pragma unroll
+    for (int st = 0; st < 8; ++st) kf[st] = *(const bf16x8*)(p + 16 * st);
+  };
+  auto load_v = [&](int kt, bf16x8 (&vf)[2][4]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) vf[u][d] = *(const bf16x8*)(VT + (long)(d * 32 + j) * a.vt_pitch + kt + 16 * kh + 8 * u);
+  };
+  if (t1 - t0 <= 2) {
+    // The small grids this kernel serves (S <= ~300: one or two key tiles per wave) are a chain of
+    // dependent memory latencies - K tile, then V tile, per key tile.  Every operand of the wave's
+    // (at most two) tiles is requested up front, before the first MFMA: one round trip instead of four.
+    bf16x8 k0[8], k1[8], v0[2][4], v1[2][4];
+    const int kta = t0 * 32, ktb = min(t0 + 1, nt - 1) * 32;   // ktb is only consumed when the wave owns two tiles
+    if (t1 > t0) {
+      load_k(kta, k0);
+      load_k(ktb, k1);
+      load_v(kta, v0);
+      load_v(ktb, v1);
+      tile(kta, k0, v0);
+      if (t1 - t0 == 2) tile(ktb, k1, v1);
+    }
+  } else {
+    for (int t = t0; t < t1; ++t) {
+      bf16x8 kf[8], vf[2][4];
+      load_k(t * 32, kf);
+      load_v(t * 32, vf);
+      tile(t * 32, kf, vf);
+    }
   }
 
   // merge the four key ranges: wave w finalises d-fragment w
@@ -404,7 +432,10 @@ __global__ __launch_bounds__(256) void attn_bf16_wide_kernel(const AttnArgs a) {
 
 }  // namespace
 
-int launch_attention(const AttnArgs& a, int out_dtype, hipStream_t st) {
+int launch_attention(const AttnArgs& a_in, int out_dtype, hipStream_t st) {
+  static const int no_preload = []() { const char* e = getenv("FOLEY_ATTN_PRELOAD"); return (e && e[0] == '0') ? 1 : 0; }();
+  AttnArgs a = a_in;
+  a.no_preload = no_preload;
   if (a.Sq <= 0 || a.Skv <= 0) return foley_set_err("attention: empty sequence", __FILE__, __LINE__);
   dim3 grid((a.Sq + 31) / 32, a.H, a.Bq), block(64);
   const dim3 grid1(grid.x * grid.y * grid.z);   // bf16 kernels: 1-D grid, XCD-aware remap inside

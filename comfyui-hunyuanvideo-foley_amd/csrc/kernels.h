@@ -111,6 +111,7 @@ struct AttnArgs {
   int split;
   int in_dtype;
   int vt_pitch;
+  int no_preload;   // set by the launcher (A/B switch FOLEY_ATTN_PRELOAD=0): small-grid kernel without the up-front operand requests
 };
 int launch_attention(const AttnArgs& a, int out_dtype, hipStream_t st);
 
