@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
   const bf16_t* __restrict__ Q = (const bf16_t*)a.q + ((long)(b * a.H + h) * a.Sq) * HD;
   const bf16_t* __restrict__ K = (const bf16_t*)a.k + ((long)(bk * a.H + h) * a.Skv) * HD;
   const bf16_t* __restrict__ VT = (const bf16_t*)a.v + ((long)(bk * a.H + h) * HD) * a.vt_pitch;
-  const float scale = 0.08838834764831845f;
+  const float scale2 = 0.08838834764831845f * 1.4426950408889634f;   // log2(e) / sqrt(128)
 
   bf16x8 qf[8];
   {
@@ -192,31 +192,36 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
     for (int e = 0; e < 16; ++e) s[e] = 0.f;
 #pragma unroll
     for (int st = 0; st < 8; ++st) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[st], qf[st], s, 0, 0, 0);
-    // s[e] = score(key kt + 16*kh + e, query q0 + j)
+    // s[e] = score(key kt + 16*kh + e, query q0 + j), kept in the log2 domain (scale2 = log2(e)/sqrt(128)):
+    // the exponentials are single v_exp_f32 instructions
     float mx = -INFINITY;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      s[e] = (kt + 16 * kh + e < a.Skv) ? s[e] * scale : -INFINITY;
+      s[e] = (kt + 16 * kh + e < a.Skv) ? s[e] * scale2 : -INFINITY;
       mx = fmaxf(mx, s[e]);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = expf(m_run - m_new);
     float ps = 0.f;
     bf16x8 pb[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const float pv = expf(s[e] - m_new);
+      const float pv = __builtin_amdgcn_exp2f(s[e] - m_new);
       ps += pv;
       pb[e >> 3][e & 7] = (__bf16)pv;
     }
     ps += __shfl_xor(ps, 32, 64);
-    l_run = l_run * alpha + ps;
+    // the 64 accumulator rescales only when some query's running maximum moved (rare after the first tiles)
+    if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // exp2(-inf) = 0 on the first tile
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+    }
+    l_run += ps;
     m_run = m_new;
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
   float wt[4], L = 0.f;
 #pragma unroll
   for (int x = 0; x < 4; ++x) {
-    wt[x] = expf(sM[x][j] - mstar);
+    wt[x] = __builtin_amdgcn_exp2f(sM[x][j] - mstar);   // running maxima live in the log2 domain
     L += wt[x] * sL[x][j];
   }
   const int tok = q0 + j;
@@ -326,7 +331,7 @@ __global__ __launch_bounds__(256) void attn_bf16_wide_kernel(const AttnArgs a) {
   const bf16_t* __restrict__ Q = (const bf16_t*)a.q + ((long)(b * a.H + h) * a.Sq) * HD;
   const bf16_t* __restrict__ K = (const bf16_t*)a.k + ((long)(bk * a.H + h) * a.Skv) * HD;
   const bf16_t* __restrict__ VT = (const bf16_t*)a.v + ((long)(bk * a.H + h) * HD) * a.vt_pitch;
-  const float scale = 0.08838834764831845f;
+  const float scale2 = 0.08838834764831845f * 1.4426950408889634f;   // log2(e) / sqrt(128)
 
   bf16x8 qf[8];
   {
@@ -377,31 +382,36 @@ __global__ __launch_bounds__(256) void attn_bf16_wide_kernel(const AttnArgs a) {
 #pragma unroll
     for (int st = 0; st < 8; ++st)
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Ks + pi * KP + (16 * st + 8 * kh) * 2), qf[st], s, 0, 0, 0);
-    // s[e] = score(key kt + 16*kh + e, query q0 + j)
+    // s[e] = score(key kt + 16*kh + e, query q0 + j), kept in the log2 domain (scale2 = log2(e)/sqrt(128)):
+    // the exponentials are single v_exp_f32 instructions
     float mx = -INFINITY;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      s[e] = (kt + 16 * kh + e < a.Skv) ? s[e] * scale : -INFINITY;
+      s[e] = (kt + 16 * kh + e < a.Skv) ? s[e] * scale2 : -INFINITY;
       mx = fmaxf(mx, s[e]);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = expf(m_run - m_new);
     float ps = 0.f;
     bf16x8 pb[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const float pv = expf(s[e] - m_new);
+      const float pv = __builtin_amdgcn_exp2f(s[e] - m_new);
       ps += pv;
       pb[e >> 3][e & 7] = (__bf16)pv;
     }
     ps += __shfl_xor(ps, 32, 64);
-    l_run = l_run * alpha + ps;
+    // the 64 accumulator rescales only when some query's running maximum moved (rare after the first tiles)
+    if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // exp2(-inf) = 0 on the first tile
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+    }
+    l_run += ps;
     m_run = m_new;
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
