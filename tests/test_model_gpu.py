@@ -549,9 +549,13 @@ def test_single_rank_nccl_bundle_adoption(tiny, dev):
 def test_bench_single_rank_forced_dist(dev):
     """bench.py under a launcher-style environment (RANK/WORLD_SIZE set, nccl process group, the single
     broadcast) on one GPU: exits 0 and prints the JSON line with the per-kernel roofline."""
-    import json, os, subprocess, sys
+    import json, os, socket, subprocess, sys
     from conftest import ROOT
-    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611",
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                FOLEY_BENCH_FORCE_DIST="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--model", "tiny", "--duration", "1",
                         "--steps", "1", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
