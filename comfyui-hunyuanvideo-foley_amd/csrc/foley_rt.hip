@@ -9,11 +9,18 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
 
 thread_local FoleyProfHook g_foley_prof = {nullptr, nullptr};
+
+// Contexts are independent, but two of them may be driven from two threads of one process (node-level data
+// parallelism, host/sampler.py::denoise_process_multi).  The set-up phases - workspace allocation and the
+// stream capture of the iteration graph - are serialised process-wide (allocation calls from one thread
+// while another thread captures are not safe in every HIP runtime); the long replay loops run concurrently.
+static std::mutex g_setup_mutex;
 
 // --------------------------------------------------------------------------- errors
 static thread_local std::string g_err;
@@ -425,6 +432,7 @@ static int resolve_forward_weights(foley_ctx* c) {
 // iteration, the triple blocks' AdaLN tables, text K/V per block, cond/visual/sync embedders.
 extern "C" int foley_prepare(foley_ctx* c, const foley_plan* pl, void* stream_v) {
   if (!c || !pl) return FAIL(FOLEY_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> setup_lock(g_setup_mutex);
   hipStream_t st = (hipStream_t)stream_v;
   HIPTRY(hipSetDevice(c->device));
   const foley_config& f = c->cfg;
@@ -930,6 +938,7 @@ extern "C" int foley_sample(foley_ctx* c, float* latents, int use_graph, foley_p
     // Every per-iteration value is read from device memory (step counter, tables) and every
     // buffer is context-owned, so ONE captured iteration replays for the whole loop and for
     // later runs of the same shape.
+    std::lock_guard<std::mutex> setup_lock(g_setup_mutex);
     hipStream_t cs;
     HIPTRY(hipStreamSynchronize(st));
     HIPTRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
@@ -988,11 +997,14 @@ extern "C" int foley_dac_decode(foley_ctx* c, const float* latents, int clips, i
       maxel = std::max(maxel, (size_t)t * ch);
     }
   }
-  HIPTRY(hipStreamSynchronize(st));
-  TRY(grow(c->dacP, maxel * clips * 4));
-  TRY(grow(c->dacQ, maxel * clips * 4));
-  TRY(grow(c->dacR, maxel * clips * 4));
-  TRY(grow(c->dacZ, (size_t)clips * T * L * 4 * 2));
+  {
+    std::lock_guard<std::mutex> setup_lock(g_setup_mutex);
+    HIPTRY(hipStreamSynchronize(st));
+    TRY(grow(c->dacP, maxel * clips * 4));
+    TRY(grow(c->dacQ, maxel * clips * 4));
+    TRY(grow(c->dacR, maxel * clips * 4));
+    TRY(grow(c->dacZ, (size_t)clips * T * L * 4 * 2));
+  }
   float *P = (float*)c->dacP.p, *Q = (float*)c->dacQ.p, *R = (float*)c->dacR.p;
   float* Z0 = (float*)c->dacZ.p;
   float* Z1 = Z0 + (size_t)clips * T * L;
