@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -635,6 +636,15 @@ static int prof_end(foley_ctx* c, hipStream_t st) {
     TRY(prof_end(c, st));                         \
   } while (0)
 
+// The single-block modulation GEMM (510 GFLOP, depends on the iteration index only) runs IN LINE at the head
+// of the forward.  Round 1 overlapped it with the two-stream blocks on a side stream; with the faster block
+// kernels of round 2 its 5184 workgroups only steal CUs from them (A/B in one box: 448.5 -> 439.5 ms per
+// 50-iteration loop at bs=1, 1753 -> 1741 ms at bs=8).  FOLEY_SMOD_SIDE=1 restores the side stream.
+static bool smod_inline() {
+  static const bool v = []() { const char* e = getenv("FOLEY_SMOD_SIDE"); return !(e && e[0] == '1'); }();
+  return v;
+}
+
 static int run_forward(foley_ctx* c, hipStream_t st) {
   const foley_config& f = c->cfg;
   const foley_plan& pl = c->plan;
@@ -653,13 +663,13 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
   auto af = [&](double b, double sq, double skv) { return 4.0 * b * H * sq * skv * 128.0; };
   auto ab = [&](double b, double sq, double skv) { return (2.0 * b * H * sq * 128.0 + 2.0 * b * H * skv * 128.0) * (double)es; };
 
-  // ---- side stream: per-token conditioning of the single-stream blocks, SiLU(add_sync + vec)
-  // (hifi_foley.py:866-867), and every single block's modulation GEMM (hifi_foley.py:366).  They
-  // depend on the iteration only, and are identical for every clip of a CFG half (M = ncfg*La).
-  // (Profiling runs them in line on the main stream so that the brackets do not overlap.)
+  // ---- per-token conditioning of the single-stream blocks, SiLU(add_sync + vec) (hifi_foley.py:866-867),
+  // and every single block's modulation GEMM (hifi_foley.py:366).  They depend on the iteration only, and
+  // are identical for every clip of a CFG half (M = ncfg*La).  In line by default (see smod_inline()).
   {
-    hipStream_t sd = c->prof.on ? st : c->side;
-    if (!c->prof.on) {
+    const bool inl = c->prof.on || smod_inline();
+    hipStream_t sd = inl ? st : c->side;
+    if (!inl) {
       HIPTRY(hipEventRecord(c->ev_fork, st));
       HIPTRY(hipStreamWaitEvent(sd, c->ev_fork, 0));
     }
@@ -673,7 +683,7 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
     }
     // the join point always exists (also with depth_single == 0): a forked capture stream must be
     // joined before the capture ends, and eager callers must not race on svec
-    if (!c->prof.on) HIPTRY(hipEventRecord(c->ev_mod[0], sd));
+    if (!inl) HIPTRY(hipEventRecord(c->ev_mod[0], sd));
   }
 
   // audio_embedder (conv k=1 == linear over the transposed latents) + add_sync (hifi_foley.py:768, 838-839)
@@ -779,7 +789,7 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
   }
 
   // join: the single blocks' modulation table is ready (profiling ran it in line)
-  if (!c->prof.on) HIPTRY(hipStreamWaitEvent(st, c->ev_mod[0], 0));
+  if (!c->prof.on && !smod_inline()) HIPTRY(hipStreamWaitEvent(st, c->ev_mod[0], 0));
   const int Hc = f.conv_hidden;
   for (int blk = 0; blk < f.depth_single; ++blk) {
     const SingleW& w = W.s[blk];
