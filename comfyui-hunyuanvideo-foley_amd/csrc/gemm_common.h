@@ -18,7 +18,7 @@ template <> struct Frag<bf16_t> {
 // dbg_mode 0: 4 stamps per workgroup.  dbg_mode 1: workgroup 0 adds its prologue / K-loop / epilogue
 // ticks and a launch count to dbg[0..3] (totals over every GEMM of a forward pass).
 __device__ __forceinline__ void tl_stamp(const GemmArgs& g, int slot) {
-  if (!g.dbg || threadIdx.x != 0 || (g.dbg_mode & 0xff) == 2) return;
+  if (!g.dbg || threadIdx.x != 0 || (g.dbg_mode & 0xff) >= 2) return;
   const long long t = wall_clock64();
   if ((g.dbg_mode & 0xff) == 0) {
     g.dbg[(long)blockIdx.x * 4 + slot] = t;

@@ -171,9 +171,14 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
         set_tap(ld_toff);
       }
     };
+    // dbg_mode 3 (tools/gemm_timeline.py --prologue): where the ring fill spends its time - entry, ring
+    // issued, first slice landed, first barrier passed (wall clock, first loader wave)
+    const bool pstamp = g.dbg && (g.dbg_mode & 0xff) == 3 && lw == 0 && lane == 0;
+    if (pstamp) g.dbg[(long)blockIdx.x * 4 + 0] = wall_clock64();
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
       if (s < nk) issue(s);
+    if (pstamp) g.dbg[(long)blockIdx.x * 4 + 1] = wall_clock64();
     int stage = 0;
     // dbg_mode 2 (tools/gemm_timeline.py --waits): the first loader wave accounts where it waits - for
     // memory (s_waitcnt: the oldest slice has not landed) or at the barrier (the consumers are not done)
@@ -185,7 +190,9 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
       if (kt + NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * (AI + BI)) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const long long tb = acct ? (long long)__builtin_readcyclecounter() : 0;
+      if (pstamp && kt == 0) g.dbg[(long)blockIdx.x * 4 + 2] = wall_clock64();
       __builtin_amdgcn_s_barrier();  // slice kt visible to the consumers; they are done with slice kt-1
+      if (pstamp && kt == 0) g.dbg[(long)blockIdx.x * 4 + 3] = wall_clock64();
       if (acct) {
         const long long tc = (long long)__builtin_readcyclecounter();
         if (kt > 0) { t_mem += tb - ta; t_bar += tc - tb; }   // the ring fill (kt == 0) is the prologue, stamped separately
