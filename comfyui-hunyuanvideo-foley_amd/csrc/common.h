@@ -66,6 +66,11 @@ __device__ __forceinline__ float wave_sum(float v) {
 // Row-broadcast operand addressing shared by the row kernels and GEMM epilogues.
 //   mode 0: one vector for every row            (index 0)
 //   mode 1: rows ordered [cfg][clip][l]; operand indexed [cfg][l]
+//   mode 2: rows ordered [cfg][clip][l]; the operand has Ls rows per cfg and token l reads row
+//           nearest_exact(l) = min(floor((l + 0.5) * Ls / L), Ls - 1): F.interpolate(mode="nearest-exact")
+//           folded into the addressing (hifi_foley.py:759-762 up-samples the sync tokens to the audio
+//           frame rate; everything computed per audio frame from them alone only has Ls distinct rows).
+//           float32 arithmetic exactly as torch does it (scale = float(Ls) / float(L), one multiply).
 struct RowBcast {
   const float* p;       // base (may be null => operand absent)
   long ld;              // elements between operand rows
@@ -74,12 +79,20 @@ struct RowBcast {
   int L;                // tokens per clip
   const int* step_ptr;  // optional device-resident iteration counter
   long step_stride;     // elements added per iteration
+  int Ls;               // mode 2: operand rows per cfg
+  float scale;          // mode 2: float(Ls) / float(L)
 };
+
+__host__ __device__ __forceinline__ int rb_nearest_exact(int l, float scale, int Ls) {
+  const int s = (int)floorf(((float)l + 0.5f) * scale);
+  return s < Ls ? s : Ls - 1;
+}
 
 __device__ __forceinline__ const float* rb_row(const RowBcast& b, int r) {
   const float* p = b.p;
   if (b.step_ptr) p += (long)(*b.step_ptr) * b.step_stride;
   if (b.mode == 1) p += ((long)(r / b.rows_per_cfg) * b.L + (r % b.L)) * b.ld;
+  else if (b.mode == 2) p += ((long)(r / b.rows_per_cfg) * b.Ls + rb_nearest_exact(r % b.L, b.scale, b.Ls)) * b.ld;
   return p;
 }
 

@@ -123,7 +123,7 @@ struct foley_ctx {
   void* txt_k = nullptr;            // [n_triple][ncfg, H, Lt, 128]     (same dtype rule as Q/K/V)
   void* txt_v = nullptr;            // [n_triple][ncfg, H, Lt, 128] or transposed [.., 128, ceil32(Lt)]
   float* v_cond0 = nullptr;         // [ncfg, Lv, D]
-  float* add_sync = nullptr;        // [ncfg, La, D]
+  float* sync_tok = nullptr;        // [ncfg, Ls, D] sync tokens after sync_in; audio frame l reads row nearest_exact(l) (RowBcast mode 2)
   int* ident_idx = nullptr;         // 0..max(Lv,La)-1
   // forward workspace
   void* xin = nullptr;              // T [M, C]
@@ -140,8 +140,8 @@ struct foley_ctx {
   void* att_v = nullptr;            // T [Mv, D]
   void* hid_a = nullptr;            // T [M, max(mlp_hidden, conv_hidden)]
   void* hid_v = nullptr;            // T [Mv, mlp_hidden]
-  void* svec = nullptr;             // T [ncfg*La, D]
-  float* smod = nullptr;            // [ncfg*La, n_single*6D]
+  void* svec = nullptr;             // T [ncfg*Ls, D]
+  float* smod = nullptr;            // [ncfg*Ls, n_single*6D]
   float* pred = nullptr;            // [M, C]
   float *part_a = nullptr, *part_v = nullptr;   // deferred split-K partial products [PART_CAP][M | Mv][D]
   float* x_saved = nullptr;         // [clips, C, La]
@@ -464,7 +464,7 @@ extern "C" int foley_prepare(foley_ctx* c, const foley_plan* pl, void* stream_v)
     ALLOC(c->txt_v, (size_t)f.depth_triple * ncfg * H * ((Lt + 31) & ~31) * 128 * es);
     HIPTRY(hipMemsetAsync(c->txt_v, 0, (size_t)f.depth_triple * ncfg * H * ((Lt + 31) & ~31) * 128 * es, st));
     ALLOC(c->v_cond0, (size_t)ncfg * Lv * D * 4);
-    ALLOC(c->add_sync, (size_t)ncfg * La * D * 4);
+    ALLOC(c->sync_tok, (size_t)ncfg * Ls * D * 4);
     ALLOC(c->xin, (size_t)M * C * es);
     ALLOC(c->audio, (size_t)M * D * 4);
     ALLOC(c->vcond, (size_t)Mv * D * 4);
@@ -480,8 +480,8 @@ extern "C" int foley_prepare(foley_ctx* c, const foley_plan* pl, void* stream_v)
     ALLOC(c->att_v, (size_t)Mv * D * es);
     ALLOC(c->hid_a, (size_t)M * hidmax * es);
     ALLOC(c->hid_v, (size_t)Mv * f.mlp_hidden * es);
-    ALLOC(c->svec, (size_t)ncfg * La * D * es);
-    ALLOC(c->smod, (size_t)f.depth_single * ncfg * La * 6 * D * 4);
+    ALLOC(c->svec, (size_t)ncfg * Ls * D * es);
+    ALLOC(c->smod, (size_t)f.depth_single * ncfg * Ls * 6 * D * 4);
     ALLOC(c->pred, (size_t)M * C * 4);
     ALLOC(c->part_a, (size_t)PART_CAP * M * D * 4);
     ALLOC(c->part_v, (size_t)PART_CAP * Mv * D * 4);
@@ -594,10 +594,20 @@ extern "C" int foley_prepare(foley_ctx* c, const foley_plan* pl, void* stream_v)
     TRY(launch_add_periodic(pl->sync, (const float*)pos, ncfg * Ls, f.sync_dim, 8, tA, T, st));
     TRY(launch_gemm(gemm_plain(tA, ncfg * Ls, s0, tB, D), T, EPI_SILU_T, 0, st));
     TRY(launch_gemm(gemm_plain(tB, ncfg * Ls, w13, tA, f.sync_hidden), T, EPI_SILUGATE_T, 0, st));
-    TRY(launch_gemm(gemm_plain(tA, ncfg * Ls, w2, tF, D), T, EPI_STORE_F32, 0, st));
-    TRY(launch_gather_rows(tF, pl->sync_gather, La, ncfg, Ls, D, c->add_sync, st));
+    // The up-sampling to the audio frame rate is not materialised: consumers address the Ls token rows
+    // through RowBcast mode 2 (common.h), so everything derived from the tokens alone - SiLU(token + vec)
+    // and the single-stream blocks' modulation GEMM - runs on ncfg*Ls rows instead of ncfg*La.
+    TRY(launch_gemm(gemm_plain(tA, ncfg * Ls, w2, c->sync_tok, D), T, EPI_STORE_F32, 0, st));
   }
   HIPTRY(hipStreamSynchronize(st));
+  {
+    // the plan's table must be the nearest-exact map the kernels compute in their addressing
+    std::vector<int> tab((size_t)La);
+    HIPTRY(hipMemcpy(tab.data(), pl->sync_gather, (size_t)La * 4, hipMemcpyDeviceToHost));
+    const float scale = (float)Ls / (float)La;
+    for (int l = 0; l < La; ++l)
+      if (tab[l] != rb_nearest_exact(l, scale, Ls)) return FAIL(FOLEY_ERR_INVALID, "plan.sync_gather is not the nearest-exact up-sampling table");
+  }
   if (!c->fw.ok) TRY(resolve_forward_weights(c));
   c->prepared = true;
   return 0;
@@ -608,7 +618,11 @@ static RowBcast rb_vec(const float* base, long step_stride, const int* step_ptr)
   return RowBcast{base, 0, 0, 1, 1, step_ptr, step_stride};
 }
 static RowBcast rb_tok(const float* base, long ld, int rows_per_cfg, int L) {
-  return RowBcast{base, ld, 1, rows_per_cfg, L, nullptr, 0};
+  return RowBcast{base, ld, 1, rows_per_cfg, L, nullptr, 0, 0, 0.f};
+}
+// operand with Ls rows per cfg, read by audio frame l at its nearest-exact source row (common.h RowBcast mode 2)
+static RowBcast rb_up(const float* base, long ld, int rows_per_cfg, int L, int Ls) {
+  return RowBcast{base, ld, 2, rows_per_cfg, L, nullptr, 0, Ls, (float)Ls / (float)L};
 }
 
 // Per-kernel profile (foley_profile_forward): the op's kernel launch carries two events as its own
@@ -651,7 +665,7 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
   const ForwardW& W = c->fw;
   if (!W.ok) return FAIL(FOLEY_ERR_STATE, "forward weights are not resolved (foley_prepare)");
   const int D = f.hidden, H = f.heads, C = f.latent_dim, T = f.compute_dtype;
-  const int ncfg = pl.ncfg, clips = pl.clips, La = pl.La, Lv = pl.Lv, Lt = pl.Lt, NI = pl.n_iter;
+  const int ncfg = pl.ncfg, clips = pl.clips, La = pl.La, Lv = pl.Lv, Ls = pl.Ls, Lt = pl.Lt, NI = pl.n_iter;
   const int Bc = ncfg * clips, M = Bc * La, Mv = Bc * Lv, S = La + Lv;
   const bool bf = T == FOLEY_BF16;
   const size_t es = esize(T);
@@ -664,8 +678,9 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
   auto ab = [&](double b, double sq, double skv) { return (2.0 * b * H * sq * 128.0 + 2.0 * b * H * skv * 128.0) * (double)es; };
 
   // ---- per-token conditioning of the single-stream blocks, SiLU(add_sync + vec) (hifi_foley.py:866-867),
-  // and every single block's modulation GEMM (hifi_foley.py:366).  They depend on the iteration only, and
-  // are identical for every clip of a CFG half (M = ncfg*La).  In line by default (see smod_inline()).
+  // and every single block's modulation GEMM (hifi_foley.py:366).  They depend on the iteration only, are
+  // identical for every clip of a CFG half, and - add_sync being an up-sampling of the Ls sync tokens - have
+  // only Ls distinct rows per half: M = ncfg*Ls (224 instead of 500 at 5 s).  In line by default (smod_inline()).
   {
     const bool inl = c->prof.on || smod_inline();
     hipStream_t sd = inl ? st : c->side;
@@ -673,12 +688,12 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
       HIPTRY(hipEventRecord(c->ev_fork, st));
       HIPTRY(hipStreamWaitEvent(sd, c->ev_fork, 0));
     }
-    TRY(launch_rows_add_act(c->add_sync, rb_vec(c->vec_table, D, sp), ncfg * La, D, 1, c->svec, T, sd));
+    TRY(launch_rows_add_act(c->sync_tok, rb_vec(c->vec_table, D, sp), ncfg * Ls, D, 1, c->svec, T, sd));
     if (f.depth_single > 0) {
-      // one GEMM for all blocks: [ncfg*La, D] x [n_single*6D, D]^T -> smod [ncfg*La, n_single*6D]
+      // one GEMM for all blocks: [ncfg*Ls, D] x [n_single*6D, D]^T -> smod [ncfg*Ls, n_single*6D]
       const double n = (double)f.depth_single * 6 * D;
-      TRY(prof_begin(c, st, "single.modulation (all blocks, one GEMM)", gf(ncfg * La, n, D), gb(ncfg * La, n, D, 4)));
-      TRY(launch_gemm(gemm_plain(c->svec, ncfg * La, W.smod, c->smod, (long)f.depth_single * 6 * D), T, EPI_STORE_F32, 0, sd));
+      TRY(prof_begin(c, st, "single.modulation (all blocks, one GEMM)", gf(ncfg * Ls, n, D), gb(ncfg * Ls, n, D, 4)));
+      TRY(launch_gemm(gemm_plain(c->svec, ncfg * Ls, W.smod, c->smod, (long)f.depth_single * 6 * D), T, EPI_STORE_F32, 0, sd));
       TRY(prof_end(c, st));
     }
     // the join point always exists (also with depth_single == 0): a forked capture stream must be
@@ -689,7 +704,7 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
   // audio_embedder (conv k=1 == linear over the transposed latents) + add_sync (hifi_foley.py:768, 838-839)
   {
     GemmArgs g = gemm_plain(c->xin, M, W.audio_in, c->audio, D);
-    g.rb = rb_tok(c->add_sync, D, clips * La, La);
+    g.rb = rb_up(c->sync_tok, D, clips * La, La, Ls);
     PROF("audio_embedder", gf(M, D, C), gb(M, D, C, 4), launch_gemm(g, T, EPI_STORE_F32, 0, st));
   }
   // visual stream starts from the step-invariant projection, replicated per clip (one gather launch)
@@ -794,7 +809,7 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
   for (int blk = 0; blk < f.depth_single; ++blk) {
     const SingleW& w = W.s[blk];
     const float* smod_b = c->smod + (size_t)blk * 6 * D;   // column block of the fused table
-    auto sm = [&](int chunk) { return rb_tok(smod_b + (size_t)chunk * D, 6L * D * f.depth_single, clips * La, La); };
+    auto sm = [&](int chunk) { return rb_up(smod_b + (size_t)chunk * D, 6L * D * f.depth_single, clips * La, La, Ls); };
     PROF("single.layernorm+modulate (+pending split-K sum)", 0.0, ln_bytes_s,
          launch_ln_mod_pending(c->audio, M, D, 1e-5f, sm(0), sm(1), c->xn_a, T, pend[0], st));
     pend[0] = LnPending{};
@@ -1190,7 +1205,8 @@ extern "C" int foley_dac_encode(foley_ctx* c, const float* wave, int clips, int 
 // --------------------------------------------------------------------------- op-level entry points
 static RowBcast to_rb(const foley_rowbcast* r) {
   if (!r || !r->p) return rb_none();
-  return RowBcast{r->p, (long)r->ld, r->mode, r->rows_per_cfg > 0 ? r->rows_per_cfg : 1, r->L > 0 ? r->L : 1, nullptr, 0};
+  const int L = r->L > 0 ? r->L : 1, Ls = r->mode == 2 ? (r->Ls > 0 ? r->Ls : 1) : 0;
+  return RowBcast{r->p, (long)r->ld, r->mode, r->rows_per_cfg > 0 ? r->rows_per_cfg : 1, L, nullptr, 0, Ls, Ls ? (float)Ls / (float)L : 0.f};
 }
 
 extern "C" int foley_op_gemm(const foley_gemm_desc* d, void* stream) {

@@ -124,17 +124,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[F
 struct RbCursor {   // rb_row() for rows that advance by a fixed stride, without per-row divisions
   const float* p;
   long ld;
-  int mode, rpc, L, cfg, rc, l;
+  int mode, rpc, L, cfg, rc, l, Ls;
+  float scale;
   __device__ __forceinline__ void init(const RowBcast& b, int row) {
     p = b.p;
     if (p && b.step_ptr) p += (long)(*b.step_ptr) * b.step_stride;
-    ld = b.ld; mode = p ? b.mode : 0; rpc = b.rows_per_cfg; L = b.L;
+    ld = b.ld; mode = p ? b.mode : 0; rpc = b.rows_per_cfg; L = b.L; Ls = b.Ls; scale = b.scale;
     cfg = 0; rc = 0; l = 0;
-    if (mode == 1) { cfg = row / rpc; rc = row - cfg * rpc; l = row % L; }
+    if (mode != 0) { cfg = row / rpc; rc = row - cfg * rpc; l = row % L; }
   }
-  __device__ __forceinline__ const float* row_ptr() const { return mode == 1 ? p + ((long)cfg * L + l) * ld : p; }
+  __device__ __forceinline__ const float* row_ptr() const {
+    if (mode == 1) return p + ((long)cfg * L + l) * ld;
+    if (mode == 2) return p + ((long)cfg * Ls + rb_nearest_exact(l, scale, Ls)) * ld;   // common.h RowBcast mode 2
+    return p;
+  }
   __device__ __forceinline__ void advance(int rows) {
-    if (mode != 1) return;
+    if (mode == 0) return;
     l += rows; while (l >= L) l -= L;
     rc += rows; while (rc >= rpc) { rc -= rpc; ++cfg; }
   }

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FOLEY_ABI_VERSION 5   /* 5: reference-keyed loading (foley_weights_*, foley_load_tensor, foley_bcast_weights); 4: fp8 weight storage (dtype codes 3/4, foley_gemm_desc.ldw/.wfmt); 3: foley_profile_forward; 2: foley_gemm_desc gained partials / qkv / rstride; foley_op_ln_mod_pending, foley_dac_encode */
+#define FOLEY_ABI_VERSION 6   /* 6: foley_rowbcast.Ls (mode 2: nearest-exact up-sampled operand); 5: reference-keyed loading (foley_weights_*, foley_load_tensor, foley_bcast_weights); 4: fp8 weight storage (dtype codes 3/4, foley_gemm_desc.ldw/.wfmt); 3: foley_profile_forward; 2: foley_gemm_desc gained partials / qkv / rstride; foley_op_ln_mod_pending, foley_dac_encode */
 
 enum foley_dtype {
   FOLEY_DT_F32 = 0, FOLEY_DT_BF16 = 1, FOLEY_DT_I32 = 2,
@@ -173,8 +173,11 @@ int foley_last_elapsed_ms(foley_ctx* ctx, float* ms);
 typedef struct foley_rowbcast {  /* row-broadcast operand (AdaLN shift/scale/gate, addend) */
   const float* p;       /* null => absent */
   int64_t ld;
-  int32_t mode;         /* 0: one vector for all rows; 1: rows [cfg][clip][l] use operand row [cfg][l] */
+  int32_t mode;         /* 0: one vector for all rows; 1: rows [cfg][clip][l] use operand row [cfg][l];
+                         * 2: the operand has Ls rows per cfg and token l uses row min(floor((l+0.5)*Ls/L), Ls-1),
+                         *    float32 as F.interpolate(mode="nearest-exact") computes it (hifi_foley.py:759-762) */
   int32_t rows_per_cfg, L;
+  int32_t Ls;           /* mode 2 only */
 } foley_rowbcast;
 
 /* Head split applied to a fused q/k/v (or cross-attention q) projection: per (row, head) RMSNorm

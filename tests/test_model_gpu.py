@@ -499,8 +499,9 @@ def test_profile_forward_brackets(tiny):
     assert all(e["avg_us"] > 0 for e in prof) and 0 <= bracket_us < 100
     # bracketed FLOPs == the per-forward algorithmic count minus the step-invariant (hoisted) part
     D, M, Mv, Lt, H, Hc = 256, 2 * 50, 2 * 8, 77, 2, C.TINY.conv_hidden
+    Ms = 2 * C.lengths(1.0)[2]           # the single blocks' modulation runs on the sync tokens (16 per half at 1 s), not on the audio frames
     lin = (2 * D * D * nt * 14 * (M + Mv) + ns * 2 * M * (6 * D * D + 9 * Hc * D)    # qkv, lin1(k3), w1/w3(k3), w2(k3)
-           + 2 * (M * 128 * D * 2) + 2 * M * D * ns * 6 * D)                          # audio_in + final, modulation
+           + 2 * (M * 128 * D * 2) + 2 * Ms * D * ns * 6 * D)                         # audio_in + final, modulation
     att = 4 * H * 128 * (nt * 2 * ((50 + 8) ** 2 + (50 + 8) * Lt) + ns * 2 * 50 * 50)
     total = sum(e["flop_per_launch"] * e["calls_per_forward"] for e in prof)
     assert abs(total - (lin + att)) / (lin + att) < 1e-6

@@ -418,6 +418,51 @@ def test_ln_mod(dev, out_dtype, D, eps):
     assert rel_err(out.float(), ref) < tol
 
 
+@pytest.mark.parametrize("dur", [1.0, 1.1, 2.7, 3.3, 5.0, 6.6, 13.8, 30.0])
+def test_rowbcast_nearest_exact_mode(dev, dur):
+    """RowBcast mode 2: the operand keeps the Ls sync-token rows and every audio frame l addresses row
+    nearest_exact(l) in the kernel (float32, as F.interpolate(mode='nearest-exact'), hifi_foley.py:759-762).
+    Must be bit-identical to mode 1 on the operand up-sampled on the host with tables.nearest_exact_index -
+    LayerNorm shift / scale, the pending-gate path, the GEMM addend and the gated residual; the durations
+    include the ones where a float64 index formula picks a different row."""
+    from foley_amd.host import config as Cc
+    La, _, Ls = Cc.lengths(dur)
+    idx = tables.nearest_exact_index(La, Ls).long()
+    assert torch.equal(idx, torch.nn.functional.interpolate(torch.arange(Ls, dtype=torch.float32).view(1, 1, Ls), size=La,
+                                                            mode="nearest-exact").view(-1).long())
+    clips, D = 2, 768
+    M = 2 * clips * La
+    x = (_rand((M, D), 60) * 2 + 0.3).to(dev)
+    tab = (_rand((2, Ls, 3 * D), 61) * 0.3).to(dev)                 # [cfg, Ls, 3D]: shift | scale | gate chunks
+    up = tab[:, idx.to(dev)].contiguous()                           # [cfg, La, 3D]
+    rb2 = lambda c: rt.rowbcast(tab[..., c * D:], 2, clips * La, La, ld=3 * D, Ls=Ls)
+    rb1 = lambda c: rt.rowbcast(up[..., c * D:], 1, clips * La, La, ld=3 * D)
+    for odt in (torch.float32, torch.bfloat16):
+        a, b = (torch.empty(M, D, device=dev, dtype=odt) for _ in range(2))
+        rt.op_ln_mod(x, 1e-6, rb2(0), rb2(1), a)
+        rt.op_ln_mod(x, 1e-6, rb1(0), rb1(1), b)
+        assert torch.equal(a, b)
+    # pending split-K slabs + per-token gate (single blocks), then the same LayerNorm
+    slabs = (_rand((2, M, D), 62) * 0.1).to(dev)
+    xa, xb = x.clone(), x.clone()
+    a, b = (torch.empty(M, D, device=dev, dtype=torch.bfloat16) for _ in range(2))
+    rt.op_ln_mod_pending(xa, 1e-6, rb2(0), rb2(1), a, slabs, 2, None, rb2(2))
+    rt.op_ln_mod_pending(xb, 1e-6, rb1(0), rb1(1), b, slabs, 2, None, rb1(2))
+    assert torch.equal(a, b) and torch.equal(xa, xb)
+    # GEMM epilogues: addend (audio_embedder + add_sync) and gated residual, vector and scalar epilogue paths
+    K = 128
+    A, W = (_rand((M, K), 63)).to(dev), (_rand((D, K), 64) / K ** 0.5).to(dev)
+    for dt in (torch.float32, torch.bfloat16):
+        oa, ob = (torch.empty(M, D, device=dev) for _ in range(2))
+        rt.op_gemm(A.to(dt), W.to(dt), None, out0=oa, rb=rb2(0))
+        rt.op_gemm(A.to(dt), W.to(dt), None, out0=ob, rb=rb1(0))
+        assert torch.equal(oa, ob)
+        ga, gb = x.clone(), x.clone()
+        rt.op_gemm(A.to(dt), W.to(dt), None, out0=ga, epilogue=rt.EPI_GATE_RES, rb=rb2(2), ksplit=1)
+        rt.op_gemm(A.to(dt), W.to(dt), None, out0=gb, epilogue=rt.EPI_GATE_RES, rb=rb1(2), ksplit=1)
+        assert torch.equal(ga, gb)
+
+
 def test_rowbcast_view_pointer(dev):
     """rowbcast() must pass the *view's* data pointer (chunk offset inside a wider table)."""
     t = torch.arange(24, dtype=torch.float32, device=dev).view(2, 12)
