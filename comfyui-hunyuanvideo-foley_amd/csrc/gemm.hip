@@ -672,6 +672,11 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
   }
   g.vec_out = gemm_vec_out_ok<T>(g, epi) ? 1 : 0;
   if (g1) g1s.vec_out = gemm_vec_out_ok<T>(g1s, epi) ? 1 : 0;
+  // The four-consumer tiles hold 64 / 128 accumulator registers per wave: only the LDS-transposed vector
+  // epilogue is instantiated for them (the scalar one made the compiler keep the 256x128 tile's accumulators
+  // in scratch memory - 576 bytes per lane, loads / stores inside the K loop: 0.6 -> 0.37 ms for the
+  // single-block modulation GEMM once it was gone).  Problems that need the scalar epilogue take the twins.
+  if ((tile == 25 || tile == 29) && epi != EPI_QKV_SPLIT && !(g.vec_out && (!g1 || g1s.vec_out))) tile = tile == 25 ? 15 : 19;
   if ((g.ldw != g.K || (g1 && g1s.ldw != g1s.K)) && !(tile == 15 || tile == 19 || tile == 21 || tile == 23 || tile == 25 || tile == 29))
     return foley_set_err("GEMM: padded weight rows (ldw != K) need a wave-specialised tile", __FILE__, __LINE__);
   if (tile == 11 || tile == 13) {

@@ -212,7 +212,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
     if constexpr (NW == 4) {
       f32x16 none[FM][FN];
       if constexpr (EPI == EPI_QKV_SPLIT) gemm_epilogue_qkv<T, BM, BN, WM, WN, LW>(g, none, lds, m0, n0);
-      else if (g.vec_out) gemm_epilogue_lds<T, EPI, BM, BN, WM, WN, LW>(g, none, lds, m0, n0, ks);
+      else gemm_epilogue_lds<T, EPI, BM, BN, WM, WN, LW>(g, none, lds, m0, n0, ks);   // vector epilogue only (gemm.hip launcher)
     }
     return;
   }
@@ -415,6 +415,8 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
   constexpr int XW = NW == 4 ? LW : 0;   // helper waves of the epilogue (see the loader branch)
   if constexpr (EPI == EPI_QKV_SPLIT) {
     gemm_epilogue_qkv<T, BM, BN, WM, WN, XW>(g, acc, lds, m0, n0);
+  } else if constexpr (NW == 4) {
+    gemm_epilogue_lds<T, EPI, BM, BN, WM, WN, XW>(g, acc, lds, m0, n0, ks);   // the launcher sends scalar-epilogue problems to the eight-consumer twins
   } else {
     if (g.vec_out) gemm_epilogue_lds<T, EPI, BM, BN, WM, WN, XW>(g, acc, lds, m0, n0, ks);
     else gemm_epilogue<T, EPI, FM, FN, TM, TN>(g, acc, m0, n0, wm, wn, fi, kh, ks);
