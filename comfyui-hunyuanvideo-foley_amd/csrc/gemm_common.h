@@ -181,7 +181,10 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
   float* tile = (float*)lds_raw;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, fi = lane & 31, kh = lane >> 5;
+  const bool estamp = g.dbg && (g.dbg_mode & 0xff) == 4 && tid == 0;   // tools/gemm_timeline.py --epilogue
+  if (estamp) g.dbg[(long)blockIdx.x * 4 + 0] = wall_clock64();
   __syncthreads();   // every wave is done reading the last K-slice
+  if (estamp) g.dbg[(long)blockIdx.x * 4 + 1] = wall_clock64();
   if (XW == 0 || wave < WM * WN) {
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -192,6 +195,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
           tile[(wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh) * BN + wn * TN + j * 32 + fi] = acc[i][j][e];
   }
   __syncthreads();
+  if (estamp) g.dbg[(long)blockIdx.x * 4 + 2] = wall_clock64();
 
   const int tr = tid / TPR, tc = (tid % TPR) * CP;   // row inside a pass, output column inside the tile
   int ca, cb = 0, gcol, ncheck;                      // tile columns to read, global output column
@@ -312,7 +316,10 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&ac
   float* tile = (float*)lds_raw;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, fi = lane & 31, kh = lane >> 5;
+  const bool estamp = g.dbg && (g.dbg_mode & 0xff) == 4 && tid == 0;   // tools/gemm_timeline.py --epilogue
+  if (estamp) g.dbg[(long)blockIdx.x * 4 + 0] = wall_clock64();
   __syncthreads();
+  if (estamp) g.dbg[(long)blockIdx.x * 4 + 1] = wall_clock64();
   if (XW == 0 || wave < WM * WN) {
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -323,16 +330,21 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&ac
           tile[(wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh) * BN + wn * TN + j * 32 + fi] = acc[i][j][e];
   }
   __syncthreads();
+  if (estamp) g.dbg[(long)blockIdx.x * 4 + 2] = wall_clock64();
   const int hidx = n0 >> 7;
   const int o = hidx / q.H, h = hidx - o * q.H;   // operand (q, k, v), head
   if (n0 >= g.N) return;
   const bool vtrans = q.vt_pitch > 0 && o == q.nK - 1;
+  // per-operand descriptors: all three read at constant kernel-argument offsets, then selected (an index
+  // computed at run time makes every use a separate dependent scalar load)
+  const float* const gp = o == 0 ? q.gain[0] : (o == 1 ? q.gain[1] : q.gain[2]);
+  const int* const pos = o == 0 ? q.pos[0] : (o == 1 ? q.pos[1] : q.pos[2]);
+  void* const dstp = o == 0 ? q.dst[0] : (o == 1 ? q.dst[1] : q.dst[2]);
   if (!vtrans) {
     constexpr int CP = VecStore<T>::CP, TPR = 128 / CP, RP = NT / TPR, PASSES = BM / RP;
     static_assert(NT % TPR == 0 && BM % RP == 0 && PASSES >= 1, "tile / epilogue mismatch");
     const int tr = tid / TPR, tc = (tid % TPR) * CP;
     float bias[CP], gain[CP];
-    const float* gp = q.gain[o];
 #pragma unroll
     for (int u = 0; u < CP; u += 4) {
       f32x4 bv = {0.f, 0.f, 0.f, 0.f}, gv = {1.f, 1.f, 1.f, 1.f};
@@ -341,7 +353,6 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&ac
 #pragma unroll
       for (int w = 0; w < 4; ++w) { bias[u + w] = bv[w]; gain[u + w] = gv[w]; }
     }
-    const int* pos = q.pos[o];
     // rotation angles of every pass are fetched up front (two dependent global loads each: position,
     // then table row) - left inside the pass loop they serialise behind the stores of the previous pass
     int pb[PASSES], pl[PASSES];
@@ -401,7 +412,7 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&ac
           v[2 * w + 1] = y1 * cs[p][w] + y0 * sn[p][w];
         }
       }
-      if (ok) VecStore<T>::store((T*)q.dst[o] + (((long)b * q.H + h) * q.S_tot + q.tok_off + l) * 128 + tc, v);
+      if (ok) VecStore<T>::store((T*)dstp + (((long)b * q.H + h) * q.S_tot + q.tok_off + l) * 128 + tc, v);
     }
   } else {
     // V^T: walk the clip segments of this row tile; an item = (channel d, 8 destination columns)
@@ -423,7 +434,7 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&ac
           full = full && in;
           v[u] = in ? tile[(rs - m0 + j) * BN + d] + bz : 0.f;
         }
-        T* dst = (T*)q.dst[o] + (((long)b * q.H + h) * 128 + d) * q.vt_pitch + col0;
+        T* dst = (T*)dstp + (((long)b * q.H + h) * 128 + d) * q.vt_pitch + col0;
         if constexpr (sizeof(T) == 2) {
           if (full) {
             VecStore<T>::store(dst, v);

@@ -68,11 +68,15 @@ __device__ __forceinline__ void cvt_fp8x16(const u32x4 w, bf16x8& lo, bf16x8& hi
 // WF: weight storage of the B operand - 0 bf16, 1 fp8 e4m3fn, 2 fp8 e5m2 (reference FP8WeightWrapper,
 // utils.py:316-366: storage fp8, `w.to(x.dtype)` per call, no scales).  fp8 rows are 64 bytes per K-slice:
 // the loaders move half the weight bytes (HBM -> L2 -> LDS) and the consumers widen to bf16 in registers.
-template <int BM, int BN, int WM, int WN, int NS, int LW, int EPI, int WF>
-__global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const GemmPair pr) {
+// SEL: which problem of the pair this workgroup runs - a template parameter, so that every GemmArgs field is
+// a kernel-argument load at a CONSTANT offset (hoisted and batched into a few wide s_loads at entry).  With
+// a run-time index the compiler re-loaded fields one dword at a time at their points of use: 200 scalar
+// loads, 169 of them serialised through the epilogue (tools/kernel_resources.py, gemm_timeline.py --epilogue).
+template <int BM, int BN, int WM, int WN, int NS, int LW, int EPI, int WF, int SEL>
+__device__ __forceinline__ void gemm_ws_body(const GemmPair& pr) {
   using T = bf16_t;
-  const int sel = (int)blockIdx.x >= pr.tiles0 ? 1 : 0;
-  const GemmArgs& g = pr.g[sel];
+  constexpr int sel = SEL;
+  const GemmArgs& g = pr.g[SEL];
   constexpr int NW = WM * WN;
   constexpr int BK = 64, ESZ = 2, OOB = 0x7ffffff0;
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
@@ -422,6 +426,13 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const Gemm
     else gemm_epilogue<T, EPI, FM, FN, TM, TN>(g, acc, m0, n0, wm, wn, fi, kh, ks);
   }
   tl_stamp(g, 3);
+  if (g.dbg && (g.dbg_mode & 0xff) == 4 && tid == 0) g.dbg[(long)blockIdx.x * 4 + 3] = wall_clock64();
+}
+
+template <int BM, int BN, int WM, int WN, int NS, int LW, int EPI, int WF>
+__global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const GemmPair pr) {
+  if ((int)blockIdx.x >= pr.tiles0) gemm_ws_body<BM, BN, WM, WN, NS, LW, EPI, WF, 1>(pr);   // workgroup-uniform
+  else gemm_ws_body<BM, BN, WM, WN, NS, LW, EPI, WF, 0>(pr);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -133,11 +133,14 @@ __global__ __launch_bounds__(128) void ln_mod_kernel(const LnPair pr, int D, flo
 // one-wave-per-row kernel puts 500 waves on 256 CUs, each walking a 6 KiB row (plus up to five partial
 // slabs) alone - latency bound, not bandwidth bound.  Splitting a row over WPR waves multiplies the
 // loads in flight; the two statistics cross the waves through LDS.
-template <typename OutT, int MAXV, bool PEND, int WPR>
-__global__ __launch_bounds__(128 * WPR) void ln_mod_wide_kernel(const LnPair pr, int D, float eps) {
+// SEL (which row set of the pair) is a template parameter: argument fields are then loaded at constant
+// kernel-argument offsets, in a few wide scalar loads at entry, instead of one dependent dword at a time
+// in front of the first global load of this latency-bound kernel (same reason as gemm_ws_body).
+template <typename OutT, int MAXV, bool PEND, int WPR, int SEL>
+__device__ __forceinline__ void ln_mod_wide_body(const LnPair& pr, int D, float eps) {
   __shared__ float red[2][2][WPR];   // [row of the block][statistic][wave of the row]
-  const int sel = (int)blockIdx.x >= pr.blocks0 ? 1 : 0;
-  const LnArgs& A = pr.a[sel];
+  constexpr int sel = SEL;
+  const LnArgs& A = pr.a[SEL];
   const int M = A.M;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int rb = wave / WPR, part = wave % WPR;               // row of the block (0/1), column part
@@ -228,6 +231,12 @@ __global__ __launch_bounds__(128 * WPR) void ln_mod_wide_kernel(const LnPair pr,
     for (int u = 0; u < 4; ++u) y[u] = (v[i][u] - mean) * rstd * (1.0f + cv[i][u]) + hv[i][u];
     Pack4<OutT>::store(orow + (c0 + i * 64) * 4, y);
   }
+}
+
+template <typename OutT, int MAXV, bool PEND, int WPR>
+__global__ __launch_bounds__(128 * WPR) void ln_mod_wide_kernel(const LnPair pr, int D, float eps) {
+  if ((int)blockIdx.x >= pr.blocks0) ln_mod_wide_body<OutT, MAXV, PEND, WPR, 1>(pr, D, eps);   // workgroup-uniform
+  else ln_mod_wide_body<OutT, MAXV, PEND, WPR, 0>(pr, D, eps);
 }
 
 // ------------------------------------------------------------------ q/k RMSNorm + RoPE + head split

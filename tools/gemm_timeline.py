@@ -32,6 +32,7 @@ ap.add_argument("--ablate", type=int, default=0, help="debug bits: 1 no MFMA, 2 
 ap.add_argument("--conv", action="store_true")
 ap.add_argument("--waits", action="store_true", help="wave-specialised tiles: where the first loader wave of every workgroup waits (memory vs consumers)")
 ap.add_argument("--prologue", action="store_true", help="wave-specialised tiles: ring fill of the first loader wave - issue, first slice landed, first barrier")
+ap.add_argument("--epilogue", action="store_true", help="vector epilogue (generic wave-specialised tiles): K loop done -> first barrier -> tile in LDS -> stores issued")
 ap.add_argument("--warm", action="store_true", help="measure with the weight matrix just used (L2 / Infinity-Cache warm)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -96,6 +97,17 @@ for tile in [int(v) for v in a.tile.split(",")]:
             print(f"{a.shape:5s} t{tile}k{ksplit}: wgs {len(t):4d} slices {int(t[0, 3])} | per slice (cycles): loader waits for memory p50 "
                   f"{float(per[:, 0].median()):6.0f} (max {float(per[:, 0].max()):6.0f}), at the barrier for the consumers p50 "
                   f"{float(per[:, 1].median()):6.0f} (max {float(per[:, 1].max()):6.0f}); loop p50 {float(per[:, 2].median()):6.0f} cycles/slice", flush=True)
+            continue
+        if a.epilogue:
+            dbg = torch.zeros(8192 * 4, dtype=torch.int64, device=dev)
+            lib.foley_debug_gemm_timeline(C.c_void_p(dbg.data_ptr()), 4)
+            run(Ws[3 % len(Ws)], tile, ksplit)
+            torch.cuda.synchronize()
+            lib.foley_debug_gemm_timeline(None, 0)
+            t = dbg.view(-1, 4).cpu().double()
+            t = t[t[:, 0] > 0]
+            print(f"{a.shape:5s} t{tile}k{ksplit}: wgs {len(t):4d} | epilogue of wave 0: wait for the other waves +{float((t[:, 1] - t[:, 0]).median()) / 100:5.2f}, "
+                  f"tile -> LDS +{float((t[:, 2] - t[:, 1]).median()) / 100:5.2f}, LDS -> global stores issued +{float((t[:, 3] - t[:, 2]).median()) / 100:5.2f} us", flush=True)
             continue
         if a.prologue:
             dbg = torch.zeros(8192 * 4, dtype=torch.int64, device=dev)
