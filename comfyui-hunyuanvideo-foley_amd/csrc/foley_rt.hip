@@ -152,6 +152,9 @@ struct foley_ctx {
   float *rope_cos = nullptr, *rope_sin = nullptr, *solver_coef = nullptr;
   int *pos_audio_self = nullptr, *pos_visual_self = nullptr, *pos_linear = nullptr, *sync_gather = nullptr;
   int* rep_idx = nullptr;           // [clips*Lv] j -> j % Lv: replicates the visual projection per clip in one launch
+  // rotation rows gathered per token for the fused head-split epilogues: rot_*[k][l] = rope_{cos,sin}[pos_k[l]], [len, 64] fp32
+  // (k: 0 audio self, 1 visual self, 2 linear positions)
+  float *rot_cos[3] = {nullptr, nullptr, nullptr}, *rot_sin[3] = {nullptr, nullptr, nullptr};
   void *tA = nullptr, *tB = nullptr;  // precompute scratch
   float* tF = nullptr;
   bool have_buffers = false;        // workspace allocated for `plan`'s dimensions
@@ -498,6 +501,13 @@ extern "C" int foley_prepare(foley_ctx* c, const foley_plan* pl, void* stream_v)
     ALLOC(c->sync_gather, (size_t)La * 4);
     ALLOC(c->rep_idx, (size_t)clips * Lv * 4);
     {
+      const int rl[3] = {La, Lv, Lmax};
+      for (int k = 0; k < 3; ++k) {
+        ALLOC(c->rot_cos[k], (size_t)rl[k] * 64 * 4);
+        ALLOC(c->rot_sin[k], (size_t)rl[k] * 64 * 4);
+      }
+    }
+    {
       std::vector<int> idx((size_t)clips * Lv);
       for (size_t j = 0; j < idx.size(); ++j) idx[j] = (int)(j % Lv);
       HIPTRY(hipMemcpy(c->rep_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
@@ -524,6 +534,14 @@ extern "C" int foley_prepare(foley_ctx* c, const foley_plan* pl, void* stream_v)
   COPYTAB(sync_gather, (size_t)La * 4);
 #undef COPYTAB
   pl = &c->plan;
+  {
+    const int* pt[3] = {pl->pos_audio_self, pl->pos_visual_self, pl->pos_linear};
+    const int rl[3] = {La, Lv, Lmax};
+    for (int k = 0; k < 3; ++k) {
+      TRY(launch_gather_rows(pl->rope_cos, pt[k], rl[k], 1, pl->rope_len, 64, c->rot_cos[k], st));
+      TRY(launch_gather_rows(pl->rope_sin, pt[k], rl[k], 1, pl->rope_len, 64, c->rot_sin[k], st));
+    }
+  }
   HIPTRY(hipMemsetAsync(c->step_ctr, 0, 256, st));
   void* tA = c->tA;
   void* tB = c->tB;
@@ -761,6 +779,9 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
       q.dst[0] = c->Q; q.dst[1] = c->K; q.dst[2] = c->V;
       q.out_dtype = T; q.vt_pitch = (bf && nK == 3) ? Sp : 0;
       q.S_tot = S; q.tok_off = z.tok_off; q.eps = 1e-6f; q.cos_tab = pl.rope_cos; q.sin_tab = pl.rope_sin;
+      const int k = pos == pl.pos_audio_self ? 0 : (pos == pl.pos_visual_self ? 1 : (pos == pl.pos_linear ? 2 : -1));
+      for (int i = 0; i < 2 && k >= 0; ++i)
+        if (q.pos[i]) { q.rcos[i] = c->rot_cos[k]; q.rsin[i] = c->rot_sin[k]; }
       return q;
     };
     // 1. joint self attention (hifi_foley.py:215-269)
@@ -822,6 +843,7 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
     q.out_dtype = T; q.vt_pitch = bf ? Lap : 0;
     q.S_tot = La; q.tok_off = 0; q.eps = 1.1920928955078125e-07f;  // nn.RMSNorm(eps=None) -> finfo(fp32).eps
     q.cos_tab = pl.rope_cos; q.sin_tab = pl.rope_sin;
+    q.rcos[0] = q.rcos[1] = c->rot_cos[2]; q.rsin[0] = q.rsin[1] = c->rot_sin[2];
     gq.qs = q;
     PROF("single.qkv GEMM + RMSNorm/RoPE head split", gf(M, 3 * D, D), gb(M, 3 * D, D, es), launch_gemm(gq, T, EPI_QKV_SPLIT, 0, st));
     {

@@ -614,8 +614,10 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
       uintptr_t al = (uintptr_t)s.cos_tab | (uintptr_t)s.sin_tab | (uintptr_t)q->bias;
       for (int i = 0; i < s.nK; ++i) {
         if (!s.dst[i]) return foley_set_err("fused head split: null destination", __FILE__, __LINE__);
-        al |= (uintptr_t)s.dst[i] | (uintptr_t)s.gain[i];
+        al |= (uintptr_t)s.dst[i] | (uintptr_t)s.gain[i] | (uintptr_t)s.rcos[i] | (uintptr_t)s.rsin[i];
         if (s.pos[i] && (!s.cos_tab || !s.sin_tab)) return foley_set_err("fused head split: RoPE tables missing", __FILE__, __LINE__);
+        if ((s.rcos[i] != nullptr) != (s.rsin[i] != nullptr) || (s.rcos[i] && !s.pos[i]))
+          return foley_set_err("fused head split: gathered rotation rows need both tables and a position table", __FILE__, __LINE__);
       }
       if (al & 15) return foley_set_err("fused head split: operands must be 16-byte aligned", __FILE__, __LINE__);
     }

@@ -312,12 +312,81 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&ac
                                                   unsigned char* lds_raw, int m0, int n0) {
   static_assert(BN == 128, "one head per tile");
   constexpr int NT = (WM * WN + XW) * 64, TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
+  constexpr int CP = VecStore<T>::CP, TPR = 128 / CP, RP = NT / TPR, PASSES = BM / RP;
+  static_assert(NT % TPR == 0 && BM % RP == 0 && PASSES >= 1, "tile / epilogue mismatch");
+  static_assert(TPR == 16 || TPR == 32, "head-split epilogue: 16 or 32 lanes per row");
   const QkvSplitArgs& q = g.qs;
   float* tile = (float*)lds_raw;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, fi = lane & 31, kh = lane >> 5;
   const bool estamp = g.dbg && (g.dbg_mode & 0xff) == 4 && tid == 0;   // tools/gemm_timeline.py --epilogue
   if (estamp) g.dbg[(long)blockIdx.x * 4 + 0] = wall_clock64();
+  const int hidx = n0 >> 7;
+  const int o = hidx / q.H, h = hidx - o * q.H;   // operand (q, k, v), head
+  const bool live = n0 < g.N;                     // workgroup-uniform
+  const bool vtrans = q.vt_pitch > 0 && o == q.nK - 1;
+  // per-operand descriptors: all three read at constant kernel-argument offsets, then selected (an index
+  // computed at run time makes every use a separate dependent scalar load)
+  const float* const gp = o == 0 ? q.gain[0] : (o == 1 ? q.gain[1] : q.gain[2]);
+  const int* const pos = o == 0 ? q.pos[0] : (o == 1 ? q.pos[1] : q.pos[2]);
+  const float* const rcos = o == 0 ? q.rcos[0] : (o == 1 ? q.rcos[1] : q.rcos[2]);
+  const float* const rsin = o == 0 ? q.rsin[0] : (o == 1 ? q.rsin[1] : q.rsin[2]);
+  void* const dstp = o == 0 ? q.dst[0] : (o == 1 ? q.dst[1] : q.dst[2]);
+  // ---- every global read of the q / k path is requested HERE, before the barriers and the LDS transpose:
+  // bias, gain and the rotation rows of all passes (one load level when the caller supplies rows gathered
+  // per token, QkvSplitArgs::rcos / rsin; position -> table row, two dependent levels, otherwise).
+  const int tr = tid / TPR, tc = (tid % TPR) * CP;
+  float bias[CP], gain[CP];
+  int pl[PASSES];
+  long doff[PASSES];   // destination element offset of the pass's row; < 0: row beyond M (no store)
+  float cs[PASSES][CP / 2], sn[PASSES][CP / 2];
+  const bool qk = live && !vtrans;
+  // Scalars of the row loop, read once and pinned: left to itself the compiler re-loads each of them from the
+  // kernel-argument segment in every pass (a dependent s_load + wait each, ~100 of them in this epilogue).
+  int qH = q.H, qS = q.S_tot, qoff = q.tok_off, qL = q.L, gM = g.M;
+  float qeps = q.eps;
+  asm volatile("" : "+s"(qH), "+s"(qS), "+s"(qoff), "+s"(qL), "+s"(gM), "+s"(qeps));
+  if (qk) {
+#pragma unroll
+    for (int u = 0; u < CP; u += 4) {
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f}, gv = {1.f, 1.f, 1.f, 1.f};
+      if (g.bias) bv = *(const f32x4*)(g.bias + n0 + tc + u);
+      if (gp) gv = *(const f32x4*)(gp + tc + u);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { bias[u + w] = bv[w]; gain[u + w] = gv[w]; }
+    }
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int row = m0 + p * RP + tr;
+      const int rr = row < gM ? row : gM - 1;
+      const int b = rr / qL;
+      pl[p] = rr - b * qL;
+      doff[p] = row < gM ? (((long)b * qH + h) * qS + qoff + pl[p]) * 128 + tc : -1;
+    }
+    if (pos) {
+      long pp[PASSES];
+      const float *ct = q.cos_tab, *st = q.sin_tab;
+      if (rcos) {
+        ct = rcos; st = rsin;
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) pp[p] = (long)pl[p] * 64 + (tc >> 1);
+      } else {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) pp[p] = (long)pos[pl[p]] * 64 + (tc >> 1);
+      }
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) {
+        if constexpr (CP == 8) {
+          const f32x4 c4 = *(const f32x4*)(ct + pp[p]), s4 = *(const f32x4*)(st + pp[p]);
+#pragma unroll
+          for (int w = 0; w < 4; ++w) { cs[p][w] = c4[w]; sn[p][w] = s4[w]; }
+        } else {
+          cs[p][0] = ct[pp[p]]; cs[p][1] = ct[pp[p] + 1];
+          sn[p][0] = st[pp[p]]; sn[p][1] = st[pp[p] + 1];
+        }
+      }
+    }
+  }
   __syncthreads();
   if (estamp) g.dbg[(long)blockIdx.x * 4 + 1] = wall_clock64();
   if (XW == 0 || wave < WM * WN) {
@@ -331,61 +400,11 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&ac
   }
   __syncthreads();
   if (estamp) g.dbg[(long)blockIdx.x * 4 + 2] = wall_clock64();
-  const int hidx = n0 >> 7;
-  const int o = hidx / q.H, h = hidx - o * q.H;   // operand (q, k, v), head
-  if (n0 >= g.N) return;
-  const bool vtrans = q.vt_pitch > 0 && o == q.nK - 1;
-  // per-operand descriptors: all three read at constant kernel-argument offsets, then selected (an index
-  // computed at run time makes every use a separate dependent scalar load)
-  const float* const gp = o == 0 ? q.gain[0] : (o == 1 ? q.gain[1] : q.gain[2]);
-  const int* const pos = o == 0 ? q.pos[0] : (o == 1 ? q.pos[1] : q.pos[2]);
-  void* const dstp = o == 0 ? q.dst[0] : (o == 1 ? q.dst[1] : q.dst[2]);
+  if (!live) return;
   if (!vtrans) {
-    constexpr int CP = VecStore<T>::CP, TPR = 128 / CP, RP = NT / TPR, PASSES = BM / RP;
-    static_assert(NT % TPR == 0 && BM % RP == 0 && PASSES >= 1, "tile / epilogue mismatch");
-    const int tr = tid / TPR, tc = (tid % TPR) * CP;
-    float bias[CP], gain[CP];
-#pragma unroll
-    for (int u = 0; u < CP; u += 4) {
-      f32x4 bv = {0.f, 0.f, 0.f, 0.f}, gv = {1.f, 1.f, 1.f, 1.f};
-      if (g.bias) bv = *(const f32x4*)(g.bias + n0 + tc + u);
-      if (gp) gv = *(const f32x4*)(gp + tc + u);
-#pragma unroll
-      for (int w = 0; w < 4; ++w) { bias[u + w] = bv[w]; gain[u + w] = gv[w]; }
-    }
-    // rotation angles of every pass are fetched up front (two dependent global loads each: position,
-    // then table row) - left inside the pass loop they serialise behind the stores of the previous pass
-    int pb[PASSES], pl[PASSES];
-    float cs[PASSES][CP / 2], sn[PASSES][CP / 2];
-#pragma unroll
-    for (int p = 0; p < PASSES; ++p) {
-      const int row = m0 + p * RP + tr;
-      const int rr = row < g.M ? row : g.M - 1;
-      pb[p] = rr / q.L;
-      pl[p] = rr - pb[p] * q.L;
-    }
-    if (pos) {
-      long pp[PASSES];
-#pragma unroll
-      for (int p = 0; p < PASSES; ++p) pp[p] = (long)pos[pl[p]] * 64 + (tc >> 1);
-#pragma unroll
-      for (int p = 0; p < PASSES; ++p) {
-        if constexpr (CP == 8) {
-          const f32x4 c4 = *(const f32x4*)(q.cos_tab + pp[p]), s4 = *(const f32x4*)(q.sin_tab + pp[p]);
-#pragma unroll
-          for (int w = 0; w < 4; ++w) { cs[p][w] = c4[w]; sn[p][w] = s4[w]; }
-        } else {
-          cs[p][0] = q.cos_tab[pp[p]]; cs[p][1] = q.cos_tab[pp[p] + 1];
-          sn[p][0] = q.sin_tab[pp[p]]; sn[p][1] = q.sin_tab[pp[p] + 1];
-        }
-      }
-    }
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int rl = p * RP + tr;
-      const int row = m0 + rl;
-      const bool ok = row < g.M;
-      const int b = pb[p], l = pl[p];
       float v[CP];
 #pragma unroll
       for (int u = 0; u < CP; u += 4) {
@@ -399,8 +418,7 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&ac
         for (int u = 0; u < CP; ++u) ss += v[u] * v[u];
         ss = row16_sum(ss);                                   // TPR is 16 (bf16) or 32 (fp32) lanes per row
         if constexpr (TPR == 32) ss += __shfl_xor(ss, 16);
-        static_assert(TPR == 16 || TPR == 32, "head-split epilogue: 16 or 32 lanes per row");
-        const float rinv = rsqrtf(ss * (1.0f / 128.0f) + q.eps);
+        const float rinv = rsqrtf(ss * (1.0f / 128.0f) + qeps);
 #pragma unroll
         for (int u = 0; u < CP; ++u) v[u] = v[u] * rinv * gain[u];
       }
@@ -412,7 +430,7 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&ac
           v[2 * w + 1] = y1 * cs[p][w] + y0 * sn[p][w];
         }
       }
-      if (ok) VecStore<T>::store((T*)dstp + (((long)b * q.H + h) * q.S_tot + q.tok_off + l) * 128 + tc, v);
+      if (doff[p] >= 0) VecStore<T>::store((T*)dstp + doff[p], v);
     }
   } else {
     // V^T: walk the clip segments of this row tile; an item = (channel d, 8 destination columns)

@@ -105,7 +105,8 @@ __device__ __forceinline__ void gemm_ws_body(const GemmPair& pr) {
   }
   const int tm = bid % tiles_m, tn = bid / tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: role branch, LDS piece addresses (m0) and tile offsets stay on the SALU
   tl_stamp(g, 0);
 
   int kt_begin = 0, nk = g.K / BK;
@@ -491,7 +492,8 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_conv3_kernel(cons
   }
   const int tm = bid % tiles_m, tn = bid / tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar (see gemm_ws_body)
   tl_stamp(g, 0);
   const int C = g.tapC;
   int kc_begin = 0, nkc = C / BK;   // channel chunks; K ranges of a split are chunk ranges

@@ -37,6 +37,10 @@ struct QkvSplitArgs {
   float eps;
   const float* cos_tab;  // [P, 64]
   const float* sin_tab;
+  // optional, fused GEMM epilogue only: rotation rows already gathered per token, rcos[o][l] = cos_tab[pos[o][l]]
+  // ([L, 64] fp32 each) - one load level instead of two dependent ones in front of the stores
+  const float* rcos[3];
+  const float* rsin[3];
 };
 struct GemmArgs {
   const void* A;
