@@ -79,8 +79,10 @@ struct RowBcast {
   int L;                // tokens per clip
   const int* step_ptr;  // optional device-resident iteration counter
   long step_stride;     // elements added per iteration
-  int Ls;               // mode 2: operand rows per cfg
+  int Ls;               // mode 2: rows per cfg of the up-sampled sequence
   float scale;          // mode 2: float(Ls) / float(L)
+  int per;              // mode 2: 0, or a power of two: the Ls rows repeat with this period and only the first `per`
+                        // rows per cfg are stored (empty sync features: sync_pos_emb makes 8 distinct rows per half)
 };
 
 __host__ __device__ __forceinline__ int rb_nearest_exact(int l, float scale, int Ls) {
@@ -92,7 +94,10 @@ __device__ __forceinline__ const float* rb_row(const RowBcast& b, int r) {
   const float* p = b.p;
   if (b.step_ptr) p += (long)(*b.step_ptr) * b.step_stride;
   if (b.mode == 1) p += ((long)(r / b.rows_per_cfg) * b.L + (r % b.L)) * b.ld;
-  else if (b.mode == 2) p += ((long)(r / b.rows_per_cfg) * b.Ls + rb_nearest_exact(r % b.L, b.scale, b.Ls)) * b.ld;
+  else if (b.mode == 2) {
+    const int s = rb_nearest_exact(r % b.L, b.scale, b.Ls), cfg = r / b.rows_per_cfg;
+    p += (b.per ? (long)cfg * b.per + (s & (b.per - 1)) : (long)cfg * b.Ls + s) * b.ld;
+  }
   return p;
 }
 

@@ -124,6 +124,8 @@ struct foley_ctx {
   void* txt_v = nullptr;            // [n_triple][ncfg, H, Lt, 128] or transposed [.., 128, ceil32(Lt)]
   float* v_cond0 = nullptr;         // [ncfg, Lv, D]
   float* sync_tok = nullptr;        // [ncfg, Ls, D] sync tokens after sync_in; audio frame l reads row nearest_exact(l) (RowBcast mode 2)
+  int sync_per = 0;                 // 8 when the token rows of EVERY cfg half repeat with period 8 (empty sync features), else 0
+  int* flag = nullptr;              // device scratch word of the periodicity check
   int* ident_idx = nullptr;         // 0..max(Lv,La)-1
   // forward workspace
   void* xin = nullptr;              // T [M, C]
@@ -468,6 +470,7 @@ extern "C" int foley_prepare(foley_ctx* c, const foley_plan* pl, void* stream_v)
     HIPTRY(hipMemsetAsync(c->txt_v, 0, (size_t)f.depth_triple * ncfg * H * ((Lt + 31) & ~31) * 128 * es, st));
     ALLOC(c->v_cond0, (size_t)ncfg * Lv * D * 4);
     ALLOC(c->sync_tok, (size_t)ncfg * Ls * D * 4);
+    ALLOC(c->flag, 256);
     ALLOC(c->xin, (size_t)M * C * es);
     ALLOC(c->audio, (size_t)M * D * 4);
     ALLOC(c->vcond, (size_t)Mv * D * 4);
@@ -616,8 +619,20 @@ extern "C" int foley_prepare(foley_ctx* c, const foley_plan* pl, void* stream_v)
     // through RowBcast mode 2 (common.h), so everything derived from the tokens alone - SiLU(token + vec)
     // and the single-stream blocks' modulation GEMM - runs on ncfg*Ls rows instead of ncfg*La.
     TRY(launch_gemm(gemm_plain(tA, ncfg * Ls, w2, c->sync_tok, D), T, EPI_STORE_F32, 0, st));
+    // Empty sync features (text-to-audio; the unconditional half of a CFG pair) are one learned row plus
+    // sync_pos_emb, which repeats every 8 tokens: the token rows are then 8-periodic and the per-token work of the
+    // single-stream blocks only has 8 distinct rows per half.  Detected on the data (bit patterns), not assumed.
+    HIPTRY(hipMemsetAsync(c->flag, 0, 4, st));
+    TRY(launch_rows_periodic_check(c->sync_tok, ncfg, Ls, 8, D, c->flag, st));
   }
   HIPTRY(hipStreamSynchronize(st));
+  {
+    int differs = 1;
+    HIPTRY(hipMemcpy(&differs, c->flag, 4, hipMemcpyDeviceToHost));
+    const int per = (!differs && Ls > 8) ? 8 : 0;
+    if (c->graph_exec && per != c->sync_per) ctx_drop_graph(c);   // the captured modulation GEMM has another M
+    c->sync_per = per;
+  }
   {
     // the plan's table must be the nearest-exact map the kernels compute in their addressing
     std::vector<int> tab((size_t)La);
@@ -636,11 +651,11 @@ static RowBcast rb_vec(const float* base, long step_stride, const int* step_ptr)
   return RowBcast{base, 0, 0, 1, 1, step_ptr, step_stride};
 }
 static RowBcast rb_tok(const float* base, long ld, int rows_per_cfg, int L) {
-  return RowBcast{base, ld, 1, rows_per_cfg, L, nullptr, 0, 0, 0.f};
+  return RowBcast{base, ld, 1, rows_per_cfg, L, nullptr, 0, 0, 0.f, 0};
 }
 // operand with Ls rows per cfg, read by audio frame l at its nearest-exact source row (common.h RowBcast mode 2)
-static RowBcast rb_up(const float* base, long ld, int rows_per_cfg, int L, int Ls) {
-  return RowBcast{base, ld, 2, rows_per_cfg, L, nullptr, 0, Ls, (float)Ls / (float)L};
+static RowBcast rb_up(const float* base, long ld, int rows_per_cfg, int L, int Ls, int per = 0) {
+  return RowBcast{base, ld, 2, rows_per_cfg, L, nullptr, 0, Ls, (float)Ls / (float)L, per};
 }
 
 // Per-kernel profile (foley_profile_forward): the op's kernel launch carries two events as its own
@@ -708,10 +723,14 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
     }
     TRY(launch_rows_add_act(c->sync_tok, rb_vec(c->vec_table, D, sp), ncfg * Ls, D, 1, c->svec, T, sd));
     if (f.depth_single > 0) {
-      // one GEMM for all blocks: [ncfg*Ls, D] x [n_single*6D, D]^T -> smod [ncfg*Ls, n_single*6D]
+      // one GEMM for all blocks: [ncfg*P, D] x [n_single*6D, D]^T -> smod [ncfg*P, n_single*6D], P = Ls, or 8 when
+      // the token rows are 8-periodic (virtual rows: row r of the product is token r % P of half r / P)
       const double n = (double)f.depth_single * 6 * D;
-      TRY(prof_begin(c, st, "single.modulation (all blocks, one GEMM)", gf(ncfg * Ls, n, D), gb(ncfg * Ls, n, D, 4)));
-      TRY(launch_gemm(gemm_plain(c->svec, ncfg * Ls, W.smod, c->smod, (long)f.depth_single * 6 * D), T, EPI_STORE_F32, 0, sd));
+      const int P = c->sync_per ? c->sync_per : Ls;
+      GemmArgs gm = gemm_plain(c->svec, ncfg * P, W.smod, c->smod, (long)f.depth_single * 6 * D);
+      gm.segV = P; gm.segS = Ls;
+      TRY(prof_begin(c, st, "single.modulation (all blocks, one GEMM)", gf(ncfg * P, n, D), gb(ncfg * P, n, D, 4)));
+      TRY(launch_gemm(gm, T, EPI_STORE_F32, 0, sd));
       TRY(prof_end(c, st));
     }
     // the join point always exists (also with depth_single == 0): a forked capture stream must be
@@ -830,7 +849,7 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
   for (int blk = 0; blk < f.depth_single; ++blk) {
     const SingleW& w = W.s[blk];
     const float* smod_b = c->smod + (size_t)blk * 6 * D;   // column block of the fused table
-    auto sm = [&](int chunk) { return rb_up(smod_b + (size_t)chunk * D, 6L * D * f.depth_single, clips * La, La, Ls); };
+    auto sm = [&](int chunk) { return rb_up(smod_b + (size_t)chunk * D, 6L * D * f.depth_single, clips * La, La, Ls, c->sync_per); };
     PROF("single.layernorm+modulate (+pending split-K sum)", 0.0, ln_bytes_s,
          launch_ln_mod_pending(c->audio, M, D, 1e-5f, sm(0), sm(1), c->xn_a, T, pend[0], st));
     pend[0] = LnPending{};
@@ -1228,7 +1247,8 @@ extern "C" int foley_dac_encode(foley_ctx* c, const float* wave, int clips, int 
 static RowBcast to_rb(const foley_rowbcast* r) {
   if (!r || !r->p) return rb_none();
   const int L = r->L > 0 ? r->L : 1, Ls = r->mode == 2 ? (r->Ls > 0 ? r->Ls : 1) : 0;
-  return RowBcast{r->p, (long)r->ld, r->mode, r->rows_per_cfg > 0 ? r->rows_per_cfg : 1, L, nullptr, 0, Ls, Ls ? (float)Ls / (float)L : 0.f};
+  const int per = (r->mode == 2 && r->period > 0 && !(r->period & (r->period - 1))) ? r->period : 0;
+  return RowBcast{r->p, (long)r->ld, r->mode, r->rows_per_cfg > 0 ? r->rows_per_cfg : 1, L, nullptr, 0, Ls, Ls ? (float)Ls / (float)L : 0.f, per};
 }
 
 extern "C" int foley_op_gemm(const foley_gemm_desc* d, void* stream) {

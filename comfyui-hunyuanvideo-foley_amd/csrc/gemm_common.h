@@ -124,18 +124,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[F
 struct RbCursor {   // rb_row() for rows that advance by a fixed stride, without per-row divisions
   const float* p;
   long ld;
-  int mode, rpc, L, cfg, rc, l, Ls;
+  int mode, rpc, L, cfg, rc, l, Ls, per;
   float scale;
   __device__ __forceinline__ void init(const RowBcast& b, int row) {
     p = b.p;
     if (p && b.step_ptr) p += (long)(*b.step_ptr) * b.step_stride;
-    ld = b.ld; mode = p ? b.mode : 0; rpc = b.rows_per_cfg; L = b.L; Ls = b.Ls; scale = b.scale;
+    ld = b.ld; mode = p ? b.mode : 0; rpc = b.rows_per_cfg; L = b.L; Ls = b.Ls; scale = b.scale; per = b.per;
     cfg = 0; rc = 0; l = 0;
     if (mode != 0) { cfg = row / rpc; rc = row - cfg * rpc; l = row % L; }
   }
   __device__ __forceinline__ const float* row_ptr() const {
     if (mode == 1) return p + ((long)cfg * L + l) * ld;
-    if (mode == 2) return p + ((long)cfg * Ls + rb_nearest_exact(l, scale, Ls)) * ld;   // common.h RowBcast mode 2
+    if (mode == 2) {   // common.h RowBcast mode 2
+      const int s = rb_nearest_exact(l, scale, Ls);
+      return p + (per ? (long)cfg * per + (s & (per - 1)) : (long)cfg * Ls + s) * ld;
+    }
     return p;
   }
   __device__ __forceinline__ void advance(int rows) {
@@ -307,7 +310,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
 // transposed [clip, H, 128, pitch] for the bf16 attention kernel, 8 tokens (16 bytes) per store on
 // destination-aligned groups.  Same math as qkv_split_kernel (rowops.hip), which stays for callers
 // that have the projection in memory.
-template <typename T, int BM, int BN, int WM, int WN, int XW = 0>
+template <typename T, int BM, int BN, int WM, int WN, int XW = 0, bool EARLY = true>
 __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&acc)[BM / WM / 32][BN / WN / 32],
                                                   unsigned char* lds_raw, int m0, int n0) {
   static_assert(BN == 128, "one head per tile");
@@ -341,12 +344,16 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&ac
   long doff[PASSES];   // destination element offset of the pass's row; < 0: row beyond M (no store)
   float cs[PASSES][CP / 2], sn[PASSES][CP / 2];
   const bool qk = live && !vtrans;
+  // EARLY: request these reads before the LDS transpose.  Kernels of up to 512 threads (register cap 256 per lane)
+  // do; the 768-thread tiles (cap 168) cannot hold them next to the accumulators without spilling and request
+  // them after it.
   // Scalars of the row loop, read once and pinned: left to itself the compiler re-loads each of them from the
   // kernel-argument segment in every pass (a dependent s_load + wait each, ~100 of them in this epilogue).
   int qH = q.H, qS = q.S_tot, qoff = q.tok_off, qL = q.L, gM = g.M;
   float qeps = q.eps;
   asm volatile("" : "+s"(qH), "+s"(qS), "+s"(qoff), "+s"(qL), "+s"(gM), "+s"(qeps));
-  if (qk) {
+  auto request = [&]() {
+    if (!qk) return;
 #pragma unroll
     for (int u = 0; u < CP; u += 4) {
       f32x4 bv = {0.f, 0.f, 0.f, 0.f}, gv = {1.f, 1.f, 1.f, 1.f};
@@ -386,7 +393,8 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&ac
         }
       }
     }
-  }
+  };
+  if constexpr (EARLY) request();
   __syncthreads();
   if (estamp) g.dbg[(long)blockIdx.x * 4 + 1] = wall_clock64();
   if (XW == 0 || wave < WM * WN) {
@@ -401,6 +409,7 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&ac
   __syncthreads();
   if (estamp) g.dbg[(long)blockIdx.x * 4 + 2] = wall_clock64();
   if (!live) return;
+  if constexpr (!EARLY) request();
   if (!vtrans) {
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {

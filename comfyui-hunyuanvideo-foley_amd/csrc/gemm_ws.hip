@@ -419,7 +419,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmPair& pr) {
   tl_stamp(g, 2);
   constexpr int XW = NW == 4 ? LW : 0;   // helper waves of the epilogue (see the loader branch)
   if constexpr (EPI == EPI_QKV_SPLIT) {
-    gemm_epilogue_qkv<T, BM, BN, WM, WN, XW>(g, acc, lds, m0, n0);
+    gemm_epilogue_qkv<T, BM, BN, WM, WN, XW, NW == 4>(g, acc, lds, m0, n0);
   } else if constexpr (NW == 4) {
     gemm_epilogue_lds<T, EPI, BM, BN, WM, WN, XW>(g, acc, lds, m0, n0, ks);   // the launcher sends scalar-epilogue problems to the eight-consumer twins
   } else {
@@ -492,8 +492,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_conv3_kernel(cons
   }
   const int tm = bid % tiles_m, tn = bid / tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar (see gemm_ws_body)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   tl_stamp(g, 0);
   const int C = g.tapC;
   int kc_begin = 0, nkc = C / BK;   // channel chunks; K ranges of a split are chunk ranges

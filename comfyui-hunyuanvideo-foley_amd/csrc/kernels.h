@@ -152,6 +152,8 @@ int launch_qkv_split_pair(const QkvSplitArgs& a0, const QkvSplitArgs& a1, hipStr
 // out(T)[r, :] = act(a[r, :] + v[:]) ; a optional [R, D]; v optional broadcast row (step-indexed)
 int launch_rows_add_act(const float* a, const RowBcast& v, int R, int D, int act_silu, void* out,
                         int out_dtype, hipStream_t st);
+// *flag |= 1 when, in some group of `rows` rows, a row s >= period is not bit-identical to row s - period (fp32 [groups*rows, D])
+int launch_rows_periodic_check(const float* x, int groups, int rows, int period, int D, int* flag, hipStream_t st);
 // out(T)[r, :] = x[r, :] + pos[r % period, :]
 int launch_add_periodic(const float* x, const float* pos, int R, int D, int period, void* out,
                         int out_dtype, hipStream_t st);

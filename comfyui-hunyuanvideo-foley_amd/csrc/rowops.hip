@@ -668,6 +668,26 @@ int launch_qkv_split(const QkvSplitArgs& a, hipStream_t st) {
   return launch_qkv_split_pair(a, none, st);
 }
 
+// flag |= 1 when some row s >= period of a group differs (bit pattern) from row s - period
+__global__ void rows_periodic_check_kernel(const unsigned* __restrict__ x, int groups, int rows, int period, int D, int* flag) {
+  const long per_g = (long)(rows - period) * D, n = (long)groups * per_g;
+  bool diff = false;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long g = i / per_g, r = i - g * per_g;
+    const long at = (g * rows + period) * D + r;
+    diff = diff || x[at] != x[at - (long)period * D];
+  }
+  if (diff) atomicOr(flag, 1);
+}
+
+int launch_rows_periodic_check(const float* x, int groups, int rows, int period, int D, int* flag, hipStream_t st) {
+  if (rows <= period) return 0;
+  const long n = (long)groups * (rows - period) * D;
+  FOLEY_LAUNCH(rows_periodic_check_kernel, dim3(grid1d(n, 256)), dim3(256), 0, st, (const unsigned*)x, groups, rows, period, D, flag);
+  FOLEY_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_rows_add_act(const float* a, const RowBcast& v, int R, int D, int act_silu, void* out, int out_dtype,
                         hipStream_t st) {
   const long n = (long)R * D;

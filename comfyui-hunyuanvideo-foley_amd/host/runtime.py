@@ -46,7 +46,7 @@ class FoleyPlanC(C.Structure):
 
 class RowBcastC(C.Structure):
     _fields_ = [("p", C.c_void_p), ("ld", C.c_int64), ("mode", C.c_int32), ("rows_per_cfg", C.c_int32),
-                ("L", C.c_int32), ("Ls", C.c_int32)]
+                ("L", C.c_int32), ("Ls", C.c_int32), ("period", C.c_int32)]
 
 
 class QkvSplitDescC(C.Structure):
@@ -345,10 +345,10 @@ class FoleyContext:
 
 # ----------------------------------------------------------------------------- op-level wrappers (tests, microbench)
 def rowbcast(t: Optional[torch.Tensor], mode: int = 0, rows_per_cfg: int = 1, L: int = 1,
-             ld: Optional[int] = None, Ls: int = 0) -> RowBcastC:
+             ld: Optional[int] = None, Ls: int = 0, period: int = 0) -> RowBcastC:
     """mode 2: `t` holds Ls rows per cfg; token l of a clip reads row nearest_exact(l) (tables.nearest_exact_index)."""
     r = RowBcastC()
-    r.Ls = Ls
+    r.Ls, r.period = Ls, period
     if t is not None and not t.is_cuda:
         raise FoleyRuntimeError("row-broadcast operand must live on the GPU")
     r.p = t.data_ptr() if t is not None else None     # views allowed: rows are addressed through `ld`

@@ -178,6 +178,8 @@ typedef struct foley_rowbcast {  /* row-broadcast operand (AdaLN shift/scale/gat
                          *    float32 as F.interpolate(mode="nearest-exact") computes it (hifi_foley.py:759-762) */
   int32_t rows_per_cfg, L;
   int32_t Ls;           /* mode 2 only */
+  int32_t period;       /* mode 2 only: 0, or a power of two - the up-sampled sequence repeats with this period and the
+                         * operand stores only `period` rows per cfg (row (nearest_exact(l) mod period)) */
 } foley_rowbcast;
 
 /* Head split applied to a fused q/k/v (or cross-attention q) projection: per (row, head) RMSNorm

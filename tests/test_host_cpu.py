@@ -350,3 +350,19 @@ def test_checkpoint_file_formats(tmp_path):
     a = nodes.fp8_round_state_dict(got8, nodes.resolve_quantization("auto", nodes.detect_ckpt_fp8(got8)))
     b = nodes.fp8_round_state_dict(small, "fp8_e4m3fn")
     assert all(torch.equal(a[k], b[k]) for k in keys)
+
+
+@pytest.mark.skipif(os.environ.get("FOLEY_SLOW") != "1", reason="set FOLEY_SLOW=1 to run (recompiles every kernel file, ~3 min)")
+def test_no_kernel_keeps_accumulators_in_scratch():
+    """tools/kernel_resources.py: no kernel instantiation may use more than a handful of scratch bytes per lane
+    (round 2 found a GEMM tile whose accumulators lived in scratch - 576 bytes per lane - and, later, a
+    150-register spill introduced by an unrelated one-line change)."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py")], capture_output=True, text=True,
+                         timeout=1800).stdout
+    worst = 0
+    for line in out.splitlines():
+        if " scratch " in line:
+            worst = max(worst, int(line.split(" scratch ")[1].split()[0]))
+    assert worst <= 32, out

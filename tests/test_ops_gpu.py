@@ -442,6 +442,14 @@ def test_rowbcast_nearest_exact_mode(dev, dur):
         rt.op_ln_mod(x, 1e-6, rb2(0), rb2(1), a)
         rt.op_ln_mod(x, 1e-6, rb1(0), rb1(1), b)
         assert torch.equal(a, b)
+    # periodic token rows (empty sync features repeat every 8 tokens): only 8 rows per cfg are stored
+    tab8 = tab[:, :8].contiguous()
+    up8 = tab8[:, (idx % 8).to(dev)].contiguous()
+    a, b = (torch.empty(M, D, device=dev, dtype=torch.bfloat16) for _ in range(2))
+    rt.op_ln_mod(x, 1e-6, rt.rowbcast(tab8[..., 0:], 2, clips * La, La, ld=3 * D, Ls=Ls, period=8),
+                 rt.rowbcast(tab8[..., D:], 2, clips * La, La, ld=3 * D, Ls=Ls, period=8), a)
+    rt.op_ln_mod(x, 1e-6, rt.rowbcast(up8[..., 0:], 1, clips * La, La, ld=3 * D), rt.rowbcast(up8[..., D:], 1, clips * La, La, ld=3 * D), b)
+    assert torch.equal(a, b)
     # pending split-K slabs + per-token gate (single blocks), then the same LayerNorm
     slabs = (_rand((2, M, D), 62) * 0.1).to(dev)
     xa, xb = x.clone(), x.clone()
