@@ -492,7 +492,10 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_conv3_kernel(cons
   }
   const int tm = bid % tiles_m, tn = bid / tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // scalar wave index (see gemm_ws_body) - except in the 256-row fp8 instantiations, which sit at the 168-register
+  // cap of a 768-thread kernel and answer the change with 150 spilled registers
+  const int wave = (BM == 256 && WF != 0) ? (tid >> 6) : __builtin_amdgcn_readfirstlane(tid >> 6);
   tl_stamp(g, 0);
   const int C = g.tapC;
   int kc_begin = 0, nkc = C / BK;   // channel chunks; K ranges of a split are chunk ranges
