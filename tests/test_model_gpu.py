@@ -509,6 +509,19 @@ def test_profile_forward_brackets(tiny):
     y1 = model.ctx.dit_forward(lat, 1)
     y2 = model.ctx.dit_forward(lat, 1)
     assert torch.equal(y1, y2)
+    # text-to-audio: both halves carry the empty sync feature, whose tokens repeat every 8 (sync_pos_emb) - foley_prepare
+    # finds that on the data and the modulation GEMM runs on 2 x 8 rows; the forward is still the oracle's
+    cond_t = synth.synth_conditioning(C.TINY, 1.0, t2a=True, sd=sd)
+    plan_t = sampler.build_plan(model, {"siglip2_feat": cond_t["clip"], "syncformer_feat": cond_t["sync"]},
+                                {"text_feat": cond_t["text"], "uncond_text_feat": cond_t["uncond_text"]}, 50, 4.5, 4, 1, "euler")
+    model.ctx.prepare(plan_t)
+    prof_t, _ = model.ctx.profile_forward(lat, it=1, repeats=1)
+    smod = {e["label"]: e for e in prof_t}["single.modulation (all blocks, one GEMM)"]
+    assert abs(smod["flop_per_launch"] - 2 * (2 * 8) * D * ns * 6 * D) < 1
+    model.ctx.prepare(plan)      # back to the video-conditioned plan: the full token set again
+    prof_v, _ = model.ctx.profile_forward(lat, it=1, repeats=1)
+    assert abs({e["label"]: e for e in prof_v}["single.modulation (all blocks, one GEMM)"]["flop_per_launch"] - 2 * Ms * D * ns * 6 * D) < 1
+    assert torch.equal(model.ctx.dit_forward(lat, 1), y1)
 
 
 def test_single_rank_nccl_bundle_adoption(tiny, dev):
