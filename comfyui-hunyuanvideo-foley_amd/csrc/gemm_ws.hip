@@ -765,6 +765,10 @@ int launch_gemm_ws(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hip
     if (g.wfmt == 1) return launch_ws_conv3_fmt<256, 1>(g, epi, st);
     return launch_ws_conv3_fmt<256, 2>(g, epi, st);
   }
+  if (tile == 27) {   // 64x128, four consumer waves of 32x64, 6 x 24 KiB ring: the fused head split of small problems only
+    if (g.wfmt != 0 || epi != EPI_QKV_SPLIT) return foley_set_err("wave-specialised GEMM: tile 27 is the bf16 head-split tile", __FILE__, __LINE__);
+    return launch_ws_one<64, 128, 2, 2, 6, 4, EPI_QKV_SPLIT, 0>(g, g1, st);
+  }
   if (g.wfmt == 0) {
     switch (tile) {
       case 15: return launch_ws_tile<128, 128, 4, 2, 5, 4, 0>(g, g1, epi, st);   // 5 x 32 KiB ring = all 160 KiB of LDS
