@@ -765,6 +765,10 @@ int launch_gemm_ws(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hip
     if (g.wfmt == 1) return launch_ws_conv3_fmt<256, 1>(g, epi, st);
     return launch_ws_conv3_fmt<256, 2>(g, epi, st);
   }
+  if (tile == 26) {   // 96x128, four consumer waves of 96x32, 5 x 28 KiB ring: the fused head split when 96-row tiles fill one round
+    if (g.wfmt != 0 || epi != EPI_QKV_SPLIT) return foley_set_err("wave-specialised GEMM: tile 26 is a bf16 head-split tile", __FILE__, __LINE__);
+    return launch_ws_one<96, 128, 1, 4, 5, 4, EPI_QKV_SPLIT, 0>(g, g1, st);
+  }
   if (tile == 27) {   // 64x128, four consumer waves of 32x64, 6 x 24 KiB ring: the fused head split of small problems only
     if (g.wfmt != 0 || epi != EPI_QKV_SPLIT) return foley_set_err("wave-specialised GEMM: tile 27 is the bf16 head-split tile", __FILE__, __LINE__);
     return launch_ws_one<64, 128, 2, 2, 6, 4, EPI_QKV_SPLIT, 0>(g, g1, st);
