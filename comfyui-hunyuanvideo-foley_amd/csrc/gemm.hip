@@ -622,7 +622,19 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
       if (al & 15) return foley_set_err("fused head split: operands must be 16-byte aligned", __FILE__, __LINE__);
     }
     const bool listed = tile == 1 || tile == 2 || tile == 5 || tile == 7 || tile == 8 || tile == 9 || tile == 15 || tile == 19 || tile == 25 ||
-                        tile == 26 || tile == 27 || tile == 29;
+                        tile == 26 || tile == 27 || tile == 28 || tile == 29;
+    if (tile_auto && tile == 29 && !g.wfmt) {
+      // Large grids: workgroups run in ceil(n / 256) rounds of (BM + 128) * 128 bytes per K-slice each - 192-row tiles
+      // win when they save bytes without adding a round (M = 4000 q/k/v: 3 rounds either way, 320 instead of 384 rows
+      // per workgroup and slice; FOLEY_WS192=0 keeps 256 rows)
+      static const bool ws192 = []() { const char* e = getenv("FOLEY_WS192"); return !(e && e[0] == '0'); }();
+      auto cost = [&](int bm) {
+        long n = (long)((g.M + bm - 1) / bm) * (g.N / 128);
+        if (g1) n += (long)((g1s.M + bm - 1) / bm) * (g1s.N / 128);
+        return ((n + 255) / 256) * (bm + 128);
+      };
+      if (ws192 && cost(192) < cost(256)) tile = 28;
+    }
     if (!listed || (tile_auto && tile == 25)) {
       long b128 = (long)((g.M + 127) / 128) * (g.N / 128);
       if (!listed) tile = b128 >= 24 ? (sizeof(T) == 2 ? (g.wfmt ? 15 : 25) : 5) : 2;
@@ -685,7 +697,7 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     if (g1) ok = extent(g1s) && ok;
     if (!ok && g.wfmt) return foley_set_err("GEMM: fp8-weight operands exceed the 2 GiB buffer-offset range", __FILE__, __LINE__);
     if (!ok && (tile == 21 || tile == 23)) return foley_set_err("GEMM: conv3 operands exceed the 2 GiB buffer-offset range", __FILE__, __LINE__);
-    if (!ok && ((tile >= 5 && tile <= 9) || tile == 15 || tile == 19 || tile == 25 || tile == 26 || tile == 27 || tile == 29)) tile = (tile == 6) ? 3 : ((tile == 8 || tile == 27) ? 2 : 1);   // register-staged twins
+    if (!ok && ((tile >= 5 && tile <= 9) || tile == 15 || tile == 19 || tile == 25 || tile == 26 || tile == 27 || tile == 28 || tile == 29)) tile = (tile == 6) ? 3 : ((tile == 8 || tile == 27) ? 2 : 1);   // register-staged twins
   }
   g.vec_out = gemm_vec_out_ok<T>(g, epi) ? 1 : 0;
   if (g1) g1s.vec_out = gemm_vec_out_ok<T>(g1s, epi) ? 1 : 0;
@@ -694,14 +706,14 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
   // in scratch memory - 576 bytes per lane, loads / stores inside the K loop: 0.6 -> 0.37 ms for the
   // single-block modulation GEMM once it was gone).  Problems that need the scalar epilogue take the twins.
   if ((tile == 25 || tile == 29) && epi != EPI_QKV_SPLIT && !(g.vec_out && (!g1 || g1s.vec_out))) tile = tile == 25 ? 15 : 19;
-  if ((tile == 27 || tile == 26) && (epi != EPI_QKV_SPLIT || g.wfmt)) return foley_set_err("GEMM: tile 27 (64x128) serves the fused head split with bf16 weights only", __FILE__, __LINE__);
-  if ((g.ldw != g.K || (g1 && g1s.ldw != g1s.K)) && !(tile == 15 || tile == 19 || tile == 21 || tile == 23 || tile == 25 || tile == 26 || tile == 27 || tile == 29))
+  if ((tile == 27 || tile == 26 || tile == 28) && (epi != EPI_QKV_SPLIT || g.wfmt)) return foley_set_err("GEMM: tile 27 (64x128) serves the fused head split with bf16 weights only", __FILE__, __LINE__);
+  if ((g.ldw != g.K || (g1 && g1s.ldw != g1s.K)) && !(tile == 15 || tile == 19 || tile == 21 || tile == 23 || tile == 25 || tile == 26 || tile == 27 || tile == 28 || tile == 29))
     return foley_set_err("GEMM: padded weight rows (ldw != K) need a wave-specialised tile", __FILE__, __LINE__);
   if (tile == 11 || tile == 13) {
     if (g1) return foley_set_err("conv3 kernel has no two-problem form", __FILE__, __LINE__);
     return launch_gemm_conv3(g, sizeof(T) == 2 ? FOLEY_BF16 : FOLEY_F32, epi, tile == 11 ? 1 : 3, st);
   }
-  if (tile == 15 || tile == 19 || tile == 21 || tile == 23 || tile == 25 || tile == 26 || tile == 27 || tile == 29) {
+  if (tile == 15 || tile == 19 || tile == 21 || tile == 23 || tile == 25 || tile == 26 || tile == 27 || tile == 28 || tile == 29) {
     if constexpr (sizeof(T) == 2) return launch_gemm_ws(g, g1, epi, tile, st);
     else return foley_set_err("GEMM: wave-specialised tiles are bf16 only", __FILE__, __LINE__);
   }

@@ -419,7 +419,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmPair& pr) {
   tl_stamp(g, 2);
   constexpr int XW = NW == 4 ? LW : 0;   // helper waves of the epilogue (see the loader branch)
   if constexpr (EPI == EPI_QKV_SPLIT) {
-    gemm_epilogue_qkv<T, BM, BN, WM, WN, XW, NW == 4>(g, acc, lds, m0, n0);
+    gemm_epilogue_qkv<T, BM, BN, WM, WN, XW, NW == 4 && BM <= 128>(g, acc, lds, m0, n0);
   } else if constexpr (NW == 4) {
     gemm_epilogue_lds<T, EPI, BM, BN, WM, WN, XW>(g, acc, lds, m0, n0, ks);   // the launcher sends scalar-epilogue problems to the eight-consumer twins
   } else {
@@ -768,6 +768,10 @@ int launch_gemm_ws(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hip
   if (tile == 26) {   // 96x128, four consumer waves of 96x32, 5 x 28 KiB ring: the fused head split when 96-row tiles fill one round
     if (g.wfmt != 0 || epi != EPI_QKV_SPLIT) return foley_set_err("wave-specialised GEMM: tile 26 is a bf16 head-split tile", __FILE__, __LINE__);
     return launch_ws_one<96, 128, 1, 4, 5, 4, EPI_QKV_SPLIT, 0>(g, g1, st);
+  }
+  if (tile == 28) {   // 192x128, four consumer waves of 96x64, 4 x 40 KiB ring: the fused head split of large grids
+    if (g.wfmt != 0 || epi != EPI_QKV_SPLIT) return foley_set_err("wave-specialised GEMM: tile 28 is a bf16 head-split tile", __FILE__, __LINE__);
+    return launch_ws_one<192, 128, 2, 2, 4, 4, EPI_QKV_SPLIT, 0>(g, g1, st);
   }
   if (tile == 27) {   // 64x128, four consumer waves of 32x64, 6 x 24 KiB ring: the fused head split of small problems only
     if (g.wfmt != 0 || epi != EPI_QKV_SPLIT) return foley_set_err("wave-specialised GEMM: tile 27 is the bf16 head-split tile", __FILE__, __LINE__);
