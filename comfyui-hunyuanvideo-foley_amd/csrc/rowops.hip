@@ -200,27 +200,35 @@ __device__ __forceinline__ void ln_mod_wide_body(const LnPair& pr, int D, float 
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  // Each wave reduces its own part to (sum, centred sum of squares) in registers; the parts meet once in LDS and
+  // are combined exactly (Chan et al.): M2 = sum_w [M2_w + n_w (mean_w - mean)^2] - one barrier instead of two.
   s = wave_sum(s);
-  if (lane == 0) red[rb][0][part] = s;
-  __syncthreads();
-  float tot = 0.f;
-#pragma unroll
-  for (int w = 0; w < WPR; ++w) tot += red[rb][0][w];     // fixed order: every wave of the row gets the same mean
-  const float mean = tot / (float)D;
+  const float nw = (float)(MAXV * 4 * 64);
+  const float mean_w = s / nw;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const float d = v[i][u] - mean;
+      const float d = v[i][u] - mean_w;
       q += d * d;
     }
   q = wave_sum(q);
-  if (lane == 0) red[rb][1][part] = q;
+  if (lane == 0) {
+    red[rb][0][part] = s;
+    red[rb][1][part] = q;
+  }
   __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < WPR; ++w) tot += red[rb][0][w];     // fixed order: every wave of the row gets the same mean
+  const float mean = tot / (float)D;
   float qt = 0.f;
 #pragma unroll
-  for (int w = 0; w < WPR; ++w) qt += red[rb][1][w];
+  for (int w = 0; w < WPR; ++w) {
+    const float dm = red[rb][0][w] / nw - mean;
+    qt += red[rb][1][w] + nw * dm * dm;
+  }
   const float rstd = 1.0f / sqrtf(qt / (float)D + eps);
   if (!live) return;
   OutT* orow = (OutT*)A.out + (long)row * D;
