@@ -553,7 +553,8 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
   // tap-fused wave-specialised conv3 (tile 21): bf16 operands (any weight storage), dense k=3 'same' conv
   const bool ws_conv3_ok = sizeof(T) == 2 && !g1 && g.taps == 3 && g.dil == 1 && g.tap0 == -1 && g.rstride <= 1 && g.segV == g.segS &&
                            g.osegV >= g.M && (epi == EPI_STORE_F32 || epi == EPI_GATE_RES || epi == EPI_SILUGATE_T);
-  if ((tile == 21 || tile == 23) && !ws_conv3_ok) return foley_set_err("GEMM: tiles 21 / 23 need a bf16 channels-last conv k=3", __FILE__, __LINE__);
+  if ((tile == 21 || tile == 22 || tile == 23) && !ws_conv3_ok) return foley_set_err("GEMM: tiles 21 / 22 / 23 need a bf16 channels-last conv k=3", __FILE__, __LINE__);
+  if (tile == 22 && (g.wfmt || epi == EPI_SILUGATE_T)) return foley_set_err("GEMM: tile 22 serves bf16 weights, gated-residual / fp32-store epilogues", __FILE__, __LINE__);
   const bool conv3_ok = !g.wfmt && !g1 && g.taps == 3 && g.dil == 1 && g.tap0 == -1 && g.rstride <= 1 && g.segV == g.segS && g.lda == g.tapC &&
                         g.osegV >= g.M && (epi == EPI_STORE_F32 || epi == EPI_GATE_RES || epi == EPI_SILUGATE_T);
   const bool tile_auto = tile == 0;
@@ -597,6 +598,14 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
   // chunk once for the three taps (a third fewer bytes out of the L2s: lin1 16.4 -> 12.1 us, w2 32.4 -> 23.2 us,
   // w1/w3 49.3 -> 40.0 us at M = 500; tools/gemm_timeline.py).  Large grids use its 256x128 form (tile 23).
   if (tile_auto && ws_conv3_ok && (tile == 15 || tile == 25 || tile == 11 || tile == 13 || tile == 5 || tile == 3 || tile == 2)) tile = 21;
+  {
+    // split-K convs on a one-round grid: the 256x64 form has the same workgroup count on N = 1536 and moves 12 % fewer
+    // operand bytes per workgroup (FOLEY_CONV3_TALL=0 keeps 128x128)
+    static const bool tall = []() { const char* e = getenv("FOLEY_CONV3_TALL"); return !(e && e[0] == '0'); }();
+    if (tile_auto && tile == 21 && tall && deferred && epi == EPI_GATE_RES && !g.wfmt && g.M > 256 && g.N % 128 == 0 &&
+        (long)((g.M + 255) / 256) * (g.N / 64) == (long)((g.M + 127) / 128) * (g.N / 128))
+      tile = 22;
+  }
   if (tile_auto && ws_conv3_ok && (tile == 19 || tile == 29 || tile == 9)) tile = 23;   // large grids: the 256x128 tap-fused form (w1/w3 at M = 4000: 329 -> 285 us)
   if (g.wfmt && tile != 15 && tile != 19 && tile != 21 && tile != 23) {   // fp8 weights exist only in the wave-specialised mainloops
     if (!tile_auto) return foley_set_err("GEMM: fp8 weights need tile 15, 19 or 21", __FILE__, __LINE__);
@@ -656,14 +665,14 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     g.ksplit = 1;   // fp32 (parity) mode keeps a fixed summation order
   } else if (g.ksplit == 0) {
     // fill ~3 workgroups per CU, keep >= 12 K-slices per range
-    static const int bm[30] = {0, 128, 64, 64, 128, 128, 64, 128, 64, 256, 0, 128, 0, 64, 0, 128, 0, 0, 0, 256, 0, 128, 0, 256, 0, 128, 0, 0, 0, 256};
-    static const int bn[30] = {0, 128, 128, 64, 64, 128, 64, 128, 128, 128, 0, 128, 0, 64, 0, 128, 0, 0, 0, 128, 0, 128, 0, 128, 0, 128, 0, 0, 0, 128};
+    static const int bm[30] = {0, 128, 64, 64, 128, 128, 64, 128, 64, 256, 0, 128, 0, 64, 0, 128, 0, 0, 0, 256, 0, 128, 256, 256, 0, 128, 0, 0, 0, 256};
+    static const int bn[30] = {0, 128, 128, 64, 64, 128, 64, 128, 128, 128, 0, 128, 0, 64, 0, 128, 0, 0, 0, 128, 0, 128, 64, 128, 0, 128, 0, 0, 0, 128};
     if (tile < 0 || tile >= 30 || bm[tile] == 0) return foley_set_err("GEMM: unknown tile", __FILE__, __LINE__);
     const long blocks = (long)((g.M + bm[tile] - 1) / bm[tile]) * ((g.N + bn[tile] - 1) / bn[tile]);
-    const int nk = (tile == 11 || tile == 13 || tile == 21 || tile == 23) ? 3 * (g.tapC / BK) / 3 : g.K / BK;   // conv3 splits over channel chunks
+    const int nk = (tile == 11 || tile == 13 || tile == 21 || tile == 22 || tile == 23) ? 3 * (g.tapC / BK) / 3 : g.K / BK;   // conv3 splits over channel chunks
     // small tiles want ~3 workgroups per CU; the large, efficient tiles only split when they
     // cannot even cover the chip once (the fp32 atomics are not free)
-    const long target = (tile == 1 || tile == 5 || tile == 7 || tile == 9 || tile == 11 || tile == 15 || tile == 19 || tile == 21 || tile == 23 || tile == 25 || tile == 29) ? 192 : (tile == 13 ? 512 : 768);
+    const long target = (tile == 1 || tile == 5 || tile == 7 || tile == 9 || tile == 11 || tile == 15 || tile == 19 || tile == 21 || tile == 22 || tile == 23 || tile == 25 || tile == 29) ? 192 : (tile == 13 ? 512 : 768);
     long want = (target + blocks - 1) / blocks;
     if (want > nk / 12) want = nk / 12;
     if (deferred) {   // one resident round of workgroups: as many K ranges as fit on 256 CUs (>= 4 slices each)
@@ -697,7 +706,7 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     bool ok = extent(g);
     if (g1) ok = extent(g1s) && ok;
     if (!ok && g.wfmt) return foley_set_err("GEMM: fp8-weight operands exceed the 2 GiB buffer-offset range", __FILE__, __LINE__);
-    if (!ok && (tile == 21 || tile == 23)) return foley_set_err("GEMM: conv3 operands exceed the 2 GiB buffer-offset range", __FILE__, __LINE__);
+    if (!ok && (tile == 21 || tile == 22 || tile == 23)) return foley_set_err("GEMM: conv3 operands exceed the 2 GiB buffer-offset range", __FILE__, __LINE__);
     if (!ok && ((tile >= 5 && tile <= 9) || tile == 15 || tile == 19 || tile == 25 || tile == 26 || tile == 27 || tile == 28 || tile == 29)) tile = (tile == 6) ? 3 : ((tile == 8 || tile == 27) ? 2 : 1);   // register-staged twins
   }
   g.vec_out = gemm_vec_out_ok<T>(g, epi) ? 1 : 0;
@@ -708,13 +717,13 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
   // single-block modulation GEMM once it was gone).  Problems that need the scalar epilogue take the twins.
   if ((tile == 25 || tile == 29) && epi != EPI_QKV_SPLIT && !(g.vec_out && (!g1 || g1s.vec_out))) tile = tile == 25 ? 15 : 19;
   if ((tile == 27 || tile == 26 || tile == 28) && (epi != EPI_QKV_SPLIT || g.wfmt)) return foley_set_err("GEMM: tile 27 (64x128) serves the fused head split with bf16 weights only", __FILE__, __LINE__);
-  if ((g.ldw != g.K || (g1 && g1s.ldw != g1s.K)) && !(tile == 15 || tile == 19 || tile == 21 || tile == 23 || tile == 25 || tile == 26 || tile == 27 || tile == 28 || tile == 29))
+  if ((g.ldw != g.K || (g1 && g1s.ldw != g1s.K)) && !(tile == 15 || tile == 19 || tile == 21 || tile == 22 || tile == 23 || tile == 25 || tile == 26 || tile == 27 || tile == 28 || tile == 29))
     return foley_set_err("GEMM: padded weight rows (ldw != K) need a wave-specialised tile", __FILE__, __LINE__);
   if (tile == 11 || tile == 13) {
     if (g1) return foley_set_err("conv3 kernel has no two-problem form", __FILE__, __LINE__);
     return launch_gemm_conv3(g, sizeof(T) == 2 ? FOLEY_BF16 : FOLEY_F32, epi, tile == 11 ? 1 : 3, st);
   }
-  if (tile == 15 || tile == 19 || tile == 21 || tile == 23 || tile == 25 || tile == 26 || tile == 27 || tile == 28 || tile == 29) {
+  if (tile == 15 || tile == 19 || tile == 21 || tile == 22 || tile == 23 || tile == 25 || tile == 26 || tile == 27 || tile == 28 || tile == 29) {
     if constexpr (sizeof(T) == 2) return launch_gemm_ws(g, g1, epi, tile, st);
     else return foley_set_err("GEMM: wave-specialised tiles are bf16 only", __FILE__, __LINE__);
   }

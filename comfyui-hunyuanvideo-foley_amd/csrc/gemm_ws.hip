@@ -690,6 +690,33 @@ int launch_ws_conv3_one(const GemmArgs& g, hipStream_t st) {
   return 0;
 }
 
+// 256x64 form (tile 22): same workgroup count as 128x128 on N = 1536 problems, 57 instead of 65 KiB of operands per
+// 64-channel chunk and workgroup (the activation chunk is shared by three taps, so rows are cheaper than columns)
+template <int EPI>
+int launch_ws_conv3_tall(const GemmArgs& g, hipStream_t st) {
+  constexpr int BM = 256, BN = 64, WM = 8, WN = 1, LW = 4, NSB = 6, NAB = 3;
+  constexpr size_t ai = ((BM + 2 + 7) / 8 + LW - 1) / LW;
+  constexpr size_t lds_ring = NAB * ai * LW * 1024 + (size_t)NSB * BN * 128 + 128;
+  constexpr size_t lds_epi = (size_t)BM * BN * 4;
+  constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  GemmPair pr;
+  pr.g[0] = g;
+  pr.g[1] = g;
+  pr.tiles0 = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * (EPI == EPI_GATE_RES ? g.ksplit : 1);
+  auto k = gemm_ws_conv3_kernel<BM, BN, WM, WN, NSB, NAB, LW, EPI, 0>;
+  static bool raised = false;
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);
+    raised = true;
+  }
+  FOLEY_LAUNCH(k, dim3(pr.tiles0), dim3((WM * WN + LW) * 64), lds, st, pr);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);
+  return 0;
+}
+
 template <int BM, int WF>
 int launch_ws_conv3_fmt(const GemmArgs& g, int epi, hipStream_t st) {
   switch (epi) {
@@ -754,6 +781,12 @@ int launch_ws_tile(const GemmArgs& g, const GemmArgs* g1, int epi, hipStream_t s
 int launch_gemm_ws(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hipStream_t st) {
   if (g.wfmt < 0 || g.wfmt > 2 || (g1 && g1->wfmt != g.wfmt))
     return foley_set_err("wave-specialised GEMM: bad / mixed weight formats", __FILE__, __LINE__);
+  if (tile == 22) {   // tap-fused conv k=3, 256x64 (bf16 weights; gated residual / fp32 store)
+    if (g1 || g.wfmt) return foley_set_err("wave-specialised conv3 256x64: single problem, bf16 weights", __FILE__, __LINE__);
+    if (epi == EPI_GATE_RES) return launch_ws_conv3_tall<EPI_GATE_RES>(g, st);
+    if (epi == EPI_STORE_F32) return launch_ws_conv3_tall<EPI_STORE_F32>(g, st);
+    return foley_set_err("wave-specialised conv3 256x64: unsupported epilogue", __FILE__, __LINE__);
+  }
   if (tile == 21 || tile == 23) {   // tap-fused conv k=3, 128x128 / 256x128 (the launcher has checked the conv shape)
     if (g1) return foley_set_err("wave-specialised conv3 has no two-problem form", __FILE__, __LINE__);
     if (tile == 21) {
