@@ -8,6 +8,7 @@
 //   MFMA 32x32x2 operand layout: A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31],
 //   D[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31].
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -169,6 +170,8 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
   const bf16_t* __restrict__ VT = (const bf16_t*)a.v + ((long)(bk * a.H + h) * HD) * a.vt_pitch;
   const float scale2 = 0.08838834764831845f * 1.4426950408889634f;   // log2(e) / sqrt(128)
 
+  const bool stamp = a.dbg && threadIdx.x == 0;
+  if (stamp) a.dbg[(long)blockIdx.x * 8 + 0] = wall_clock64();
   bf16x8 qf[8];
   {
     const bf16_t* p = Q + (long)min(q0 + j, a.Sq - 1) * HD + 8 * kh;
@@ -249,6 +252,10 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
       load_k(ktb, k1);
       load_v(kta, v0);
       load_v(ktb, v1);
+      if (a.dbg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (stamp) a.dbg[(long)blockIdx.x * 8 + 1] = wall_clock64();
+      }
       tile(kta, k0, v0);
       if (t1 - t0 == 2) tile(ktb, k1, v1);
     }
@@ -261,6 +268,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
     }
   }
 
+  if (stamp) a.dbg[(long)blockIdx.x * 8 + 2] = wall_clock64();
   // merge the four key ranges: wave w finalises d-fragment w
   if (kh == 0) {
     sM[w][j] = m_run;
@@ -274,6 +282,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
     for (int e = 0; e < 16; ++e) sO[w][slot][e][lane] = o[d][e];
   }
   __syncthreads();
+  if (stamp) a.dbg[(long)blockIdx.x * 8 + 3] = wall_clock64();
   float mstar = -INFINITY;
 #pragma unroll
   for (int x = 0; x < 4; ++x) mstar = fmaxf(mstar, sM[x][j]);
@@ -292,23 +301,45 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
   dst += h * HD + w * 32;
   const int slot_mine = 0;  // unused for own fragment
   (void)slot_mine;
+  // four consecutive output dims ((e & 3) of one e >> 2 group) leave as ONE 8-byte (bf16) / 16-byte (fp32) store:
+  // sixteen 2-byte stores per lane made this tail 3.6 us of a 12 us kernel (tools/attn_timeline.py)
+  // One straight-line body per wave index (the index is wave-uniform): with `x == w` tested per element the 48 LDS
+  // reads of the partner fragments sat in 48 conditional regions, each waiting for its own read - 2.7 us of latency.
+  auto finish = [&](auto wc) {
+    constexpr int W = decltype(wc)::value;
+    float part[3][16];   // the other waves' partial O of d-fragment W
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    float acc = 0.f;
+    for (int x = 0, n = 0; x < 4; ++x) {
+      if (x == W) continue;
+      const int slot = W < x ? W : W - 1;
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      float v;
-      if (x == w) {
-        // own fragment is still in registers; select it without dynamic register indexing
-        v = w == 0 ? o[0][e] : (w == 1 ? o[1][e] : (w == 2 ? o[2][e] : o[3][e]));
-      } else {
-        const int slot = w < x ? w : w - 1;
-        v = sO[x][slot][e][lane];
-      }
-      acc += wt[x] * v;
+      for (int e = 0; e < 16; ++e) part[n][e] = sO[x][slot][e][lane];
+      ++n;
     }
-    dst[(e & 3) + 8 * (e >> 2) + 4 * kh] = Cvt<OutT>::to(acc * inv);
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      f32x4 r;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = g4 * 4 + u;
+        float acc = 0.f;
+#pragma unroll
+        for (int x = 0, n = 0; x < 4; ++x) {   // same summation order as before: x = 0..3
+          if (x == W) acc += wt[x] * o[W][e];
+          else acc += wt[x] * part[n++][e];
+        }
+        r[u] = acc * inv;
+      }
+      Pack4Out<OutT>::store(dst + 8 * g4 + 4 * kh, r);
+    }
+  };
+  switch (__builtin_amdgcn_readfirstlane(w)) {
+    case 0: finish(std::integral_constant<int, 0>{}); break;
+    case 1: finish(std::integral_constant<int, 1>{}); break;
+    case 2: finish(std::integral_constant<int, 2>{}); break;
+    default: finish(std::integral_constant<int, 3>{}); break;
   }
+  if (stamp) a.dbg[(long)blockIdx.x * 8 + 4] = wall_clock64();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -442,10 +473,15 @@ __global__ __launch_bounds__(256) void attn_bf16_wide_kernel(const AttnArgs a) {
 
 }  // namespace
 
+static long long* g_attn_dbg = nullptr;
+// Debug hook for tools/attn_timeline.py (not part of include/foley_hip.h)
+extern "C" void foley_debug_attn_timeline(void* p) { g_attn_dbg = (long long*)p; }
+
 int launch_attention(const AttnArgs& a_in, int out_dtype, hipStream_t st) {
   static const int no_preload = []() { const char* e = getenv("FOLEY_ATTN_PRELOAD"); return (e && e[0] == '0') ? 1 : 0; }();
   AttnArgs a = a_in;
   a.no_preload = no_preload;
+  a.dbg = g_attn_dbg;
   if (a.Sq <= 0 || a.Skv <= 0) return foley_set_err("attention: empty sequence", __FILE__, __LINE__);
   dim3 grid((a.Sq + 31) / 32, a.H, a.Bq), block(64);
   const dim3 grid1(grid.x * grid.y * grid.z);   // bf16 kernels: 1-D grid, XCD-aware remap inside

@@ -116,6 +116,7 @@ struct AttnArgs {
   int in_dtype;
   int vt_pitch;
   int no_preload;   // set by the launcher (A/B switch FOLEY_ATTN_PRELOAD=0): small-grid kernel without the up-front operand requests
+  long long* dbg;   // tools/attn_timeline.py: 5 wall-clock stamps per workgroup of the small-grid bf16 kernel; null in production
 };
 int launch_attention(const AttnArgs& a, int out_dtype, hipStream_t st);
 
