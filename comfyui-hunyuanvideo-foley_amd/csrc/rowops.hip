@@ -34,7 +34,10 @@ template <> struct Pack4<bf16_t> {
 struct LnPair {
   LnArgs a[2];
   int blocks0;
+  long long* dbg;   // tools/ln_timeline.py: 4 wall-clock stamps per workgroup of the wide kernel; null in production
 };
+static long long* g_ln_dbg = nullptr;
+extern "C" void foley_debug_ln_timeline(void* p) { g_ln_dbg = (long long*)p; }
 
 template <typename OutT, int MAXV, bool PEND>
 __global__ __launch_bounds__(128) void ln_mod_kernel(const LnPair pr, int D, float eps) {
@@ -148,6 +151,8 @@ __device__ __forceinline__ void ln_mod_wide_body(const LnPair& pr, int D, float 
   const bool live = row_u < M;
   const int row = live ? row_u : M - 1;                       // dead waves shadow the last row (no stores)
   const int c0 = part * (MAXV * 64) + lane;                   // first float4 of this lane; stride 64
+  const bool stamp = pr.dbg && threadIdx.x == 0;
+  if (stamp) pr.dbg[(long)blockIdx.x * 4 + 0] = wall_clock64();
   f32x4* xr = (f32x4*)(A.x + (long)row * D);
   const f32x4* sh = A.shift.p ? (const f32x4*)rb_row(A.shift, row) : nullptr;
   const f32x4* sc = A.scale.p ? (const f32x4*)rb_row(A.scale, row) : nullptr;
@@ -197,6 +202,10 @@ __device__ __forceinline__ void ln_mod_wide_body(const LnPair& pr, int D, float 
       if (live) xr[c0 + i * 64] = v[i];
     }
   }
+  if (pr.dbg) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (stamp) pr.dbg[(long)blockIdx.x * 4 + 1] = wall_clock64();
+  }
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
@@ -230,6 +239,7 @@ __device__ __forceinline__ void ln_mod_wide_body(const LnPair& pr, int D, float 
     qt += red[rb][1][w] + nw * dm * dm;
   }
   const float rstd = 1.0f / sqrtf(qt / (float)D + eps);
+  if (stamp) pr.dbg[(long)blockIdx.x * 4 + 2] = wall_clock64();
   if (!live) return;
   OutT* orow = (OutT*)A.out + (long)row * D;
 #pragma unroll
@@ -239,6 +249,7 @@ __device__ __forceinline__ void ln_mod_wide_body(const LnPair& pr, int D, float 
     for (int u = 0; u < 4; ++u) y[u] = (v[i][u] - mean) * rstd * (1.0f + cv[i][u]) + hv[i][u];
     Pack4<OutT>::store(orow + (c0 + i * 64) * 4, y);
   }
+  if (stamp) pr.dbg[(long)blockIdx.x * 4 + 3] = wall_clock64();
 }
 
 template <typename OutT, int MAXV, bool PEND, int WPR>
@@ -574,6 +585,7 @@ int launch_ln_mod_pair(const LnArgs& a0, const LnArgs& a1, int D, float eps, int
   pr.a[0] = a0;
   pr.a[1] = a1;
   pr.blocks0 = (a0.M + 1) / 2;
+  pr.dbg = g_ln_dbg;
   dim3 grid(pr.blocks0 + (a1.M + 1) / 2), block(128);
   const int need = (D / 4 + 63) / 64;   // float4 per lane
   if (out_dtype != FOLEY_F32 && out_dtype != FOLEY_BF16) return foley_set_err("ln_mod: bad dtype", __FILE__, __LINE__);
