@@ -395,6 +395,9 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&ac
     }
   };
   if constexpr (EARLY) request();
+  // transposed-V tiles: the thread's channel bias, requested before the barriers too (it used to be a global load
+  // inside the item loop, in front of every item's LDS reads)
+  const float vbias = (live && vtrans && g.bias) ? g.bias[n0 + (tid & 127)] : 0.f;
   __syncthreads();
   if (estamp) g.dbg[(long)blockIdx.x * 4 + 1] = wall_clock64();
   if (XW == 0 || wave < WM * WN) {
@@ -443,6 +446,9 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&ac
     }
   } else {
     // V^T: walk the clip segments of this row tile; an item = (channel d, 8 destination columns)
+    static_assert(NT % 128 == 0, "every thread keeps one channel");
+    const int d = tid & 127;
+    const float bz = vbias;
     const int row_end = min(m0 + BM, g.M);
     const int b_first = m0 / q.L, b_last = (row_end - 1) / q.L;
     for (int b = b_first; b <= b_last; ++b) {
@@ -450,8 +456,7 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&ac
       const int count = re - rs, c0 = q.tok_off + (rs - b * q.L);
       const int G0 = c0 >> 3, ngroups = ((c0 + count - 1) >> 3) - G0 + 1;
       for (int it = tid; it < 128 * ngroups; it += NT) {
-        const int d = it & 127, col0 = (G0 + (it >> 7)) * 8, j0 = col0 - c0;
-        const float bz = g.bias ? g.bias[n0 + d] : 0.f;
+        const int col0 = (G0 + (it >> 7)) * 8, j0 = col0 - c0;   // d = it & 127 = tid & 127: NT is a multiple of 128
         float v[8];
         bool full = true;
 #pragma unroll
