@@ -186,20 +186,6 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
   const int wm = wave / WN, wn = wave % WN, fi = lane & 31, kh = lane >> 5;
   const bool estamp = g.dbg && (g.dbg_mode & 0xff) == 4 && tid == 0;   // tools/gemm_timeline.py --epilogue
   if (estamp) g.dbg[(long)blockIdx.x * 4 + 0] = wall_clock64();
-  __syncthreads();   // every wave is done reading the last K-slice
-  if (estamp) g.dbg[(long)blockIdx.x * 4 + 1] = wall_clock64();
-  if (XW == 0 || wave < WM * WN) {
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-          tile[(wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh) * BN + wn * TN + j * 32 + fi] = acc[i][j][e];
-  }
-  __syncthreads();
-  if (estamp) g.dbg[(long)blockIdx.x * 4 + 2] = wall_clock64();
-
   const int tr = tid / TPR, tc = (tid % TPR) * CP;   // row inside a pass, output column inside the tile
   int ca, cb = 0, gcol, ncheck;                      // tile columns to read, global output column
   if constexpr (EPI == EPI_SILUGATE_T) {
@@ -213,10 +199,12 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
     ncheck = gcol;
   }
   const bool col_ok = ncheck < g.N;
+  // the bias is requested before the barriers and the LDS transpose (a dependent global load after them otherwise)
   float bias_a[CP], bias_b[CP];
 #pragma unroll
   for (int u = 0; u < CP; ++u) bias_a[u] = bias_b[u] = 0.f;
-  if (g.bias && col_ok) {
+  const bool bias_used = !(EPI == EPI_GATE_RES && g.ksplit > 1);   // deferred split-K leaves the bias to the LayerNorm
+  if (g.bias && col_ok && bias_used) {
 #pragma unroll
     for (int u = 0; u < CP; u += 4) {
       const f32x4 v = *(const f32x4*)(g.bias + n0 + ca + u);
@@ -227,6 +215,19 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
       }
     }
   }
+  __syncthreads();   // every wave is done reading the last K-slice
+  if (estamp) g.dbg[(long)blockIdx.x * 4 + 1] = wall_clock64();
+  if (XW == 0 || wave < WM * WN) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          tile[(wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh) * BN + wn * TN + j * 32 + fi] = acc[i][j][e];
+  }
+  __syncthreads();
+  if (estamp) g.dbg[(long)blockIdx.x * 4 + 2] = wall_clock64();
   OutT* out = (OutT*)g.out0 + g.out_shift + gcol;
   const int row0 = m0 + tr;
 
