@@ -165,13 +165,23 @@ def build_plan(model: FoleyModel, visual_feats: Dict[str, torch.Tensor], text_fe
     else:
         ncfg, text_in, clip_in, sync_in = 1, text, clip, sync
     fp8_time = fp8_time_dtype(model)
-    tb = tables.build_tables(La, Lv, Ls, Lt, steps, sampler, cfg.flow_shift, cfg.time_freq_dim, fp8_time=fp8_time)
+    # The run's tables (schedule, solver coefficients, RoPE rows, position / up-sampling maps) depend on these scalars
+    # only: built once per distinct run shape and kept on the device (host-side table building is milliseconds of
+    # Python per call - more than the whole precompute on the GPU)
+    key = (La, Lv, Ls, Lt, steps, sampler, float(cfg.flow_shift), cfg.time_freq_dim, str(fp8_time), str(dev))
+    cache = model.__dict__.setdefault("_tables_cache", {})
+    tabs = cache.get(key)
+    if tabs is None:
+        tb = tables.build_tables(La, Lv, Ls, Lt, steps, sampler, cfg.flow_shift, cfg.time_freq_dim, fp8_time=fp8_time)
+        tabs = {k: tb[k].to(dev).contiguous() for k in ("t_feat", "rope_cos", "rope_sin", "pos_audio_self", "pos_visual_self",
+                                                        "pos_linear", "sync_gather", "solver_coef")}
+        if len(cache) >= 16:
+            cache.pop(next(iter(cache)))
+        cache[key] = tabs
     plan = {"ncfg": ncfg, "clips": batch_size, "La": La, "Lv": Lv, "Ls": Ls, "Lt": Lt, "n_iter": steps,
-            "guidance": float(guidance_scale), "rope_len": tb["rope_cos"].shape[0],
+            "guidance": float(guidance_scale), "rope_len": tabs["rope_cos"].shape[0],
             "text": text_in.contiguous(), "clip": clip_in.contiguous(), "sync": sync_in.contiguous()}
-    for k in ("t_feat", "rope_cos", "rope_sin", "pos_audio_self", "pos_visual_self", "pos_linear", "sync_gather",
-              "solver_coef"):
-        plan[k] = tb[k].to(dev).contiguous()
+    plan.update(tabs)
     return plan
 
 
