@@ -39,8 +39,8 @@ template <> struct Pack4Out<float> {
 template <> struct Pack4Out<bf16_t> {
   static __device__ __forceinline__ void store(bf16_t* p, const f32x4 v) {
     uint2 w;
-    w.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-    w.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    w.x = pack_bf16x2(v[0], v[1]);
+    w.y = pack_bf16x2(v[2], v[3]);
     *(uint2*)p = w;
   }
 };

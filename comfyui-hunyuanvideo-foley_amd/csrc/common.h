@@ -22,6 +22,14 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   return (bf16_t)(u >> 16);
 }
 
+// two floats -> packed bf16 pair with ONE v_cvt_pk_bf16_f32 (gfx950; round-to-nearest-even as f32_to_bf16 / torch, which
+// cost six VALU instructions per element in software - every bf16 store of every epilogue and row kernel)
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  const bf16x2_t p = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, p);
+}
+
 template <typename T> struct Cvt;
 template <> struct Cvt<float> {
   static __device__ __forceinline__ float to(float v) { return v; }

@@ -161,7 +161,7 @@ template <> struct VecStore<bf16_t> {
   static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
     u32x4 w;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) w[u] = (uint32_t)f32_to_bf16(v[2 * u]) | ((uint32_t)f32_to_bf16(v[2 * u + 1]) << 16);
+    for (int u = 0; u < 4; ++u) w[u] = pack_bf16x2(v[2 * u], v[2 * u + 1]);
     *(u32x4*)p = w;
   }
 };
