@@ -292,10 +292,13 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
         if constexpr (EPI == EPI_SILUGATE_T) {
           const f32x4 b = *(const f32x4*)(src + cb + u);
 #pragma unroll
-          for (int w = 0; w < 4; ++w) v[u + w] = silu_f(a[w] + bias_a[u + w]) * (b[w] + bias_b[u + w]);
+          for (int w = 0; w < 4; ++w) v[u + w] = silu_o<OutT>(a[w] + bias_a[u + w]) * (b[w] + bias_b[u + w]);
         } else {
 #pragma unroll
-          for (int w = 0; w < 4; ++w) v[u + w] = act_epi(a[w] + bias_a[u + w], EPI);
+          for (int w = 0; w < 4; ++w) {
+            const float t = a[w] + bias_a[u + w];
+            v[u + w] = EPI == EPI_SILU_T ? silu_o<OutT>(t) : (EPI == EPI_GELU_T ? gelu_o<OutT>(t) : t);
+          }
         }
       }
       VecStore<OutT>::store(out + (long)row * g.out_row, v);
