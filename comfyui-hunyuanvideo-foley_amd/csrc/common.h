@@ -78,11 +78,13 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// Sum over the 64 lanes, result in every lane: the four row sums meet through two DPP row broadcasts (lane 15 of a
+// row into the next row, lane 31 into the upper half) and one v_readlane - no ds_bpermute round trips through the LDS.
 __device__ __forceinline__ float wave_sum(float v) {
   v = row16_sum(v);
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // Row-broadcast operand addressing shared by the row kernels and GEMM epilogues.
