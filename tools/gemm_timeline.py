@@ -30,6 +30,7 @@ ap.add_argument("--brief", action="store_true")
 ap.add_argument("--fused-qkv", action="store_true", help="fused head-split epilogue (shape qkv: 3 x 12 heads, clips of 250 tokens)")
 ap.add_argument("--ablate", type=int, default=0, help="debug bits: 1 no MFMA, 2 no fragment reads, 4 no global->LDS loads (glds kernels)")
 ap.add_argument("--conv", action="store_true")
+ap.add_argument("--act", default="", choices=["", "gelu", "silu", "silugate"], help="bf16-output epilogue (bias + activation) instead of the fp32 store")
 ap.add_argument("--waits", action="store_true", help="wave-specialised tiles: where the first loader wave of every workgroup waits (memory vs consumers)")
 ap.add_argument("--prologue", action="store_true", help="wave-specialised tiles: ring fill of the first loader wave - issue, first slice landed, first barrier")
 ap.add_argument("--epilogue", action="store_true", help="vector epilogue (generic wave-specialised tiles): K loop done -> first barrier -> tile in LDS -> stores issued")
@@ -48,6 +49,8 @@ gate = torch.randn(N, device=dev)
 
 
 slabs = torch.empty(16, a.m, N, device=dev) if a.partials else None
+bias_act = torch.randn(N, device=dev) * 0.1
+out_act = torch.empty(a.m, N // 2 if a.act == "silugate" else N, device=dev, dtype=torch.bfloat16)
 
 
 qkv_desc = None
@@ -70,6 +73,9 @@ def run(W, tile, ksplit):
     elif ksplit:
         rt.op_gemm(A, W, None, out0=x, tile=tile, epilogue=rt.EPI_GATE_RES, rb=rt.rowbcast(gate, 0), ksplit=ksplit,
                    partials=slabs, **ckw)
+    elif a.act:
+        epi = {"gelu": rt.EPI_GELU_T, "silu": rt.EPI_SILU_T, "silugate": rt.EPI_SILUGATE_T}[a.act]
+        rt.op_gemm(A, W, bias_act, out0=out_act, tile=tile, epilogue=epi, **ckw)
     else:
         rt.op_gemm(A, W, None, out0=x, tile=tile, **ckw)
 
