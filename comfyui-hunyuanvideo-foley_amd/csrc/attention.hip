@@ -399,11 +399,14 @@ __global__ __launch_bounds__(256) void attn_bf16_wide_kernel(const AttnArgs a) {
   };
   const int nt = (a.Skv + 31) >> 5;
   const int pi = 16 * ((j >> 2) & 1) + (j & 3) + 4 * (j >> 3);  // A-row j carries key kt + pi
+  const bool acct = a.dbg && tid == 0;   // tools/attn_timeline.py --wide: cycles in the math and in the staging + barrier
+  long long c_math = 0, c_stage = 0, c_t0 = acct ? (long long)__builtin_readcyclecounter() : 0;
   gload(0);
   lstore(0);
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
     const int kt = t * 32;
+    const long long ca = acct ? (long long)__builtin_readcyclecounter() : 0;
     if (t + 1 < nt) gload(t + 1);                 // next tile's global loads fly during this tile's math
     const unsigned char* Ks = lds + (t & 1) * STG;
     const unsigned char* Vs = Ks + 32 * KP;
@@ -415,19 +418,22 @@ __global__ __launch_bounds__(256) void attn_bf16_wide_kernel(const AttnArgs a) {
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Ks + pi * KP + (16 * st + 8 * kh) * 2), qf[st], s, 0, 0, 0);
     // s[e] = score(key kt + 16*kh + e, query q0 + j), kept in the log2 domain (scale2 = log2(e)/sqrt(128)):
     // the exponentials are single v_exp_f32 instructions
+    // raw scores: the scale (log2(e)/sqrt(128) > 0) commutes with the maximum and is folded into the exponent's FMA;
+    // only a tile that sticks out of the sequence masks its elements (wave-uniform test)
     float mx = -INFINITY;
+    if (kt + 32 > a.Skv) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      s[e] = (kt + 16 * kh + e < a.Skv) ? s[e] * scale2 : -INFINITY;
-      mx = fmaxf(mx, s[e]);
+      for (int e = 0; e < 16; ++e) s[e] = (kt + 16 * kh + e < a.Skv) ? s[e] : -INFINITY;
     }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[e]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
+    const float m_new = fmaxf(m_run, mx * scale2);
     float ps = 0.f;
     bf16x8 pb[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const float pv = __builtin_amdgcn_exp2f(s[e] - m_new);
+      const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], scale2, -m_new));
       ps += pv;
       pb[e >> 3][e & 7] = (__bf16)pv;
     }
@@ -448,10 +454,22 @@ __global__ __launch_bounds__(256) void attn_bf16_wide_kernel(const AttnArgs a) {
 #pragma unroll
       for (int d = 0; d < 4; ++d)
         o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Vs + (d * 32 + j) * VP + (16 * kh + 8 * u) * 2), pb[u], o[d], 0, 0, 0);
+    const long long cb = acct ? (long long)__builtin_readcyclecounter() : 0;
     if (t + 1 < nt) {
       lstore((t + 1) & 1);        // stage (t+1)&1 was last read in iteration t-1: every wave passed the barrier below since
       __syncthreads();
     }
+    if (acct) {
+      const long long cc = (long long)__builtin_readcyclecounter();
+      c_math += cb - ca;
+      c_stage += cc - cb;
+    }
+  }
+  if (acct) {
+    a.dbg[(long)blockIdx.x * 8 + 0] = (long long)__builtin_readcyclecounter() - c_t0;
+    a.dbg[(long)blockIdx.x * 8 + 1] = c_math;
+    a.dbg[(long)blockIdx.x * 8 + 2] = c_stage;
+    a.dbg[(long)blockIdx.x * 8 + 3] = nt;
   }
 
   const int tok = q0 + j;

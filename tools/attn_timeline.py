@@ -39,6 +39,18 @@ for q, k, v in sets[:3]:
     rt.op_attention(q, k, v, out, out, 0)
 torch.cuda.synchronize()
 rows = []
+if (a.sq + 127) // 128 * a.h * a.b >= 256:    # the launcher takes the large-grid kernel: cycle accounting instead of stamps
+    dbg = torch.zeros(8192 * 8, dtype=torch.int64, device=dev)
+    lib.foley_debug_attn_timeline(C.c_void_p(dbg.data_ptr()))
+    q, k, v = sets[3]
+    rt.op_attention(q, k, v, out, out, 0)
+    torch.cuda.synchronize()
+    lib.foley_debug_attn_timeline(None)
+    t = dbg.view(-1, 8).cpu().double()
+    t = t[t[:, 3] > 0]
+    print(f"wide kernel: wgs {len(t)} key tiles {int(t[0, 3])} | per tile (cycles, wave 0): math {float((t[:, 1] / t[:, 3]).median()):6.0f}, "
+          f"staging + barrier {float((t[:, 2] / t[:, 3]).median()):6.0f}; whole loop {float(t[:, 0].median()):8.0f} cycles")
+    sys.exit(0)
 for rep in range(3):
     junk.fill_(rep)                      # push the operands out of the L2s
     dbg = torch.zeros(4096 * 8, dtype=torch.int64, device=dev)
