@@ -1,6 +1,6 @@
 """Headline benchmark: audio-seconds generated per wall-second for the Foley sampling path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5] [--bs B] [--precision bf16|fp32]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5] [--bs B] [--precision bf16|fp32] [--progress]
 
 A "step" is ONE pass of the whole hot path over one batch of synthetic input, host to host: H2D of
 the CPU-generator noise, step-invariant precompute, the 50-iteration Euler/CFG loop over the xxl
@@ -10,7 +10,12 @@ conditioning are resident in HBM when the timed region starts.
 Configurations (BASELINE.json `configs`):
   c2 (default)  T2A 5 s, 50 Euler steps, CFG 4.5, bf16, hunyuanvideo-foley-xxl        - the headline metric
   c3            V2A: same shapes, non-empty SigLIP2 / Synchformer stand-in features (seed 2)
+  c4            V2A features, bs = 8 clips per GPU: with --gpus 8 this is BASELINE configs[3] (bs=64 over 8 GPUs)
   c5            fp8_e4m3fn weight storage, 30 s clip, negative-prompt CFG
+
+The default line (c2, bs=1/GPU at every N, so that the driver's per-N values are one scaling curve) also carries, as
+`extra`: bs8 (the bs=8/GPU half of the metric), c4 (V2A features, bs=8/GPU - at N=8 the C4 workload), progress (the
+per-iteration host callback path ComfyUI's progress bar takes) and, at N=1, c3 and c5 - two timed passes each.
 
 Multi-GPU: `python bench.py --gpus N` SPAWNS its own N ranks (one process per GPU, RCCL) when it
 is not already running under a launcher; under `torch.distributed.run` (RANK / WORLD_SIZE set) it
@@ -48,6 +53,9 @@ CONFIGS = {
                desc="T2A 5 s, 50 Euler steps, CFG 4.5"),
     "c3": dict(duration=5.0, t2a=False, quantization="none",
                desc="V2A 5 s @ 8 fps (SigLIP2 + Synchformer stand-in features), 50 Euler steps, CFG 4.5"),
+    "c4": dict(duration=5.0, t2a=False, quantization="none", bs=8,
+               desc="V2A 5 s (SigLIP2 + Synchformer stand-in features), 50 Euler steps, CFG 4.5, data-parallel clips, one RCCL "
+                    "broadcast of weights + conditioning (BASELINE configs[3] at --gpus 8: bs=64)"),
     "c5": dict(duration=30.0, t2a=True, quantization="fp8_e4m3fn",
                desc="fp8_e4m3fn weight storage, 30 s long-form, negative-prompt CFG 4.5, 50 Euler steps"),
 }
@@ -165,6 +173,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the per-kernel profile pass and the bs=8 measurement")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--progress", action="store_true",
+                    help="time the path a ComfyUI run takes: a host progress callback after every loop iteration "
+                         "(graph replay + D2D copy + stream synchronise per iteration, foley_rt.hip foley_sample)")
     ap.add_argument("--dry-run", action="store_true",
                     help="setup only (pack, the single broadcast, sharding) on CPU tensors - no HIP work; used by the gloo tests")
     return ap.parse_args(argv)
@@ -234,7 +245,7 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
     bcast_s = D.broadcast_bundle(bundle) if use_dist else 0.0
     cond = {k: v.clone() for k, v in bundle.cond_views().items()}
     la = int(duration * cfg.frame_rate)
-    bs_main = a.bs or 1
+    bs_main = a.bs or conf.get("bs", 1)
     gen = torch.Generator("cpu").manual_seed(1234)
     noise_all = sampler.draw_noise(world * bs_main, cfg.latent_dim, la, dtype, gen)     # same on every rank
     lo, hi = D.shard_range(world * bs_main, rank, world)
@@ -276,14 +287,18 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
 
     pieces = {}
 
-    def measure(bs: int, noise_cpu: torch.Tensor, steps: int, warmup: int):
+    def measure(bs: int, noise_cpu: torch.Tensor, steps: int, warmup: int, visual=visual, text=text, model=model,
+                duration=duration, progress=a.progress):
         """Host-to-host passes: pinned CPU noise in, CPU waveform out."""
         noise_cpu = noise_cpu.pin_memory()
+        la = noise_cpu.shape[2]
+        ticks = []
+        cb = (lambda i, n: ticks.append(i)) if progress else None
 
         def one_pass():
             audio, _sr = sampler.denoise_process_with_generator(
                 visual, text, duration, model, dac, GUIDANCE, STEPS_PER_CLIP, bs, "euler",
-                noise=noise_cpu.to(dev, non_blocking=True), use_graph=graph)
+                noise=noise_cpu.to(dev, non_blocking=True), use_graph=graph, progress=cb)
             return audio.cpu()
 
         for _ in range(warmup):
@@ -317,6 +332,7 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         assert audio.shape == (bs, 1, la * dac_cfg.hop) and bool(torch.isfinite(audio).all())
+        assert not progress or len(ticks) == (steps + warmup) * STEPS_PER_CLIP
         return dt, loop_ms, dac_ms
 
     dt, loop_ms, dac_ms = measure(bs_main, noise_all[lo:hi], a.steps, a.warmup)
@@ -342,27 +358,51 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
 
     # ---- the bs=8-per-GPU half of the BASELINE metric, same JSON line
     extra = {}
-    if not a.no_extra and a.bs is None and a.config == "c2":
-        gen8 = torch.Generator("cpu").manual_seed(1234)
-        n8 = sampler.draw_noise(world * 8, cfg.latent_dim, la, dtype, gen8)
-        lo8, hi8 = D.shard_range(world * 8, rank, world)
-        dt8, loop8, dac8 = measure(8, n8[lo8:hi8], 2, 1)
-        extra["bs8"] = {"value": world * 8 * 2 * duration / dt8, "unit": "audio-sec/sec", "clips_per_gpu": 8, "steps": 2,
-                        "warmup": 1, "ms_per_step": 1e3 * dt8 / 2, "loop_ms": loop8, "dac_decode_ms": dac8,
-                        "loop_frac": 8 * f_loop / (loop8 * 1e-3) / 1e12 / peak}
+    if not a.no_extra and a.bs is None and a.config == "c2" and not a.progress:
+        def extra_line(bs, dur, workload, **kw):
+            """2 timed passes (1 warm-up) of another configuration of the same path; clips sharded like the main line."""
+            la_x = int(dur * cfg.frame_rate)
+            gx = torch.Generator("cpu").manual_seed(1234)
+            nx = sampler.draw_noise(world * bs, cfg.latent_dim, la_x, dtype, gx)
+            lox, hix = D.shard_range(world * bs, rank, world)
+            dtx, loopx, dacx = measure(bs, nx[lox:hix], 2, 1, duration=dur, **kw)
+            fl = flops_clip(cfg, dur, STEPS_PER_CLIP, GUIDANCE) - 2.30933e9 * la_x
+            return {"value": world * bs * 2 * dur / dtx, "unit": "audio-sec/sec", "workload": workload, "clips_per_gpu": bs,
+                    "steps": 2, "warmup": 1, "ms_per_step": 1e3 * dtx / 2, "loop_ms": loopx, "dac_decode_ms": dacx,
+                    "loop_frac": bs * fl / (loopx * 1e-3) / 1e12 / peak}
+
+        extra["bs8"] = extra_line(8, duration, "c2 at bs=8 per GPU (the bs=8 half of the BASELINE metric)")
+        # stand-in V2A features: a pure function of the seed, synthesised on every rank like the noise
+        c3c = synth.synth_conditioning(cfg, duration, t2a=False, device=dev, seed=1)
+        vis3 = {"siglip2_feat": c3c["clip"], "syncformer_feat": c3c["sync"]}
+        extra["c4"] = extra_line(8, duration, f"c4: {CONFIGS['c4']['desc']}; {world} GPU(s) x 8 clips", visual=vis3)
+        extra["progress"] = extra_line(1, duration, "c2 bs=1 with a host progress callback after every loop iteration "
+                                       "(the path a ComfyUI run takes)", progress=True)
+        if world == 1:
+            extra["c3"] = extra_line(1, duration, f"c3: {CONFIGS['c3']['desc']}", visual=vis3)
+            from foley_amd import nodes
+            m5 = nodes.HunyuanModelLoader.pack_state_dict(sd, "bf16", "fp8_e4m3fn", device=dev, cfg=cfg, dac_cfg=dac_cfg)
+            c5c = synth.synth_conditioning(cfg, CONFIGS["c5"]["duration"], t2a=True, sd=sd, device=dev, seed=1)
+            extra["c5"] = extra_line(1, CONFIGS["c5"]["duration"], f"c5: {CONFIGS['c5']['desc']}", model=m5,
+                                     visual={"siglip2_feat": c5c["clip"], "syncformer_feat": c5c["sync"]})
+            del m5
 
     if rank == 0:
         clips = world * bs_main * a.steps
         loop_tf = bs_main * f_loop / (loop_ms * 1e-3) / 1e12
         traffic, traffic_src = None, None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        import glob
+        for tf_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):   # newest round first
+            try:
+                tj = json.load(open(tf_path))
+            except Exception:
+                continue
+            # only a counter pass taken on exactly these kernel sources and this workload is reported
             if tj.get("kernel_src_sha") == kernel_src_sha() and tj.get("workload") == f"{a.config}/bs{bs_main}/{a.precision}/{a.model}":
                 traffic = tj["hbm_bytes_per_loop_iteration"]
-                traffic_src = {"file": "profiles/r02_pmc_traffic.json", "kernel_src_sha": tj["kernel_src_sha"],
+                traffic_src = {"file": os.path.relpath(tf_path, ROOT), "kernel_src_sha": tj["kernel_src_sha"],
                                "unit": "bytes per loop iteration (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes on these kernel sources)"}
-        except Exception:
-            pass
+                break
         dom = next((k for k in kernels if k["gflop_per_launch"] > 0), None)   # largest time per iteration among the MFMA kernels
         roof = {"bound": "mfma", "peak": peak, "unit": "TFLOP/s",
                 "achieved": dom["tflops"] if dom else loop_tf, "frac": dom["frac"] if dom else loop_tf / peak,
@@ -381,6 +421,7 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
                                    f"{a.precision} GEMM operands / fp32 accumulate, weight storage {quant}, "
                                    f"DAC-VAE fp32 decode to 48 kHz, host-to-host (H2D noise + D2H waveform timed)",
                        "clips_per_gpu": bs_main, "parallelism": f"dp{world}", "hip_graph": graph,
+                       "progress_callback": bool(a.progress),
                        "collectives": 1 if use_dist else 0, "broadcast_s": bcast_s, "bundle_bytes": spec.total},
             "roofline": roof,
         }

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
 #pragma unroll
       for (int d = 0; d < 4; ++d) vf[u][d] = *(const bf16x8*)(VT + (long)(d * 32 + j) * a.vt_pitch + kt + 16 * kh + 8 * u);
   };
-  if (t1 - t0 <= 2) {
+  if (!a.no_preload && t1 - t0 <= 2) {
     // The small grids this kernel serves (S <= ~300: one or two key tiles per wave) are a chain of
     // dependent memory latencies - K tile, then V tile, per key tile.  Every operand of the wave's
     // (at most two) tiles is requested up front, before the first MFMA: one round trip instead of four.

@@ -17,8 +17,8 @@
 
 thread_local FoleyProfHook g_foley_prof = {nullptr, nullptr};
 
-// Contexts are independent, but two of them may be driven from two threads of one process (node-level data
-// parallelism, host/sampler.py::denoise_process_multi).  The set-up phases - workspace allocation and the
+// Contexts are independent, but several of them may be driven from several threads of one process (node-level data
+// parallelism: host/sampler.py::denoise_process_multi runs one context per visible GPU, one thread each).  The set-up phases - workspace allocation and the
 // stream capture of the iteration graph - are serialised process-wide (allocation calls from one thread
 // while another thread captures are not safe in every HIP runtime); the long replay loops run concurrently.
 static std::mutex g_setup_mutex;
@@ -941,6 +941,7 @@ extern "C" int foley_profile_forward(foley_ctx* c, const float* latents, int ite
   int rc = 0;
   for (int r = 0; r < repeats && rc == 0; ++r) rc = run_forward(c, st);
   c->prof.on = false;
+  g_foley_prof = FoleyProfHook{nullptr, nullptr};   // an op that failed between prof_begin and its launch leaves the hook armed
   if (rc) return rc;
   // empty brackets for the calibration
   constexpr int NCAL = 32;
@@ -1172,11 +1173,14 @@ extern "C" int foley_dac_encode(foley_ctx* c, const float* wave, int clips, int 
     }
   }
   const int Tz = (int)(T / hop);
-  HIPTRY(hipStreamSynchronize(st));
-  TRY(grow(c->dacP, maxel * clips * 4));
-  TRY(grow(c->dacQ, maxel * clips * 4));
-  TRY(grow(c->dacR, maxel * clips * 4));
-  TRY(grow(c->dacZ, (size_t)clips * Tz * L * 4 * 3));
+  {
+    std::lock_guard<std::mutex> setup_lock(g_setup_mutex);
+    HIPTRY(hipStreamSynchronize(st));
+    TRY(grow(c->dacP, maxel * clips * 4));
+    TRY(grow(c->dacQ, maxel * clips * 4));
+    TRY(grow(c->dacR, maxel * clips * 4));
+    TRY(grow(c->dacZ, (size_t)clips * Tz * L * 4 * 3));
+  }
   float *S_in = (float*)c->dacP.p, *X = (float*)c->dacQ.p, *S_alt = (float*)c->dacR.p;
   float* Z0 = (float*)c->dacZ.p;
   float* Z1 = Z0 + (size_t)clips * Tz * L;

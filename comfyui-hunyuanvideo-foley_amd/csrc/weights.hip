@@ -20,6 +20,7 @@
 
 #include <cstring>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -188,6 +189,7 @@ struct Slot {
   std::vector<int64_t> shape;
   size_t off = 0, bytes = 0;
   long parts_needed = 1, parts_done = 0;
+  std::set<long> parts_seen;   // destination offsets already packed: a repeated key overwrites its part, it does not count twice
 };
 struct Pending {   // one half of a weight-norm pair waiting for the other
   void* buf = nullptr;
@@ -349,7 +351,7 @@ int launch_pack(WStore& w, const std::string& slot, const Src& src, std::initial
   FOLEY_LAUNCH(pack_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, st, d);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return W_FAIL(FOLEY_ERR_HIP, hipGetErrorString(e));
-  s.parts_done += 1;
+  if (s.parts_seen.insert(out_off).second) s.parts_done += 1;   // parts of a slot are told apart by where they land
   return 0;
 }
 

@@ -150,7 +150,11 @@ def synchformer_segments(sd: SD, x: Tensor, prefix: str = "vfeat_extractor.") ->
     w = sd[p + "patch_embed_3d.proj.weight"]                       # [D, 3, 2, 16, 16]
     D, _c, zt, ph, pw = w.shape
     x = x.permute(0, 2, 1, 3, 4)                                    # [N, 3, T, H, W]
-    x = F.conv3d(x.to(w.dtype), w, sd[p + "patch_embed_3d.proj.bias"], stride=(zt, ph, pw))
+    # under autocast (the GPU path) the fp32 frames go to the conv as they are - ONE cast to fp16 by autocast, like the
+    # reference (feature_utils.py:99-104); casting to a bf16 parameter dtype first would drop three mantissa bits
+    if not (x.is_cuda and torch.is_autocast_enabled()):
+        x = x.to(w.dtype)
+    x = F.conv3d(x, w, sd[p + "patch_embed_3d.proj.bias"], stride=(zt, ph, pw))
     frames, space = x.shape[2], x.shape[3] * x.shape[4]             # 8, 196
     x = x.flatten(2).transpose(1, 2)                                # [N, frames*space, D], token order (t, h, w)
     pos, temp = sd[p + "pos_embed"], sd[p + "temp_embed"]           # [1, 1+space, D], [1, frames, D]

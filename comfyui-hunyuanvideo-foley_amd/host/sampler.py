@@ -7,7 +7,8 @@ tables; every FLOP of the hot path runs in the HIP library.
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, Optional
+import threading
+from typing import Callable, Dict, List, Optional, Sequence
 
 import torch
 import torch.nn.functional as F
@@ -206,4 +207,90 @@ def denoise_process_with_generator(visual_feats, text_feats, audio_len_in_s, mod
     sr = dac.sample_rate if dac is not None else model.dac_cfg.sample_rate
     if return_latents:
         return audio, sr, latents
+    return audio, sr
+
+
+# ----------------------------------------------------------------------------- node-level data parallelism
+def replicate(model: FoleyModel, dac: Optional[FoleyDAC], devices: Sequence) -> List:
+    """One (FoleyModel, FoleyDAC) pair per device of `devices` for clip-level data parallelism inside ONE
+    process (the ComfyUI case: a single prompt-worker process that sees all GPUs of the node).  The pair of the
+    device the model already lives on is reused; every other device receives ONE device-to-device copy of the
+    packed DiT arena and one of the DAC arena (peer copies over xGMI) - the in-process counterpart of the
+    single broadcast of host/distributed.py.  Replicas are cached on the model."""
+    if model.arena is None:
+        raise FoleyRuntimeError("replicate() needs a model packed by the host packers (an arena it can copy)")
+    cache = model.__dict__.setdefault("_replicas", {})
+    out = []
+    for d in devices:
+        d = torch.device(d)
+        if d.type != "cuda":
+            raise FoleyRuntimeError("replicas live on HIP devices")
+        if d.index is None:
+            d = torch.device("cuda", torch.cuda.current_device())
+        if d == model.device and not any(m is model for m, _ in out):
+            out.append((model, dac))
+            continue
+        key = (str(d), sum(1 for m, _ in out if m.device == d))        # the same device twice = two contexts on it
+        if key not in cache:
+            arena = packers.Arena(model.arena.buffer.numel(), model.arena.table, d,
+                                  buffer=model.arena.buffer.to(d, copy=True))
+            m = FoleyModel.from_arena(model.cfg, arena, model.dtype, d, dac_cfg=model.dac_cfg,
+                                      quantization=model.quantization)
+            dd = None
+            if dac is not None:
+                da = packers.Arena(dac.arena.buffer.numel(), dac.arena.table, d, buffer=dac.arena.buffer.to(d, copy=True))
+                dd = FoleyDAC.from_arena(da, d, dac.cfg)
+            cache[key] = (m, dd)
+        out.append(cache[key])
+    return out
+
+
+def denoise_process_multi(visual_feats, text_feats, audio_len_in_s, replicas: Sequence, guidance_scale: float,
+                          num_inference_steps: int, batch_size: int, sampler: str,
+                          generator: Optional[torch.Generator] = None, use_graph: bool = True,
+                          progress: Optional[Callable[[int, int], None]] = None, return_latents: bool = False):
+    """`denoise_process_with_generator` with the clips of the batch sharded over `replicas` (the pairs
+    `replicate()` returns), one host thread per GPU.  Clips are independent (reference utils.py:159-199: the
+    batch only repeats the conditioning), so there is no collective: the noise of the WHOLE batch is drawn once
+    from `generator` exactly like the single-GPU call does and sliced (`distributed.shard_range`), which makes the
+    result bit-identical to one GPU running the full batch whenever the shards use the same tile shapes - and
+    equal to bf16 / fp32 accuracy otherwise.  Returns (audio [bs, 1, T] fp32 on the first replica's device, sr)."""
+    from .distributed import shard_range
+    if not replicas:
+        raise FoleyRuntimeError("no replicas")
+    m0 = replicas[0][0]
+    cfg = m0.cfg
+    La = int(audio_len_in_s * cfg.frame_rate)
+    noise = draw_noise(batch_size, cfg.latent_dim, La, m0.dtype, generator)
+    shards = [shard_range(batch_size, r, len(replicas)) for r in range(len(replicas))]
+    results: List = [None] * len(replicas)
+    errors: List = []
+
+    def work(r):
+        lo, hi = shards[r]
+        if hi <= lo:
+            return
+        model, dac = replicas[r]
+        try:
+            with torch.cuda.device(model.device), torch.cuda.stream(torch.cuda.Stream(model.device)):
+                results[r] = denoise_process_with_generator(
+                    visual_feats, text_feats, audio_len_in_s, model, dac, guidance_scale, num_inference_steps, hi - lo,
+                    sampler, use_graph=use_graph, noise=noise[lo:hi], return_latents=True,
+                    progress=progress if r == 0 else None)
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:          # surfaced on the calling thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(r,), name=f"foley-dp-{r}") for r in range(len(replicas))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    done = [x for x in results if x is not None]
+    audio = torch.cat([x[0].to(m0.device) for x in done])
+    sr = done[0][1]
+    if return_latents:
+        return audio, sr, torch.cat([x[2].to(m0.device) for x in done])
     return audio, sr

@@ -347,10 +347,19 @@ class HunyuanFoleySampler:
             pbar = comfy.utils.ProgressBar(steps)
         except Exception:
             pass
-        audio, sr = _sampler.denoise_process_with_generator(
-            visual, text, audio_len_in_s, model, deps["dac_model"], guidance_scale=cfg_scale,
-            num_inference_steps=steps, batch_size=batch_size, sampler=sampler, generator=rng,
-            progress=(lambda i, n: pbar.update_absolute(i, n)) if pbar is not None else None)
+        progress = (lambda i, n: pbar.update_absolute(i, n)) if pbar is not None else None
+        n_dev = torch.cuda.device_count() if os.environ.get("FOLEY_DATA_PARALLEL", "0") == "1" else 1
+        if batch_size > 1 and n_dev > 1 and model.arena is not None:
+            # clips are independent: shard them over the node's GPUs (host/sampler.py::denoise_process_multi; the widget
+            # list is the reference's, so the switch is an environment variable - INTEGRATION.md)
+            devs = [model.device] + [torch.device("cuda", i) for i in range(n_dev) if i != model.device.index]
+            reps = _sampler.replicate(model, deps["dac_model"], devs[:batch_size])
+            audio, sr = _sampler.denoise_process_multi(visual, text, audio_len_in_s, reps, cfg_scale, steps, batch_size,
+                                                       sampler, generator=rng, progress=progress)
+        else:
+            audio, sr = _sampler.denoise_process_with_generator(
+                visual, text, audio_len_in_s, model, deps["dac_model"], guidance_scale=cfg_scale,
+                num_inference_steps=steps, batch_size=batch_size, sampler=sampler, generator=rng, progress=progress)
         waveform_batch = audio.float().cpu()
         first = {"waveform": waveform_batch[0].unsqueeze(0), "sample_rate": sr}
         return (first, {"waveform": waveform_batch, "sample_rate": sr})

@@ -294,6 +294,89 @@ def test_full_size_properties(dev):
     assert max(errs) < 5e-2
 
 
+def test_full_size_properties_v2a(dev):
+    """BASELINE config C3 at full size: xxl, 5 s, CFG 4.5 with NON-empty SigLIP2 / Synchformer features
+    (reference utils.py:159-199: the unconditional half carries the learned empty rows, hifi_foley.py:755-762
+    up-samples the 112 sync tokens).  Unlike C2 the conditional half keeps all Ls = 112 distinct sync rows
+    while the unconditional half is 8-periodic, so the plan must NOT take the periodic shortcut: the
+    single-block modulation GEMM runs on M = 2*112 rows and the per-token operands are addressed through
+    RowBcast mode 2 with per = 0.  Checked
+    (0) against the oracle: one xxl-width (depth 1+1) forward of the [uncond ; cond] x 2-clip batch, fp32, 2e-5,
+        and the bf16 mode of the same forward;
+    (1)-(4) at full depth through the properties of test_full_size_properties (the oracle needs minutes per
+        forward there): batch independence, graph replay == eager, bf16 vs fp32, and that the dense features
+        are really in use (differs from the text-only run on the same noise)."""
+    cfg = C.XXL
+    La, Lv, Ls = C.lengths(5.0, cfg)
+    assert (La, Lv, Ls) == (250, 40, 112)
+    # ---- (0) oracle comparison at full width, depth 1+1
+    c11 = C.DiTConfig(name="xxl-1-1", depth_triple=1, depth_single=1)
+    sd11 = synth.synth_dit_state_dict(c11)
+    cond11 = synth.synth_conditioning(c11, 5.0, t2a=False, sd=sd11)
+    vis11 = {"siglip2_feat": cond11["clip"], "syncformer_feat": cond11["sync"]}
+    txt11 = {"text_feat": cond11["text"], "uncond_text_feat": cond11["uncond_text"]}
+    x = torch.randn(2, 128, La, generator=torch.Generator().manual_seed(31))
+    it, steps = 3, 10
+    t_it = tables.model_timesteps(tables.sigma_grid(steps))[it]
+    text77 = O.pad_or_trim_text(cond11["text"])
+    unc77 = O.pad_or_trim_text(cond11["uncond_text"])
+    e_clip = sd11["empty_clip_feat"].view(1, 1, -1).expand(1, Lv, -1)
+    e_sync = sd11["empty_sync_feat"].view(1, 1, -1).expand(1, Ls, -1)
+    with torch.inference_mode():       # rows ordered [cfg][clip]: uncond x 2 clips, then cond x 2 clips
+        ref = O.dit_forward(sd11, c11.heads, torch.cat([x, x]), t_it.expand(4),
+                            torch.cat([unc77, unc77, text77, text77]),
+                            torch.cat([e_clip, e_clip, cond11["clip"], cond11["clip"]]),
+                            torch.cat([e_sync, e_sync, cond11["sync"], cond11["sync"]]))
+    ref_rows = ref.transpose(1, 2).reshape(4 * La, 128)
+    for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 4e-2)):
+        m = sampler.FoleyModel(c11, sd11, dtype, dev)
+        m.ctx.prepare(sampler.build_plan(m, vis11, txt11, La, 4.5, steps, 2, "euler"))
+        xin = x.to(dtype).float() if dtype != torch.float32 else x
+        rows = m.ctx.dit_forward(xin.to(dev).contiguous(), it)
+        e = rel_err(rows, ref_rows)
+        print("xxl-1-1 V2A forward, CFG pair x 2 clips, %s: %.2e" % (dtype, e))
+        assert e < tol
+        del m
+    # ---- (1)-(4) full depth
+    sd = synth.synth_dit_state_dict(cfg, device=dev)
+    cond = synth.synth_conditioning(cfg, 5.0, t2a=False, sd=sd, device=dev)
+    assert cond["clip"].shape[1] == Lv and cond["sync"].shape[1] == Ls
+    visual = {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]}
+    text = {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]}
+    model = sampler.FoleyModel(cfg, sd, torch.bfloat16, dev)
+    steps = 3
+    n1 = torch.randn(1, 128, La, generator=torch.Generator().manual_seed(11))
+    n2 = torch.randn(1, 128, La, generator=torch.Generator().manual_seed(12))
+
+    def run(noise, graph, m=model, vis=visual):
+        plan = sampler.build_plan(m, vis, text, La, 4.5, steps, noise.shape[0], "euler")
+        m.ctx.prepare(plan)
+        lat = noise.clone().to(dev).contiguous()
+        m.ctx.sample(lat, use_graph=graph)
+        return lat.cpu()
+
+    b3 = run(torch.cat([n1, n2, n1]), True)
+    assert torch.isfinite(b3).all()
+    assert torch.equal(b3[0], b3[2]) and not torch.equal(b3[0], b3[1])          # (1) clips are independent
+    s1 = run(n1, True)
+    assert rel_err(s1[0], b3[0]) < 5e-2
+    assert torch.equal(run(n1, False), s1)                                       # (2) graph replay == eager
+    ct = synth.synth_conditioning(cfg, 5.0, t2a=True, sd=sd, device=dev)
+    t2a = run(n1, True, vis={"siglip2_feat": ct["clip"], "syncformer_feat": ct["sync"]})
+    assert rel_err(t2a, s1) > 1e-3                                               # (4) the features matter
+    assert torch.equal(run(n1, True), s1)                                        # ... and the switch back leaves no stale periodic plan
+    model32 = sampler.FoleyModel(cfg, sd, torch.float32, dev)
+    f32 = run(n1, False, model32)
+    print("C3 full size: bf16 single-vs-batch %.2e, bf16-vs-fp32 %.2e" % (rel_err(s1[0], b3[0]), rel_err(s1, f32)))
+    assert rel_err(s1, f32) < 5e-2                                               # (3) bf16 vs fp32 after 3 steps
+    # the bs=8 shapes of C4 (what each GPU of the 8-GPU job runs): rows against their single-clip runs
+    n8 = torch.randn(8, 128, La, generator=torch.Generator().manual_seed(13))
+    b8 = run(n8, True)
+    errs = [rel_err(b8[i], run(n8[i:i + 1], True)[0]) for i in (0, 5)]
+    print("C4 per-GPU batch (bs=8) rows vs single-clip runs:", ["%.2e" % e for e in errs])
+    assert max(errs) < 5e-2
+
+
 def test_c5_full_size_properties(dev):
     """BASELINE config C5 as a whole: xxl + fp8_e4m3fn weight storage + 30 s (La=1500, Lv=240, Ls=736)
     + negative-prompt CFG 4.5, through the loader's own entry point.  The oracle needs ~10 min per
@@ -580,6 +663,52 @@ def test_bench_single_rank_forced_dist(dev):
     assert out["roofline"]["kernels"] and out["roofline"]["frac"] > 0
 
 
+def test_denoise_process_multi_shards_the_batch(tiny, dev):
+    """Node-level data parallelism inside one process (host/sampler.py::replicate / denoise_process_multi): the
+    clips of a batch are sharded over replicas, one host thread and one context each, with no collective.  On a
+    1-GPU box the two replicas are two contexts on the same device (the threading, the per-thread stream capture
+    and the process-wide set-up lock are what is exercised); with two GPUs the second replica lives on cuda:1
+    after ONE peer copy of the arena.  The sharded run must equal the single-context run of the full batch."""
+    sd, dsd, model, dac = tiny
+    cond = synth.synth_conditioning(C.TINY, 1.0, t2a=False)
+    vis = {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]}
+    txt = {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]}
+    full, sr, lat_full = sampler.denoise_process_with_generator(
+        vis, txt, 1.0, model, dac, 4.5, 10, 3, "euler", generator=torch.Generator("cpu").manual_seed(7), return_latents=True)
+    second = torch.device("cuda:1") if torch.cuda.device_count() >= 2 else dev
+    reps = sampler.replicate(model, dac, [dev, second])
+    assert reps[0][0] is model and reps[1][0] is not model and reps[1][0].device == second
+    assert sampler.replicate(model, dac, [dev, second])[1][0] is reps[1][0]          # cached
+    ticks = []
+    multi, sr2, lat_multi = sampler.denoise_process_multi(
+        vis, txt, 1.0, reps, 4.5, 10, 3, "euler", generator=torch.Generator("cpu").manual_seed(7), return_latents=True,
+        progress=lambda i, n: ticks.append(i))
+    assert sr2 == sr and multi.shape == full.shape and ticks == list(range(1, 11))
+    assert rel_err(lat_multi, lat_full) < 1e-5 and rel_err(multi, full) < 1e-5
+    # a shard count above the batch size leaves the surplus replicas idle
+    one, _sr = sampler.denoise_process_multi(vis, txt, 1.0, reps, 4.5, 10, 1, "euler",
+                                             generator=torch.Generator("cpu").manual_seed(7))
+    assert rel_err(one, full[:1]) < 1e-5
+
+
+def test_bench_two_ranks_over_rccl(dev):
+    """The N > 1 path on real hardware, when the box has it: `bench.py --gpus 2` spawns its own two ranks (one per
+    GPU), rank 0 packs into the bundle, ONE ncclBroadcast over xGMI ships it, every rank samples its own clips.
+    Skips on a 1-GPU box (the driver's 8-GPU scaling run is then the only hardware evidence)."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "c4", "--model", "tiny",
+                        "--duration", "1", "--bs", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extra"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["config"]["collectives"] == 1 and out["config"]["clips_per_gpu"] == 2
+    assert out["config"]["workload"].startswith("c4") and out["value"] > 0 and out["config"]["broadcast_s"] > 0
+
+
 def test_v2a_node_with_image_input(dev):
     """The reference's example workflow wires a VHS IMAGE batch into the sampler (link 114): the node
     must EXECUTE with an IMAGE input - frame resampling, SigLIP2 / Synchformer / CLAP on the GPU, then the
@@ -629,7 +758,8 @@ def test_bf16_mode_against_reference_bf16(dev):
     running the reference on the build container's CPU).  bf16 arithmetic is not reproducible bit for bit
     across devices, so the gates are stated against the reference's own bf16-vs-fp32 distance d0 on the
     same inputs (stored in the fixture): the HIP bf16 mode must be as close to the reference's bf16 output
-    as bf16 rounding allows (<= 2.5 d0) and no further from the fp32 truth than the reference's own bf16
+    as bf16 rounding allows (<= 1.5 d0; measured 0.94 - 1.02 d0: two correct
+    bf16 executions of one computation differ by about d0) and no further from the fp32 truth than the reference's own bf16
     run is (<= 1.5 d0).  Tolerances: forward d0 = 7.0e-3; 10-step CFG latents d0 = 9.1e-3, waveform
     d0 = 4.0e-2; C5 (fp8-wrapped, 30 s shapes) gate 2.5e-2 against the fp8-wrapped reference."""
     from foley_amd import nodes
@@ -645,7 +775,7 @@ def test_bf16_mode_against_reference_bf16(dev):
     d0 = rel_err(g12["fwd_y16"], g12["fwd_y32"])
     e16, e32 = rel_err(y, g12["fwd_y16"]), rel_err(y, g12["fwd_y32"])
     print("forward: d0 %.2e, vs reference bf16 %.2e, vs reference fp32 %.2e" % (d0, e16, e32))
-    assert 5e-3 < d0 < 1e-2 and e16 < 2.5 * d0 and e32 < 1.5 * d0
+    assert 5e-3 < d0 < 1e-2 and e16 < 1.5 * d0 and e32 < 1.5 * d0
     # ---- 10-step CFG 4.5 Euler run, bs 2, same seed -> same bf16 noise draw as the reference
     dac = sampler.FoleyDAC(dsd, dev, C.DAC_TINY)
     cnd = synth.synth_conditioning(c, 1.0, t2a=False, sd=sd)
@@ -662,7 +792,7 @@ def test_bf16_mode_against_reference_bf16(dev):
     ew16, ew32 = rel_err(audio[..., ::5], g12["cfg_b16_wave_s5"]), rel_err(audio[..., ::5], g12["cfg_f32_wave_s5"])
     print("10-step CFG: latents d0 %.2e (ours vs ref-bf16 %.2e, vs ref-fp32 %.2e); waveform d0 %.2e (%.2e, %.2e)"
           % (dl, el16, el32, dw, ew16, ew32))
-    assert el16 < 2.5 * dl and el32 < 1.5 * dl and ew16 < 2.5 * dw and ew32 < 1.5 * dw
+    assert el16 < 1.5 * dl and el32 < 1.5 * dl and ew16 < 1.5 * dw and ew32 < 1.5 * dw
     # ---- C5 structure: fp8_e4m3fn storage + bf16 compute, 30 s shapes, the cond half of the CFG pair
     m8 = nodes.HunyuanModelLoader.pack_state_dict(sd, "bf16", "fp8_e4m3fn", device=dev, cfg=c)
     La, Lv, Ls = C.lengths(30.0, c)

@@ -349,7 +349,10 @@ def test_attention(dev, out_dtype, B, H, Sq, Skv, split, kv_bdiv):
 @pytest.mark.parametrize("B,H,Sq,Skv,split,kv_bdiv", [
     (2, 2, 58, 58, 8, 1), (4, 3, 290, 77, 40, 2), (2, 12, 250, 250, 0, 1), (1, 1, 33, 31, 5, 1), (1, 2, 100, 1500, 0, 1),
     # >= 256 workgroups of 128 queries: the wide kernel (K / V^T tiles staged in LDS, no key split)
-    (16, 12, 290, 290, 40, 1), (16, 12, 290, 77, 40, 8), (32, 4, 257, 95, 3, 1), (64, 2, 129, 33, 0, 2)])
+    (16, 12, 290, 290, 40, 1), (16, 12, 290, 77, 40, 8), (32, 4, 257, 95, 3, 1), (64, 2, 129, 33, 0, 2),
+    # config C5 (30 s, CFG pair): the wide kernel at its real key-tile counts - 55 / 47 tiles of online-softmax
+    # rescaling with a ragged last tile (1740 = 54*32 + 12, 1500 = 46*32 + 28), and the 77 cached text keys
+    (2, 12, 1740, 1740, 240, 1), (2, 12, 1500, 1500, 0, 1), (2, 12, 1740, 77, 240, 1)])
 def test_attention_bf16(dev, B, H, Sq, Skv, split, kv_bdiv):
     """Throughput kernels: bf16 Q/K, transposed bf16 V with a padded pitch; 4-wave key split for
     small grids, 128-query workgroups with LDS-staged key tiles for large ones."""
