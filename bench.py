@@ -45,7 +45,7 @@ from foley_amd.host import config as C  # noqa: E402
 from foley_amd.host import distributed as D  # noqa: E402
 from foley_amd.host import packers, sampler, synth  # noqa: E402
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 STEPS_PER_CLIP, GUIDANCE = 50, 4.5
 CONFIGS = {
@@ -167,7 +167,7 @@ def parse_args(argv=None):
     ap.add_argument("--bs", type=int, default=None, help="clips per GPU per step (default 1, plus an extra bs=8 measurement)")
     ap.add_argument("--duration", type=float, default=None)
     ap.add_argument("--quantization", default=None, choices=["none", "fp8_e4m3fn", "fp8_e5m2"])
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--model", default="xxl", choices=["xxl", "xl", "tiny"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -45,6 +45,15 @@ template <> struct Pack4Out<bf16_t> {
   }
 };
 
+template <> struct Pack4Out<f16_t> {
+  static __device__ __forceinline__ void store(f16_t* p, const f32x4 v) {
+    uint2 w;
+    w.x = pack_f16x2(v[0], v[1]);
+    w.y = pack_f16x2(v[2], v[3]);
+    *(uint2*)p = w;
+  }
+};
+
 template <typename OutT>
 __global__ __launch_bounds__(64) void attn_kernel(const AttnArgs a) {
   const int lane = threadIdx.x;
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(64) void attn_kernel(const AttnArgs a) {
 // Key rows are fed to the first MFMA in a permuted order (pi) chosen so that each lane's 16
 // scores belong to 16 CONSECUTIVE keys: the exponentiated scores then form, in place, the
 // key-contiguous B operand of the second MFMA, and V^T rows are plain 16-byte loads.
-template <typename OutT>
+template <typename T, typename OutT>
 __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
   __shared__ float sO[4][3][16][64];  // partial O of the d-fragments a wave does not finalise itself
   __shared__ float sM[4][32], sL[4][32];
@@ -165,16 +174,16 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
   attn_block_coords(a, 32, qt, h, b);
   const int q0 = qt * 32;
   const int bk = b / a.kv_bdiv;
-  const bf16_t* __restrict__ Q = (const bf16_t*)a.q + ((long)(b * a.H + h) * a.Sq) * HD;
-  const bf16_t* __restrict__ K = (const bf16_t*)a.k + ((long)(bk * a.H + h) * a.Skv) * HD;
-  const bf16_t* __restrict__ VT = (const bf16_t*)a.v + ((long)(bk * a.H + h) * HD) * a.vt_pitch;
+  const T* __restrict__ Q = (const T*)a.q + ((long)(b * a.H + h) * a.Sq) * HD;
+  const T* __restrict__ K = (const T*)a.k + ((long)(bk * a.H + h) * a.Skv) * HD;
+  const T* __restrict__ VT = (const T*)a.v + ((long)(bk * a.H + h) * HD) * a.vt_pitch;
   const float scale2 = 0.08838834764831845f * 1.4426950408889634f;   // log2(e) / sqrt(128)
 
   const bool stamp = a.dbg && threadIdx.x == 0;
   if (stamp) a.dbg[(long)blockIdx.x * 8 + 0] = wall_clock64();
   bf16x8 qf[8];
   {
-    const bf16_t* p = Q + (long)min(q0 + j, a.Sq - 1) * HD + 8 * kh;
+    const T* p = Q + (long)min(q0 + j, a.Sq - 1) * HD + 8 * kh;
 #pragma unroll
     for (int s = 0; s < 8; ++s) qf[s] = *(const bf16x8*)(p + 16 * s);
   }
@@ -194,7 +203,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) s[e] = 0.f;
 #pragma unroll
-    for (int st = 0; st < 8; ++st) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[st], qf[st], s, 0, 0, 0);
+    for (int st = 0; st < 8; ++st) s = mfma16<T>(kf[st], qf[st], s);
     // s[e] = score(key kt + 16*kh + e, query q0 + j), kept in the log2 domain (scale2 = log2(e)/sqrt(128)):
     // the exponentials are single v_exp_f32 instructions
     float mx = -INFINITY;
@@ -211,7 +220,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
     for (int e = 0; e < 16; ++e) {
       const float pv = __builtin_amdgcn_exp2f(s[e] - m_new);
       ps += pv;
-      pb[e >> 3][e & 7] = (__bf16)pv;
+      pb[e >> 3][e & 7] = to_carrier<T>(pv);
     }
     ps += __shfl_xor(ps, 32, 64);
     // the 64 accumulator rescales only when some query's running maximum moved (rare after the first tiles)
@@ -228,10 +237,10 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int d = 0; d < 4; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[u][d], pb[u], o[d], 0, 0, 0);
+      for (int d = 0; d < 4; ++d) o[d] = mfma16<T>(vf[u][d], pb[u], o[d]);
   };
   auto load_k = [&](int kt, bf16x8 (&kf)[8]) {
-    const bf16_t* p = K + (long)min(kt + pi, a.Skv - 1) * HD + 8 * kh;
+    const T* p = K + (long)min(kt + pi, a.Skv - 1) * HD + 8 * kh;
 #pragma unroll
     for (int st = 0; st < 8; ++st) kf[st] = *(const bf16x8*)(p + 16 * st);
   };
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
 // the operands are read from L2 once per 128 queries instead of once per 32 (the narrow kernel above
 // re-reads them for each of its 32-query workgroups: ~10x at S = 290).  No cross-wave merge.
 // LDS rows are padded (K: 272 B, V^T: 80 B) so the 16-lane groups of ds_read_b128 hit distinct banks.
-template <typename OutT>
+template <typename T, typename OutT>
 __global__ __launch_bounds__(256) void attn_bf16_wide_kernel(const AttnArgs a) {
   constexpr int KP = 272, VP = 80;                       // LDS row pitches in bytes
   constexpr int STG = 32 * KP + 128 * VP;                // one stage: K tile + V^T tile
@@ -359,14 +368,14 @@ __global__ __launch_bounds__(256) void attn_bf16_wide_kernel(const AttnArgs a) {
   attn_block_coords(a, 128, qt, h, b);
   const int q0 = qt * 128 + w * 32;
   const int bk = b / a.kv_bdiv;
-  const bf16_t* __restrict__ Q = (const bf16_t*)a.q + ((long)(b * a.H + h) * a.Sq) * HD;
-  const bf16_t* __restrict__ K = (const bf16_t*)a.k + ((long)(bk * a.H + h) * a.Skv) * HD;
-  const bf16_t* __restrict__ VT = (const bf16_t*)a.v + ((long)(bk * a.H + h) * HD) * a.vt_pitch;
+  const T* __restrict__ Q = (const T*)a.q + ((long)(b * a.H + h) * a.Sq) * HD;
+  const T* __restrict__ K = (const T*)a.k + ((long)(bk * a.H + h) * a.Skv) * HD;
+  const T* __restrict__ VT = (const T*)a.v + ((long)(bk * a.H + h) * HD) * a.vt_pitch;
   const float scale2 = 0.08838834764831845f * 1.4426950408889634f;   // log2(e) / sqrt(128)
 
   bf16x8 qf[8];
   {
-    const bf16_t* p = Q + (long)min(q0 + j, a.Sq - 1) * HD + 8 * kh;
+    const T* p = Q + (long)min(q0 + j, a.Sq - 1) * HD + 8 * kh;
 #pragma unroll
     for (int s = 0; s < 8; ++s) qf[s] = *(const bf16x8*)(p + 16 * s);
   }
@@ -415,7 +424,7 @@ __global__ __launch_bounds__(256) void attn_bf16_wide_kernel(const AttnArgs a) {
     for (int e = 0; e < 16; ++e) s[e] = 0.f;
 #pragma unroll
     for (int st = 0; st < 8; ++st)
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Ks + pi * KP + (16 * st + 8 * kh) * 2), qf[st], s, 0, 0, 0);
+      s = mfma16<T>(*(const bf16x8*)(Ks + pi * KP + (16 * st + 8 * kh) * 2), qf[st], s);
     // s[e] = score(key kt + 16*kh + e, query q0 + j), kept in the log2 domain (scale2 = log2(e)/sqrt(128)):
     // the exponentials are single v_exp_f32 instructions
     // raw scores: the scale (log2(e)/sqrt(128) > 0) commutes with the maximum and is folded into the exponent's FMA;
@@ -435,7 +444,7 @@ __global__ __launch_bounds__(256) void attn_bf16_wide_kernel(const AttnArgs a) {
     for (int e = 0; e < 16; ++e) {
       const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], scale2, -m_new));
       ps += pv;
-      pb[e >> 3][e & 7] = (__bf16)pv;
+      pb[e >> 3][e & 7] = to_carrier<T>(pv);
     }
     ps += __shfl_xor(ps, 32, 64);
     // the 64 accumulator rescales only when some query's running maximum moved (rare after the first tiles)
@@ -453,7 +462,7 @@ __global__ __launch_bounds__(256) void attn_bf16_wide_kernel(const AttnArgs a) {
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int d = 0; d < 4; ++d)
-        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Vs + (d * 32 + j) * VP + (16 * kh + 8 * u) * 2), pb[u], o[d], 0, 0, 0);
+        o[d] = mfma16<T>(*(const bf16x8*)(Vs + (d * 32 + j) * VP + (16 * kh + 8 * u) * 2), pb[u], o[d]);
     const long long cb = acct ? (long long)__builtin_readcyclecounter() : 0;
     if (t + 1 < nt) {
       lstore((t + 1) & 1);        // stage (t+1)&1 was last read in iteration t-1: every wave passed the barrier below since
@@ -503,22 +512,29 @@ int launch_attention(const AttnArgs& a_in, int out_dtype, hipStream_t st) {
   if (a.Sq <= 0 || a.Skv <= 0) return foley_set_err("attention: empty sequence", __FILE__, __LINE__);
   dim3 grid((a.Sq + 31) / 32, a.H, a.Bq), block(64);
   const dim3 grid1(grid.x * grid.y * grid.z);   // bf16 kernels: 1-D grid, XCD-aware remap inside
-  if (a.in_dtype == FOLEY_BF16) {
+  if (foley_is_half(a.in_dtype)) {
     if (a.vt_pitch < ((a.Skv + 31) & ~31) || (a.vt_pitch & 7))
       return foley_set_err("attention: V^T pitch must cover Skv rounded up to 32 (multiple of 8)", __FILE__, __LINE__);
+    if (out_dtype != a.in_dtype && out_dtype != FOLEY_F32)
+      return foley_set_err("attention: 16-bit operands produce the same type or fp32", __FILE__, __LINE__);
     // enough 128-query workgroups to cover the chip => the wide kernel (operands read once per 128 queries)
     const dim3 gw(((a.Sq + 127) / 128) * a.H * a.Bq);
-    if ((long)gw.x >= 256) {
-      if (out_dtype == FOLEY_BF16) FOLEY_LAUNCH(attn_bf16_wide_kernel<bf16_t>, gw, dim3(256), 0, st, a);
-      else FOLEY_LAUNCH(attn_bf16_wide_kernel<float>, gw, dim3(256), 0, st, a);
-    } else if (out_dtype == FOLEY_BF16) FOLEY_LAUNCH(attn_bf16_kernel<bf16_t>, grid1, dim3(256), 0, st, a);
-    else FOLEY_LAUNCH(attn_bf16_kernel<float>, grid1, dim3(256), 0, st, a);
+    const bool wide = (long)gw.x >= 256, h16 = a.in_dtype == FOLEY_F16, o32 = out_dtype == FOLEY_F32;
+#define FOLEY_ATTN16(T, O)                                                                 \
+    do {                                                                                     \
+      if (wide) FOLEY_LAUNCH((attn_bf16_wide_kernel<T, O>), gw, dim3(256), 0, st, a);         \
+      else FOLEY_LAUNCH((attn_bf16_kernel<T, O>), grid1, dim3(256), 0, st, a);                \
+    } while (0)
+    if (h16) { if (o32) FOLEY_ATTN16(f16_t, float); else FOLEY_ATTN16(f16_t, f16_t); }
+    else { if (o32) FOLEY_ATTN16(bf16_t, float); else FOLEY_ATTN16(bf16_t, bf16_t); }
+#undef FOLEY_ATTN16
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) return foley_set_err(hipGetErrorString(e2), __FILE__, __LINE__);
     return 0;
   }
   if (out_dtype == FOLEY_F32) FOLEY_LAUNCH(attn_kernel<float>, grid, block, 0, st, a);
   else if (out_dtype == FOLEY_BF16) FOLEY_LAUNCH(attn_kernel<bf16_t>, grid, block, 0, st, a);
+  else if (out_dtype == FOLEY_F16) FOLEY_LAUNCH(attn_kernel<f16_t>, grid, block, 0, st, a);
   else return foley_set_err("attention: bad output dtype", __FILE__, __LINE__);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);

@@ -9,9 +9,14 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;  // 16-byte staging register (native vector: stays in VGPRs)
 typedef uint16_t bf16_t;  // storage type for bf16 in global/LDS memory
+typedef _Float16 f16_t;   // storage type for IEEE fp16 (precision=fp16 / fp16 checkpoints: the reference runs those under
+                          // torch.autocast(float16), nodes.py:89-106, utils.py:229-234).  Every 16-bit code path is shared
+                          // with bf16 - same tiles, LDS images and DMA; only the MFMA opcode and the conversions differ.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
 // ---- dtype codes shared with include/foley_hip.h -------------------------------------------
-enum { FOLEY_F32 = 0, FOLEY_BF16 = 1, FOLEY_I32 = 2, FOLEY_F8E4M3 = 3, FOLEY_F8E5M2 = 4 };
+enum { FOLEY_F32 = 0, FOLEY_BF16 = 1, FOLEY_I32 = 2, FOLEY_F8E4M3 = 3, FOLEY_F8E5M2 = 4, FOLEY_F16 = 5 };
+__host__ __device__ constexpr bool foley_is_half(int dt) { return dt == FOLEY_BF16 || dt == FOLEY_F16; }   // 16-bit operand types
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 // round-to-nearest-even, NaN preserved (matches torch .to(bfloat16))
@@ -30,6 +35,32 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, p);
 }
 
+// two floats -> packed fp16 pair (round-to-nearest-even, like torch .to(float16))
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+  const f16x2_t p = {(_Float16)lo, (_Float16)hi};
+  return __builtin_bit_cast(uint32_t, p);
+}
+// packed pair in the 16-bit type T (bf16_t or f16_t)
+template <typename T> __device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
+  if constexpr (sizeof(T) == 2 && !__is_same(T, bf16_t)) return pack_f16x2(lo, hi);
+  else return pack_bf16x2(lo, hi);
+}
+// 16-bit MFMA of the operand type: fragments travel as 128-bit registers (bf16x8 is just the carrier type)
+template <typename T> __device__ __forceinline__ f32x16 mfma16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+  if constexpr (__is_same(T, f16_t)) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// one fp32 value as a lane of the 16-bit carrier vector (attention: probabilities -> B operand of the P V product)
+template <typename T> __device__ __forceinline__ __bf16 to_carrier(float v) {
+  if constexpr (__is_same(T, f16_t)) return __builtin_bit_cast(__bf16, (_Float16)v);
+  else return (__bf16)v;
+}
+template <typename T> struct DtCode;
+template <> struct DtCode<float> { static constexpr int v = FOLEY_F32; };
+template <> struct DtCode<bf16_t> { static constexpr int v = FOLEY_BF16; };
+template <> struct DtCode<f16_t> { static constexpr int v = FOLEY_F16; };
+
 template <typename T> struct Cvt;
 template <> struct Cvt<float> {
   static __device__ __forceinline__ float to(float v) { return v; }
@@ -38,6 +69,10 @@ template <> struct Cvt<float> {
 template <> struct Cvt<bf16_t> {
   static __device__ __forceinline__ bf16_t to(float v) { return f32_to_bf16(v); }
   static __device__ __forceinline__ float from(bf16_t v) { return bf16_to_f32(v); }
+};
+template <> struct Cvt<f16_t> {
+  static __device__ __forceinline__ f16_t to(float v) { return (f16_t)v; }
+  static __device__ __forceinline__ float from(f16_t v) { return (float)v; }
 };
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }

@@ -184,7 +184,7 @@ void foley_ctx_set_wstore_free(foley_ctx* c, void (*fn)(void*)) { c->wstore_free
 const foley_config* foley_ctx_config(foley_ctx* c) { return &c->cfg; }
 int foley_ctx_device(foley_ctx* c) { return c->device; }
 
-static size_t esize(int dtype) { return dtype == FOLEY_BF16 ? 2 : (dtype == FOLEY_F8E4M3 || dtype == FOLEY_F8E5M2) ? 1 : 4; }
+static size_t esize(int dtype) { return foley_is_half(dtype) ? 2 : (dtype == FOLEY_F8E4M3 || dtype == FOLEY_F8E5M2) ? 1 : 4; }
 
 static int ctx_alloc(foley_ctx* c, size_t bytes, void** out) {
   void* p = nullptr;
@@ -277,7 +277,7 @@ static int get_lin(foley_ctx* c, const std::string& name, int dtype, int N, int 
   const void* w;
   out->wfmt = 0;
   auto it = c->tensors.find(name + ".w");
-  if (it != c->tensors.end() && dtype == FOLEY_BF16 && (it->second.dtype == FOLEY_F8E4M3 || it->second.dtype == FOLEY_F8E5M2)) {
+  if (it != c->tensors.end() && foley_is_half(dtype) && (it->second.dtype == FOLEY_F8E4M3 || it->second.dtype == FOLEY_F8E5M2)) {
     // fp8 weight-only storage (reference FP8WeightWrapper): the GEMM widens in registers
     out->wfmt = it->second.dtype == FOLEY_F8E4M3 ? 1 : 2;
     TRY(get_tensor(c, name + ".w", it->second.dtype, {N, K}, &w));
@@ -327,8 +327,8 @@ extern "C" int foley_ctx_create(int device, const foley_config* cfg, foley_ctx**
   if (!cfg || !out) return FAIL(FOLEY_ERR_INVALID, "null argument");
   if (cfg->hidden % cfg->heads || cfg->hidden / cfg->heads != 128)
     return FAIL(FOLEY_ERR_INVALID, "head_dim must be 128");
-  if (cfg->compute_dtype != FOLEY_DT_F32 && cfg->compute_dtype != FOLEY_DT_BF16)
-    return FAIL(FOLEY_ERR_INVALID, "compute_dtype must be f32 or bf16");
+  if (cfg->compute_dtype != FOLEY_DT_F32 && cfg->compute_dtype != FOLEY_DT_BF16 && cfg->compute_dtype != FOLEY_DT_F16)
+    return FAIL(FOLEY_ERR_INVALID, "compute_dtype must be f32, bf16 or f16");
   if (cfg->dac_n_rates < 1 || cfg->dac_n_rates > 8) return FAIL(FOLEY_ERR_INVALID, "bad dac_n_rates");
   int ndev = 0;
   HIPTRY(hipGetDeviceCount(&ndev));
@@ -587,8 +587,8 @@ extern "C" int foley_prepare(foley_ctx* c, const foley_plan* pl, void* stream_v)
       q.gain[0] = (const float*)kn; q.pos[0] = pl->pos_linear;
       const int Ltp = (Lt + 31) & ~31;
       q.dst[0] = (char*)c->txt_k + (size_t)b * ncfg * H * Lt * 128 * es;
-      q.dst[1] = (char*)c->txt_v + (size_t)b * ncfg * H * (T == FOLEY_BF16 ? Ltp : Lt) * 128 * es;
-      q.out_dtype = T; q.vt_pitch = T == FOLEY_BF16 ? Ltp : 0;
+      q.dst[1] = (char*)c->txt_v + (size_t)b * ncfg * H * (foley_is_half(T) ? Ltp : Lt) * 128 * es;
+      q.out_dtype = T; q.vt_pitch = foley_is_half(T) ? Ltp : 0;
       q.S_tot = Lt; q.tok_off = 0; q.eps = 1e-6f; q.cos_tab = pl->rope_cos; q.sin_tab = pl->rope_sin;
       TRY(launch_qkv_split(q, st));
     }
@@ -700,7 +700,7 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
   const int D = f.hidden, H = f.heads, C = f.latent_dim, T = f.compute_dtype;
   const int ncfg = pl.ncfg, clips = pl.clips, La = pl.La, Lv = pl.Lv, Ls = pl.Ls, Lt = pl.Lt, NI = pl.n_iter;
   const int Bc = ncfg * clips, M = Bc * La, Mv = Bc * Lv, S = La + Lv;
-  const bool bf = T == FOLEY_BF16;
+  const bool bf = foley_is_half(T);   // 16-bit throughput mode (bf16 or fp16 operands): transposed V, fused head split
   const size_t es = esize(T);
   const int Sp = (S + 31) & ~31, Lap = (La + 31) & ~31;  // V^T row pitches (bf16 attention)
   const int* sp = c->step_ctr;

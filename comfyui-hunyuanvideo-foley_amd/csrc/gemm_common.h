@@ -14,6 +14,9 @@ template <> struct Frag<float> {
 template <> struct Frag<bf16_t> {
   static constexpr int EPC = 8;
 };
+template <> struct Frag<f16_t> {
+  static constexpr int EPC = 8;
+};
 
 // dbg_mode 0: 4 stamps per workgroup.  dbg_mode 1: workgroup 0 adds its prologue / K-loop / epilogue
 // ticks and a launch count to dbg[0..3] (totals over every GEMM of a forward pass).
@@ -162,6 +165,15 @@ template <> struct VecStore<bf16_t> {
     u32x4 w;
 #pragma unroll
     for (int u = 0; u < 4; ++u) w[u] = pack_bf16x2(v[2 * u], v[2 * u + 1]);
+    *(u32x4*)p = w;
+  }
+};
+template <> struct VecStore<f16_t> {
+  static constexpr int CP = 8;
+  static __device__ __forceinline__ void store(f16_t* p, const float (&v)[8]) {
+    u32x4 w;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) w[u] = pack_f16x2(v[2 * u], v[2 * u + 1]);
     *(u32x4*)p = w;
   }
 };

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_conv3_kernel(const GemmPair 
               for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int jj = 0; jj < FN; ++jj)
-                  acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[jj], acc[i][jj], 0, 0, 0);
+                  acc[i][jj] = mfma16<T>(a[i], b[jj], acc[i][jj]);
             }
           }
         }
@@ -240,6 +240,11 @@ int launch_gemm_conv3(const GemmArgs& g, int dtype, int epi, int tile, hipStream
     if (g.tapC % 64) return foley_set_err("conv3: channel count must be a multiple of 64", __FILE__, __LINE__);
     if (tile == 1) return launch_c3_epi<bf16_t, 128, 128, 4, 2, 3>(g, epi, st);
     return launch_c3_epi<bf16_t, 64, 64, 2, 2, 3>(g, epi, st);
+  }
+  if (dtype == FOLEY_F16) {
+    if (g.tapC % 64) return foley_set_err("conv3: channel count must be a multiple of 64", __FILE__, __LINE__);
+    if (tile == 1) return launch_c3_epi<f16_t, 128, 128, 4, 2, 3>(g, epi, st);
+    return launch_c3_epi<f16_t, 64, 64, 2, 2, 3>(g, epi, st);
   }
   if (dtype == FOLEY_F32) {
     if (g.tapC % 32) return foley_set_err("conv3: channel count must be a multiple of 32", __FILE__, __LINE__);

@@ -1,4 +1,5 @@
-// Wave-specialised GEMM mainloop for gfx950 (bf16 operands): LW loader waves do nothing but feed
+// Wave-specialised GEMM mainloop for gfx950 (16-bit operands: T = bf16_t or f16_t; included by gemm_ws_bf16.hip and
+// gemm_ws_f16.hip, one translation unit per operand type so that they compile in parallel): LW loader waves do nothing but feed
 // the LDS ring with buffer_load_dwordx4 ... lds, WM*WN consumer waves do nothing but read fragments
 // and issue MFMAs; one s_barrier per K-slice couples them.
 //
@@ -17,6 +18,7 @@
 // Same operand addressing as gemm.hip (virtual rows / taps; zero fill through the buffer range
 // check), same source-side XOR swizzle, same epilogues (gemm_common.h).  reference ops: F.linear,
 // ChannelLastConv1d (mlp_layers.py:104-110), see include/foley_hip.h foley_op_gemm.
+#pragma once
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -44,25 +46,32 @@ __device__ __forceinline__ void buf_prefetch4(const void* base, unsigned bytes, 
 
 // fp8 -> bf16 (exact: every e4m3fn / e5m2 value is a bf16 value): 16 weights of one ds_read_b128 become
 // the B fragments of two consecutive k-steps.  v_cvt_scalef32_pk_bf16_{fp8,bf8} with scale 1.
-template <int WF>
+template <int WF, typename T>
 __device__ __forceinline__ void cvt_fp8x16(const u32x4 w, bf16x8& lo, bf16x8& hi) {
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-  bf16x2 p[8];
+  uint32_t p[8];   // packed pairs in the operand type (bf16 or fp16); both conversions are exact
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    if constexpr (WF == 1) {
-      p[2 * i] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)w[i], 1.0f, false);
-      p[2 * i + 1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)w[i], 1.0f, true);
+    if constexpr (__is_same(T, f16_t)) {
+      if constexpr (WF == 1) {
+        p[2 * i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)w[i], 1.0f, false));
+        p[2 * i + 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)w[i], 1.0f, true));
+      } else {
+        p[2 * i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_bf8((int)w[i], 1.0f, false));
+        p[2 * i + 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_bf8((int)w[i], 1.0f, true));
+      }
     } else {
-      p[2 * i] = __builtin_amdgcn_cvt_scalef32_pk_bf16_bf8((int)w[i], 1.0f, false);
-      p[2 * i + 1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_bf8((int)w[i], 1.0f, true);
+      if constexpr (WF == 1) {
+        p[2 * i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)w[i], 1.0f, false));
+        p[2 * i + 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)w[i], 1.0f, true));
+      } else {
+        p[2 * i] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_bf8((int)w[i], 1.0f, false));
+        p[2 * i + 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_bf8((int)w[i], 1.0f, true));
+      }
     }
   }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    lo[2 * i] = p[i][0]; lo[2 * i + 1] = p[i][1];
-    hi[2 * i] = p[4 + i][0]; hi[2 * i + 1] = p[4 + i][1];
-  }
+  const u32x4 l = {p[0], p[1], p[2], p[3]}, h = {p[4], p[5], p[6], p[7]};
+  lo = __builtin_bit_cast(bf16x8, l);
+  hi = __builtin_bit_cast(bf16x8, h);
 }
 
 // WF: weight storage of the B operand - 0 bf16, 1 fp8 e4m3fn, 2 fp8 e5m2 (reference FP8WeightWrapper,
@@ -72,9 +81,8 @@ __device__ __forceinline__ void cvt_fp8x16(const u32x4 w, bf16x8& lo, bf16x8& hi
 // a kernel-argument load at a CONSTANT offset (hoisted and batched into a few wide s_loads at entry).  With
 // a run-time index the compiler re-loaded fields one dword at a time at their points of use: 200 scalar
 // loads, 169 of them serialised through the epilogue (tools/kernel_resources.py, gemm_timeline.py --epilogue).
-template <int BM, int BN, int WM, int WN, int NS, int LW, int EPI, int WF, int SEL>
+template <typename T, int BM, int BN, int WM, int WN, int NS, int LW, int EPI, int WF, int SEL>
 __device__ __forceinline__ void gemm_ws_body(const GemmPair& pr) {
-  using T = bf16_t;
   constexpr int sel = SEL;
   const GemmArgs& g = pr.g[SEL];
   constexpr int NW = WM * WN;
@@ -317,7 +325,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmPair& pr) {
     auto cvtb = [&]() {
       if constexpr (WF != 0) {
 #pragma unroll
-        for (int j = 0; j < FN; ++j) cvt_fp8x16<WF>(rawb[j], fb[0][j], fb[1][j]);
+        for (int j = 0; j < FN; ++j) cvt_fp8x16<WF, T>(rawb[j], fb[0][j], fb[1][j]);
       }
     };
     auto mm = [&](auto set) {
@@ -326,7 +334,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmPair& pr) {
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][i], fb[S][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<T>(fa[S][i], fb[S][j], acc[i][j]);
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
@@ -370,7 +378,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmPair& pr) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int j = 0; j < FN; ++j) cvt_fp8x16<WF>(rawb[t][j], fb[2 * t][j], fb[2 * t + 1][j]);
+        for (int j = 0; j < FN; ++j) cvt_fp8x16<WF, T>(rawb[t][j], fb[2 * t][j], fb[2 * t + 1][j]);
     }
   };
   auto mma = [&]() {
@@ -380,7 +388,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmPair& pr) {
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<T>(fa[s][i], fb[s][j], acc[i][j]);
   };
   int stage = 0;
   for (int kt = 0; kt < nk; ++kt) {
@@ -430,10 +438,10 @@ __device__ __forceinline__ void gemm_ws_body(const GemmPair& pr) {
   if (g.dbg && (g.dbg_mode & 0xff) == 4 && tid == 0) g.dbg[(long)blockIdx.x * 4 + 3] = wall_clock64();
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int LW, int EPI, int WF>
+template <typename T, int BM, int BN, int WM, int WN, int NS, int LW, int EPI, int WF>
 __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_kernel(const GemmPair pr) {
-  if ((int)blockIdx.x >= pr.tiles0) gemm_ws_body<BM, BN, WM, WN, NS, LW, EPI, WF, 1>(pr);   // workgroup-uniform
-  else gemm_ws_body<BM, BN, WM, WN, NS, LW, EPI, WF, 0>(pr);
+  if ((int)blockIdx.x >= pr.tiles0) gemm_ws_body<T, BM, BN, WM, WN, NS, LW, EPI, WF, 1>(pr);   // workgroup-uniform
+  else gemm_ws_body<T, BM, BN, WM, WN, NS, LW, EPI, WF, 0>(pr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -456,9 +464,8 @@ constexpr int conv3_inflight(int nsb, int tap, int ai, int bi) {
   return n;
 }
 
-template <int BM, int BN, int WM, int WN, int NSB, int NAB, int LW, int EPI, int WF>
+template <typename T, int BM, int BN, int WM, int WN, int NSB, int NAB, int LW, int EPI, int WF>
 __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_conv3_kernel(const GemmPair pr) {
-  using T = bf16_t;
   const GemmArgs& g = pr.g[0];
   constexpr int NW = WM * WN;
   constexpr int BK = 64, ESZ = 2, OOB = 0x7ffffff0;
@@ -606,7 +613,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_conv3_kernel(cons
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int j = 0; j < FN; ++j) cvt_fp8x16<WF>(rawb[t][j], fb[2 * t][j], fb[2 * t + 1][j]);
+        for (int j = 0; j < FN; ++j) cvt_fp8x16<WF, T>(rawb[t][j], fb[2 * t][j], fb[2 * t + 1][j]);
     }
   };
   auto mma = [&]() {
@@ -616,7 +623,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_conv3_kernel(cons
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][i], fb[s][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<T>(fa[s][i], fb[s][j], acc[i][j]);
   };
   const unsigned char* zrow = lds + ZOFF;
   for (int kt0 = 0; kt0 < nk; kt0 += 3) {
@@ -663,7 +670,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_conv3_kernel(cons
   tl_stamp(g, 3);
 }
 
-template <int BM, int EPI, int WF>
+template <typename T, int BM, int EPI, int WF>
 int launch_ws_conv3_one(const GemmArgs& g, hipStream_t st) {
   // 128x128: activation chunks 3 deep + 6 weight slices; 256x128 (large grids): 2 + 4 (fp8 weights: 3 + 6)
   constexpr int BN = 128, WM = 4, WN = 2, LW = 4;
@@ -677,7 +684,7 @@ int launch_ws_conv3_one(const GemmArgs& g, hipStream_t st) {
   pr.g[0] = g;
   pr.g[1] = g;
   pr.tiles0 = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * (EPI == EPI_GATE_RES ? g.ksplit : 1);
-  auto k = gemm_ws_conv3_kernel<BM, BN, WM, WN, NSB, NAB, LW, EPI, WF>;
+  auto k = gemm_ws_conv3_kernel<T, BM, BN, WM, WN, NSB, NAB, LW, EPI, WF>;
   static bool raised = false;
   if (!raised) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -692,7 +699,7 @@ int launch_ws_conv3_one(const GemmArgs& g, hipStream_t st) {
 
 // 256x64 form (tile 22): same workgroup count as 128x128 on N = 1536 problems, 57 instead of 65 KiB of operands per
 // 64-channel chunk and workgroup (the activation chunk is shared by three taps, so rows are cheaper than columns)
-template <int EPI>
+template <typename T, int EPI>
 int launch_ws_conv3_tall(const GemmArgs& g, hipStream_t st) {
   constexpr int BM = 256, BN = 64, WM = 8, WN = 1, LW = 4, NSB = 6, NAB = 3;
   constexpr size_t ai = ((BM + 2 + 7) / 8 + LW - 1) / LW;
@@ -704,7 +711,7 @@ int launch_ws_conv3_tall(const GemmArgs& g, hipStream_t st) {
   pr.g[0] = g;
   pr.g[1] = g;
   pr.tiles0 = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * (EPI == EPI_GATE_RES ? g.ksplit : 1);
-  auto k = gemm_ws_conv3_kernel<BM, BN, WM, WN, NSB, NAB, LW, EPI, 0>;
+  auto k = gemm_ws_conv3_kernel<T, BM, BN, WM, WN, NSB, NAB, LW, EPI, 0>;
   static bool raised = false;
   if (!raised) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -717,17 +724,17 @@ int launch_ws_conv3_tall(const GemmArgs& g, hipStream_t st) {
   return 0;
 }
 
-template <int BM, int WF>
+template <typename T, int BM, int WF>
 int launch_ws_conv3_fmt(const GemmArgs& g, int epi, hipStream_t st) {
   switch (epi) {
-    case EPI_STORE_F32: return launch_ws_conv3_one<BM, EPI_STORE_F32, WF>(g, st);
-    case EPI_GATE_RES: return launch_ws_conv3_one<BM, EPI_GATE_RES, WF>(g, st);
-    case EPI_SILUGATE_T: return launch_ws_conv3_one<BM, EPI_SILUGATE_T, WF>(g, st);
+    case EPI_STORE_F32: return launch_ws_conv3_one<T, BM, EPI_STORE_F32, WF>(g, st);
+    case EPI_GATE_RES: return launch_ws_conv3_one<T, BM, EPI_GATE_RES, WF>(g, st);
+    case EPI_SILUGATE_T: return launch_ws_conv3_one<T, BM, EPI_SILUGATE_T, WF>(g, st);
   }
   return foley_set_err("wave-specialised conv3: unsupported epilogue", __FILE__, __LINE__);
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int LW, int EPI, int WF>
+template <typename T, int BM, int BN, int WM, int WN, int NS, int LW, int EPI, int WF>
 int launch_ws_one(const GemmArgs& g, const GemmArgs* g1, hipStream_t st) {
   auto ntiles = [](const GemmArgs& q) {
     return ((q.M + BM - 1) / BM) * ((q.N + BN - 1) / BN) * (EPI == EPI_GATE_RES ? q.ksplit : 1);
@@ -740,7 +747,7 @@ int launch_ws_one(const GemmArgs& g, const GemmArgs* g1, hipStream_t st) {
   constexpr size_t lds_ring = (size_t)NS * (BM * 128 + BN * (WF ? 64 : 128));
   constexpr size_t lds_epi = (size_t)BM * BN * 4;            // the epilogues transpose the accumulator tile through LDS
   constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
-  auto k = gemm_ws_kernel<BM, BN, WM, WN, NS, LW, EPI, WF>;
+  auto k = gemm_ws_kernel<T, BM, BN, WM, WN, NS, LW, EPI, WF>;
   static bool raised = false;
   if (!raised) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -753,80 +760,81 @@ int launch_ws_one(const GemmArgs& g, const GemmArgs* g1, hipStream_t st) {
   return 0;
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int LW, int WF>
+template <typename T, int BM, int BN, int WM, int WN, int NS, int LW, int WF>
 int launch_ws_tile(const GemmArgs& g, const GemmArgs* g1, int epi, hipStream_t st) {
   switch (epi) {
-    case EPI_STORE_F32: return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_STORE_F32, WF>(g, g1, st);
-    case EPI_GELU_T: return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_GELU_T, WF>(g, g1, st);
-    case EPI_GATE_RES: return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_GATE_RES, WF>(g, g1, st);
-    case EPI_QKV_SPLIT: return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_QKV_SPLIT, WF>(g, g1, st);
+    case EPI_STORE_F32: return launch_ws_one<T, BM, BN, WM, WN, NS, LW, EPI_STORE_F32, WF>(g, g1, st);
+    case EPI_GELU_T: return launch_ws_one<T, BM, BN, WM, WN, NS, LW, EPI_GELU_T, WF>(g, g1, st);
+    case EPI_GATE_RES: return launch_ws_one<T, BM, BN, WM, WN, NS, LW, EPI_GATE_RES, WF>(g, g1, st);
+    case EPI_QKV_SPLIT: return launch_ws_one<T, BM, BN, WM, WN, NS, LW, EPI_QKV_SPLIT, WF>(g, g1, st);
     case EPI_SILUGATE_T:
-      if constexpr ((BN / WN) % 64 == 0) return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_SILUGATE_T, WF>(g, g1, st);
+      if constexpr ((BN / WN) % 64 == 0) return launch_ws_one<T, BM, BN, WM, WN, NS, LW, EPI_SILUGATE_T, WF>(g, g1, st);
       else return foley_set_err("gated epilogue needs a 64-wide wave tile", __FILE__, __LINE__);
   }
   if constexpr (WF == 0) {   // epilogues only the bf16-weight embedders use
     switch (epi) {
-      case EPI_STORE_T: return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_STORE_T, 0>(g, g1, st);
-      case EPI_SILU_T: return launch_ws_one<BM, BN, WM, WN, NS, LW, EPI_SILU_T, 0>(g, g1, st);
+      case EPI_STORE_T: return launch_ws_one<T, BM, BN, WM, WN, NS, LW, EPI_STORE_T, 0>(g, g1, st);
+      case EPI_SILU_T: return launch_ws_one<T, BM, BN, WM, WN, NS, LW, EPI_SILU_T, 0>(g, g1, st);
     }
   }
   return foley_set_err("wave-specialised GEMM: unsupported epilogue for this weight format", __FILE__, __LINE__);
 }
 
-}  // namespace
-
 // tile: 21 = tap-fused conv k=3 (128x128, 8 consumer + 4 loader waves); 15 = 128x128 (8 consumer + 4 loader waves), 19 = 256x128 (8 + 4), 25 / 29 = the same tiles with 4
 // consumer waves (64x64 / 128x64 per wave); g / g1 fully resolved
 // (ksplit, vec_out, operand extents) by gemm.hip's launcher
-int launch_gemm_ws(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hipStream_t st) {
+template <typename T>
+int launch_gemm_ws_t(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hipStream_t st) {
   if (g.wfmt < 0 || g.wfmt > 2 || (g1 && g1->wfmt != g.wfmt))
     return foley_set_err("wave-specialised GEMM: bad / mixed weight formats", __FILE__, __LINE__);
   if (tile == 22) {   // tap-fused conv k=3, 256x64 (bf16 weights; gated residual / fp32 store)
     if (g1 || g.wfmt) return foley_set_err("wave-specialised conv3 256x64: single problem, bf16 weights", __FILE__, __LINE__);
-    if (epi == EPI_GATE_RES) return launch_ws_conv3_tall<EPI_GATE_RES>(g, st);
-    if (epi == EPI_STORE_F32) return launch_ws_conv3_tall<EPI_STORE_F32>(g, st);
+    if (epi == EPI_GATE_RES) return launch_ws_conv3_tall<T, EPI_GATE_RES>(g, st);
+    if (epi == EPI_STORE_F32) return launch_ws_conv3_tall<T, EPI_STORE_F32>(g, st);
     return foley_set_err("wave-specialised conv3 256x64: unsupported epilogue", __FILE__, __LINE__);
   }
   if (tile == 21 || tile == 23) {   // tap-fused conv k=3, 128x128 / 256x128 (the launcher has checked the conv shape)
     if (g1) return foley_set_err("wave-specialised conv3 has no two-problem form", __FILE__, __LINE__);
     if (tile == 21) {
-      if (g.wfmt == 0) return launch_ws_conv3_fmt<128, 0>(g, epi, st);
-      if (g.wfmt == 1) return launch_ws_conv3_fmt<128, 1>(g, epi, st);
-      return launch_ws_conv3_fmt<128, 2>(g, epi, st);
+      if (g.wfmt == 0) return launch_ws_conv3_fmt<T, 128, 0>(g, epi, st);
+      if (g.wfmt == 1) return launch_ws_conv3_fmt<T, 128, 1>(g, epi, st);
+      return launch_ws_conv3_fmt<T, 128, 2>(g, epi, st);
     }
-    if (g.wfmt == 0) return launch_ws_conv3_fmt<256, 0>(g, epi, st);
-    if (g.wfmt == 1) return launch_ws_conv3_fmt<256, 1>(g, epi, st);
-    return launch_ws_conv3_fmt<256, 2>(g, epi, st);
+    if (g.wfmt == 0) return launch_ws_conv3_fmt<T, 256, 0>(g, epi, st);
+    if (g.wfmt == 1) return launch_ws_conv3_fmt<T, 256, 1>(g, epi, st);
+    return launch_ws_conv3_fmt<T, 256, 2>(g, epi, st);
   }
   if (tile == 26) {   // 96x128, four consumer waves of 96x32, 5 x 28 KiB ring: the fused head split when 96-row tiles fill one round
     if (g.wfmt != 0 || epi != EPI_QKV_SPLIT) return foley_set_err("wave-specialised GEMM: tile 26 is a bf16 head-split tile", __FILE__, __LINE__);
-    return launch_ws_one<96, 128, 1, 4, 5, 4, EPI_QKV_SPLIT, 0>(g, g1, st);
+    return launch_ws_one<T, 96, 128, 1, 4, 5, 4, EPI_QKV_SPLIT, 0>(g, g1, st);
   }
   if (tile == 28) {   // 192x128, four consumer waves of 96x64, 4 x 40 KiB ring: the fused head split of large grids
     if (g.wfmt != 0 || epi != EPI_QKV_SPLIT) return foley_set_err("wave-specialised GEMM: tile 28 is a bf16 head-split tile", __FILE__, __LINE__);
-    return launch_ws_one<192, 128, 2, 2, 4, 4, EPI_QKV_SPLIT, 0>(g, g1, st);
+    return launch_ws_one<T, 192, 128, 2, 2, 4, 4, EPI_QKV_SPLIT, 0>(g, g1, st);
   }
   if (tile == 27) {   // 64x128, four consumer waves of 32x64, 6 x 24 KiB ring: the fused head split of small problems only
     if (g.wfmt != 0 || epi != EPI_QKV_SPLIT) return foley_set_err("wave-specialised GEMM: tile 27 is the bf16 head-split tile", __FILE__, __LINE__);
-    return launch_ws_one<64, 128, 2, 2, 6, 4, EPI_QKV_SPLIT, 0>(g, g1, st);
+    return launch_ws_one<T, 64, 128, 2, 2, 6, 4, EPI_QKV_SPLIT, 0>(g, g1, st);
   }
   if (g.wfmt == 0) {
     switch (tile) {
-      case 15: return launch_ws_tile<128, 128, 4, 2, 5, 4, 0>(g, g1, epi, st);   // 5 x 32 KiB ring = all 160 KiB of LDS
-      case 19: return launch_ws_tile<256, 128, 4, 2, 3, 4, 0>(g, g1, epi, st);
-      case 25: return launch_ws_tile<128, 128, 2, 2, 5, 4, 0>(g, g1, epi, st);   // 4 consumer waves of 64x64 (one per SIMD) + 4 loaders
-      case 29: return launch_ws_tile<256, 128, 2, 2, 3, 4, 0>(g, g1, epi, st);   // 4 consumer waves of 128x64
+      case 15: return launch_ws_tile<T, 128, 128, 4, 2, 5, 4, 0>(g, g1, epi, st);   // 5 x 32 KiB ring = all 160 KiB of LDS
+      case 19: return launch_ws_tile<T, 256, 128, 4, 2, 3, 4, 0>(g, g1, epi, st);
+      case 25: return launch_ws_tile<T, 128, 128, 2, 2, 5, 4, 0>(g, g1, epi, st);   // 4 consumer waves of 64x64 (one per SIMD) + 4 loaders
+      case 29: return launch_ws_tile<T, 256, 128, 2, 2, 3, 4, 0>(g, g1, epi, st);   // 4 consumer waves of 128x64
     }
   } else if (g.wfmt == 1) {   // fp8 e4m3fn weights: 24 / 40 KiB stages
     switch (tile) {
-      case 15: return launch_ws_tile<128, 128, 4, 2, 6, 4, 1>(g, g1, epi, st);
-      case 19: return launch_ws_tile<256, 128, 4, 2, 4, 4, 1>(g, g1, epi, st);
+      case 15: return launch_ws_tile<T, 128, 128, 4, 2, 6, 4, 1>(g, g1, epi, st);
+      case 19: return launch_ws_tile<T, 256, 128, 4, 2, 4, 4, 1>(g, g1, epi, st);
     }
   } else {
     switch (tile) {
-      case 15: return launch_ws_tile<128, 128, 4, 2, 6, 4, 2>(g, g1, epi, st);
-      case 19: return launch_ws_tile<256, 128, 4, 2, 4, 4, 2>(g, g1, epi, st);
+      case 15: return launch_ws_tile<T, 128, 128, 4, 2, 6, 4, 2>(g, g1, epi, st);
+      case 19: return launch_ws_tile<T, 256, 128, 4, 2, 4, 4, 2>(g, g1, epi, st);
     }
   }
   return foley_set_err("wave-specialised GEMM: unknown tile for this weight format", __FILE__, __LINE__);
 }
+
+}  // namespace

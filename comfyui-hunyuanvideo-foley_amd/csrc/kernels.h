@@ -85,7 +85,7 @@ struct GemmArgs {
                       // landed, K loop done, epilogue done); null in production
 };
 
-// dtype: FOLEY_F32 or FOLEY_BF16 operands (accumulation is always fp32). tile: 0 = auto.
+// dtype: FOLEY_F32, FOLEY_BF16 or FOLEY_F16 operands (accumulation is always fp32). tile: 0 = auto.
 // ksplit_used (optional): the K split the launcher chose (callers of the deferred split-K need it)
 int launch_gemm(const GemmArgs& g, int dtype, int epi, int tile, hipStream_t st, int* ksplit_used = nullptr);
 // Two independent problems of the same dtype / epilogue in ONE launch (the audio and the visual
@@ -95,7 +95,8 @@ int launch_gemm_pair(const GemmArgs& g0, const GemmArgs& g1, int dtype, int epi,
 // tap-fused channels-last conv k=3 (gemm_conv3.hip); tile 1 = 128x128, 3 = 64x64; g.ksplit resolved
 int launch_gemm_conv3(const GemmArgs& g, int dtype, int epi, int tile, hipStream_t st);
 // wave-specialised mainloop (gemm_ws.hip, bf16): tile 15 = 128x128, 19 = 256x128; g / g1 resolved by launch_gemm
-int launch_gemm_ws(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hipStream_t st);
+int launch_gemm_ws_bf16(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hipStream_t st);
+int launch_gemm_ws_f16(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // Attention: O = softmax(Q K^T / sqrt(128)) V, no mask.  Q [Bq, H, Sq, 128], K/V [Bkv, H, Skv, 128]

@@ -29,6 +29,15 @@ template <> struct Pack4<bf16_t> {
   }
 };
 
+template <> struct Pack4<f16_t> {
+  static __device__ __forceinline__ void store(f16_t* p, const f32x4 v) {
+    uint2 w;
+    w.x = pack_f16x2(v[0], v[1]);
+    w.y = pack_f16x2(v[2], v[3]);
+    *(uint2*)p = w;
+  }
+};
+
 // One wave per row; every global load of the row (x, shift, scale) is issued before the first
 // reduction so the kernel pays one memory round trip, results leave as 8/16-byte vector stores.
 struct LnPair {
@@ -588,16 +597,18 @@ int launch_ln_mod_pair(const LnArgs& a0, const LnArgs& a1, int D, float eps, int
   pr.dbg = g_ln_dbg;
   dim3 grid(pr.blocks0 + (a1.M + 1) / 2), block(128);
   const int need = (D / 4 + 63) / 64;   // float4 per lane
-  if (out_dtype != FOLEY_F32 && out_dtype != FOLEY_BF16) return foley_set_err("ln_mod: bad dtype", __FILE__, __LINE__);
-  const bool f32o = out_dtype == FOLEY_F32;
+  if (out_dtype != FOLEY_F32 && !foley_is_half(out_dtype)) return foley_set_err("ln_mod: bad dtype", __FILE__, __LINE__);
+  const bool f32o = out_dtype == FOLEY_F32, f16o = out_dtype == FOLEY_F16;
   const bool pend = (a0.M > 0 && a0.pend.partials) || (a1.M > 0 && a1.pend.partials);
 #define FOLEY_LN(V)                                                                                        \
   {                                                                                                        \
     if (pend) {                                                                                            \
       if (f32o) FOLEY_LAUNCH((ln_mod_kernel<float, V, true>), grid, block, 0, st, pr, D, eps);       \
+      else if (f16o) FOLEY_LAUNCH((ln_mod_kernel<f16_t, V, true>), grid, block, 0, st, pr, D, eps);  \
       else FOLEY_LAUNCH((ln_mod_kernel<bf16_t, V, true>), grid, block, 0, st, pr, D, eps);           \
     } else {                                                                                               \
       if (f32o) FOLEY_LAUNCH((ln_mod_kernel<float, V, false>), grid, block, 0, st, pr, D, eps);      \
+      else if (f16o) FOLEY_LAUNCH((ln_mod_kernel<f16_t, V, false>), grid, block, 0, st, pr, D, eps); \
       else FOLEY_LAUNCH((ln_mod_kernel<bf16_t, V, false>), grid, block, 0, st, pr, D, eps);          \
     }                                                                                                      \
   }
@@ -610,9 +621,11 @@ int launch_ln_mod_pair(const LnArgs& a0, const LnArgs& a1, int D, float eps, int
       dim3 blk(128 * W);                                                                                               \
       if (pend) {                                                                                                      \
         if (f32o) FOLEY_LAUNCH((ln_mod_wide_kernel<float, V, true, W>), grid, blk, 0, st, pr, D, eps);                \
+        else if (f16o) FOLEY_LAUNCH((ln_mod_wide_kernel<f16_t, V, true, W>), grid, blk, 0, st, pr, D, eps);           \
         else FOLEY_LAUNCH((ln_mod_wide_kernel<bf16_t, V, true, W>), grid, blk, 0, st, pr, D, eps);                    \
       } else {                                                                                                         \
         if (f32o) FOLEY_LAUNCH((ln_mod_wide_kernel<float, V, false, W>), grid, blk, 0, st, pr, D, eps);               \
+        else if (f16o) FOLEY_LAUNCH((ln_mod_wide_kernel<f16_t, V, false, W>), grid, blk, 0, st, pr, D, eps);          \
         else FOLEY_LAUNCH((ln_mod_wide_kernel<bf16_t, V, false, W>), grid, blk, 0, st, pr, D, eps);                   \
       }                                                                                                                \
     }
@@ -677,6 +690,7 @@ int launch_qkv_split_pair(const QkvSplitArgs& a0, const QkvSplitArgs& a1, hipStr
   dim3 grid((unsigned)(pr.blocks0 + nblk(a1))), block(256);
   if (grid.x == 0) return 0;
   if (a0.out_dtype == FOLEY_BF16) FOLEY_LAUNCH(qkv_split_kernel<bf16_t>, grid, block, 0, st, pr);
+  else if (a0.out_dtype == FOLEY_F16) FOLEY_LAUNCH(qkv_split_kernel<f16_t>, grid, block, 0, st, pr);
   else FOLEY_LAUNCH(qkv_split_kernel<float>, grid, block, 0, st, pr);
   FOLEY_LAUNCH_CHECK();
   return 0;
@@ -715,6 +729,8 @@ int launch_rows_add_act(const float* a, const RowBcast& v, int R, int D, int act
     FOLEY_LAUNCH(rows_add_act_kernel<float>, dim3(grid1d(n, 256)), dim3(256), 0, st, a, v, R, D, act_silu, (float*)out);
   else if (out_dtype == FOLEY_BF16)
     FOLEY_LAUNCH(rows_add_act_kernel<bf16_t>, dim3(grid1d(n, 256)), dim3(256), 0, st, a, v, R, D, act_silu, (bf16_t*)out);
+  else if (out_dtype == FOLEY_F16)
+    FOLEY_LAUNCH(rows_add_act_kernel<f16_t>, dim3(grid1d(n, 256)), dim3(256), 0, st, a, v, R, D, act_silu, (f16_t*)out);
   else return foley_set_err("rows_add_act: bad dtype", __FILE__, __LINE__);
   FOLEY_LAUNCH_CHECK();
   return 0;
@@ -727,6 +743,8 @@ int launch_add_periodic(const float* x, const float* pos, int R, int D, int peri
     FOLEY_LAUNCH(add_periodic_kernel<float>, dim3(grid1d(n, 256)), dim3(256), 0, st, x, pos, R, D, period, (float*)out);
   else if (out_dtype == FOLEY_BF16)
     FOLEY_LAUNCH(add_periodic_kernel<bf16_t>, dim3(grid1d(n, 256)), dim3(256), 0, st, x, pos, R, D, period, (bf16_t*)out);
+  else if (out_dtype == FOLEY_F16)
+    FOLEY_LAUNCH(add_periodic_kernel<f16_t>, dim3(grid1d(n, 256)), dim3(256), 0, st, x, pos, R, D, period, (f16_t*)out);
   else return foley_set_err("add_periodic: bad dtype", __FILE__, __LINE__);
   FOLEY_LAUNCH_CHECK();
   return 0;
@@ -746,6 +764,10 @@ int launch_cast(const void* src, int sd, void* dst, int dd, long n, hipStream_t 
     FOLEY_LAUNCH((cast_kernel<float, bf16_t>), g, b, 0, st, (const float*)src, (bf16_t*)dst, n);
   else if (sd == FOLEY_BF16 && dd == FOLEY_F32)
     FOLEY_LAUNCH((cast_kernel<bf16_t, float>), g, b, 0, st, (const bf16_t*)src, (float*)dst, n);
+  else if (sd == FOLEY_F32 && dd == FOLEY_F16)
+    FOLEY_LAUNCH((cast_kernel<float, f16_t>), g, b, 0, st, (const float*)src, (f16_t*)dst, n);
+  else if (sd == FOLEY_F16 && dd == FOLEY_F32)
+    FOLEY_LAUNCH((cast_kernel<f16_t, float>), g, b, 0, st, (const f16_t*)src, (float*)dst, n);
   else if (sd == FOLEY_F32 && dd == FOLEY_F32)
     FOLEY_LAUNCH((cast_kernel<float, float>), g, b, 0, st, (const float*)src, (float*)dst, n);
   else return foley_set_err("cast: unsupported dtype pair", __FILE__, __LINE__);
@@ -759,6 +781,8 @@ int launch_latent_rows(const float* x, int clips, int C, int L, int ncfg, void* 
     FOLEY_LAUNCH(latent_rows_kernel<float>, grid, block, 0, st, x, clips, C, L, ncfg, (float*)out);
   else if (out_dtype == FOLEY_BF16)
     FOLEY_LAUNCH(latent_rows_kernel<bf16_t>, grid, block, 0, st, x, clips, C, L, ncfg, (bf16_t*)out);
+  else if (out_dtype == FOLEY_F16)
+    FOLEY_LAUNCH(latent_rows_kernel<f16_t>, grid, block, 0, st, x, clips, C, L, ncfg, (f16_t*)out);
   else return foley_set_err("latent_rows: bad dtype", __FILE__, __LINE__);
   FOLEY_LAUNCH_CHECK();
   return 0;
@@ -767,6 +791,7 @@ int launch_latent_rows(const float* x, int clips, int C, int L, int ncfg, void* 
 int launch_solver_step(const StepArgs& a, hipStream_t st) {
   dim3 grid((a.L + 31) / 32, (a.C + 31) / 32, a.clips), block(256);
   if (a.rows_dtype == FOLEY_BF16) FOLEY_LAUNCH(solver_step_kernel<bf16_t>, grid, block, 0, st, a);
+  else if (a.rows_dtype == FOLEY_F16) FOLEY_LAUNCH(solver_step_kernel<f16_t>, grid, block, 0, st, a);
   else FOLEY_LAUNCH(solver_step_kernel<float>, grid, block, 0, st, a);
   FOLEY_LAUNCH_CHECK();
   FOLEY_LAUNCH(step_increment_kernel, dim3(1), dim3(1), 0, st, a.step_ptr);

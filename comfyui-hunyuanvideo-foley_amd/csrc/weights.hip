@@ -47,7 +47,7 @@ namespace {
     }                                                            \
   } while (0)
 
-enum { DT_F16 = 5 };   // accepted as a checkpoint dtype only (FOLEY_DT_F16)
+enum { DT_F16 = FOLEY_F16 };   // fp16: a checkpoint dtype and (precision=fp16) a compute / arena dtype
 
 __host__ __device__ inline int dt_size(int dt) {
   return (dt == FOLEY_F8E4M3 || dt == FOLEY_F8E5M2) ? 1 : (dt == FOLEY_BF16 || dt == DT_F16) ? 2 : 4;
@@ -127,6 +127,7 @@ __device__ inline void store_from_f32(void* p, long i, int dt, float v) {
   switch (dt) {
     case FOLEY_F32: ((float*)p)[i] = v; break;
     case FOLEY_BF16: ((bf16_t*)p)[i] = f32_to_bf16(v); break;
+    case DT_F16: ((f16_t*)p)[i] = (f16_t)v; break;
     case FOLEY_F8E4M3: ((uint8_t*)p)[i] = f32_to_f8<4, 3, true>(v); break;
     default: ((uint8_t*)p)[i] = f32_to_f8<5, 2, false>(v); break;
   }
@@ -456,7 +457,7 @@ int load_dit(WStore& w, const std::string& key, const Src& s, hipStream_t st, bo
     *handled = false;
     return 0;
   }
-  const bool f8time = w.wfmt != 0 && f.compute_dtype == FOLEY_DT_BF16;   // golden g8 "Q14": the first time-embedding bias passes through fp8
+  const bool f8time = w.wfmt != 0 && foley_is_half(f.compute_dtype);   // golden g8 "Q14": the first time-embedding bias passes through fp8
   if (key == "audio_embedder.proj.weight") return plain(w, "audio_in.w", s, D, f.latent_dim, st, key);
   if (key == "audio_embedder.proj.bias") return plain(w, "audio_in.b", s, D, 1, st, key);
   if (key == "visual_proj.w1.weight") return gate_pack(w, "vis.w13.w", s, 0, D, f.clip_dim, 1, st, key);
@@ -613,8 +614,8 @@ WStore* store_of(foley_ctx* c) { return c ? (WStore*)*foley_ctx_wstore_slot(c) :
 extern "C" int foley_weights_begin(foley_ctx* c, int weight_format) {
   if (!c || weight_format < 0 || weight_format > 2) return W_FAIL(FOLEY_ERR_INVALID, "bad argument");
   const foley_config* cfg = foley_ctx_config(c);
-  if (weight_format && cfg->compute_dtype != FOLEY_DT_BF16)
-    return W_FAIL(FOLEY_ERR_INVALID, "fp8 weight storage needs bf16 compute");
+  if (weight_format && !foley_is_half(cfg->compute_dtype))
+    return W_FAIL(FOLEY_ERR_INVALID, "fp8 weight storage needs bf16 / fp16 compute");
   W_HIP(hipSetDevice(foley_ctx_device(c)));
   void** slot = foley_ctx_wstore_slot(c);
   if (*slot) {

@@ -75,21 +75,22 @@ def _f32(t: Tensor) -> Tensor:
 
 
 FP8_DTYPES = {"fp8_e4m3fn": torch.float8_e4m3fn, "fp8_e5m2": torch.float8_e5m2}
+HALF_DTYPES = (torch.bfloat16, torch.float16)   # 16-bit compute dtypes of the throughput kernels
 
 
 def pack_dit(sd: Dict[str, Tensor], cfg: DiTConfig, dtype: torch.dtype,
              weight_store: torch.dtype = None) -> "OrderedDict[str, Tensor]":
     """Reference DiT state dict -> packed tensors (CPU or wherever `sd` lives).
 
-    weight_store (torch.float8_e4m3fn / float8_e5m2, bf16 compute only): the matrices of the 54 blocks and the
+    weight_store (torch.float8_e4m3fn / float8_e5m2, bf16 / fp16 compute only): the matrices of the 54 blocks and the
     fused single-block modulation - 99.7 % of the bytes - STAY in fp8 in the arena (the reference's
     FP8WeightWrapper storage, utils.py:316-366; the GEMM widens them in registers).  `sd` must already hold
     fp8-representable values (nodes.fp8_round_state_dict), so the cast is exact.  The small embedders keep
     the compute dtype."""
     out: "OrderedDict[str, Tensor]" = OrderedDict()
     H = cfg.heads
-    if weight_store is not None and dtype != torch.bfloat16:
-        raise ValueError("fp8 weight storage needs bf16 compute (the reference cannot run it in fp32 either)")
+    if weight_store is not None and dtype not in HALF_DTYPES:
+        raise ValueError("fp8 weight storage needs bf16 / fp16 compute (the reference cannot run it in fp32 either)")
     in_block = [False]
 
     def mat(name: str, w: Tensor):
@@ -313,4 +314,4 @@ def dac_arena_layout(cfg: DACConfig):
 
 
 def torch_dtype(name: str) -> torch.dtype:
-    return {"fp32": torch.float32, "bf16": torch.bfloat16, "f32": torch.float32}[name]
+    return {"fp32": torch.float32, "bf16": torch.bfloat16, "f32": torch.float32, "fp16": torch.float16, "f16": torch.float16}[name]

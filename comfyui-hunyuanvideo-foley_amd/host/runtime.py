@@ -80,7 +80,7 @@ class ProfEntryC(C.Structure):
 
 
 PROGRESS_CB = C.CFUNCTYPE(None, C.c_int32, C.c_int32, C.c_void_p)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _SIGNATURES = {
     "foley_abi_version": (C.c_uint32, []),
@@ -371,8 +371,8 @@ def op_gemm(A, W, bias=None, *, M=None, epilogue=EPI_STORE_F32, out0=None, out1=
     N, K = NK if NK is not None else W.shape      # NK: logical shape when W / A are row-padded storage (lda / ldw)
     d.A, d.W, d.bias = _ptr(A), _ptr(W), _ptr(bias) if bias is not None else None
     d.N, d.K = N, K
-    if W.dtype in (torch.float8_e4m3fn, torch.float8_e5m2):      # fp8 weight storage, bf16 activations
-        d.dtype, d.wfmt = DT_BF16, (1 if W.dtype == torch.float8_e4m3fn else 2)
+    if W.dtype in (torch.float8_e4m3fn, torch.float8_e5m2):      # fp8 weight storage, bf16 (or fp16) activations
+        d.dtype, d.wfmt = dt_of(A) if A.dtype == torch.float16 else DT_BF16, (1 if W.dtype == torch.float8_e4m3fn else 2)
     else:
         d.dtype = dt_of(W)
     d.epilogue, d.tile, d.ksplit = epilogue, tile, ksplit
@@ -425,11 +425,11 @@ def op_gemm(A, W, bias=None, *, M=None, epilogue=EPI_STORE_F32, out0=None, out1=
 
 
 def op_attention(q, k, v, outA, outB, split: int, kv_bdiv: int = 1):
-    """fp32 q/k/v [B,H,S,128], or bf16 q/k [B,H,S,128] with v transposed [B,H,128,pitch]."""
+    """fp32 q/k/v [B,H,S,128], or bf16 / fp16 q/k [B,H,S,128] with v transposed [B,H,128,pitch]."""
     lib = load_library()
     Bq, H, Sq, _ = q.shape
     Skv = k.shape[2]
-    vt_pitch = v.shape[3] if q.dtype == torch.bfloat16 else 0
+    vt_pitch = v.shape[3] if q.dtype in (torch.bfloat16, torch.float16) else 0
     _check(lib, lib.foley_op_attention(_ptr(q), _ptr(k), _ptr(v), dt_of(q), vt_pitch, Bq, H, Sq, Skv, kv_bdiv,
                                        _ptr(outA), _ptr(outB), split, dt_of(outB), _stream()), "foley_op_attention")
 

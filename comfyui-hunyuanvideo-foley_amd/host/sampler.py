@@ -31,8 +31,8 @@ class FoleyModel:
         self.dtype = compute_dtype
         self.device = torch.device(device)
         self.quantization = quantization
-        # fp8 weight-only storage stays fp8 in HBM (bf16 compute); `dit_state` then holds fp8-rounded values
-        store = packers.FP8_DTYPES.get(quantization) if compute_dtype == torch.bfloat16 else None
+        # fp8 weight-only storage stays fp8 in HBM (bf16 / fp16 compute); `dit_state` then holds fp8-rounded values
+        store = packers.FP8_DTYPES.get(quantization) if compute_dtype in packers.HALF_DTYPES else None
         packed = packers.pack_dit(dit_state, cfg, compute_dtype, weight_store=store)
         self.arena = packers.Arena.from_packed(packed, self.device)
         self._finish_init()
@@ -60,7 +60,7 @@ class FoleyModel:
         self.quantization = quantization
         self.arena = None
         self.ctx = FoleyContext(cfg, dac_cfg, compute_dtype, self.device)
-        fmt = {"fp8_e4m3fn": 1, "fp8_e5m2": 2}.get(quantization, 0) if compute_dtype == torch.bfloat16 else 0
+        fmt = {"fp8_e4m3fn": 1, "fp8_e5m2": 2}.get(quantization, 0) if compute_dtype in packers.HALF_DTYPES else 0
         self.ctx.load_reference_state([dit_state, dac_state], fmt)
         self.empty_clip_feat = dit_state["empty_clip_feat"].detach().to(self.device, torch.float32).reshape(1, -1)
         self.empty_sync_feat = dit_state["empty_sync_feat"].detach().to(self.device, torch.float32).reshape(1, -1)

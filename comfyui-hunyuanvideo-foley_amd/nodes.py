@@ -171,7 +171,7 @@ class HunyuanModelLoader:
             "required": {
                 "model_name": (_foley_files(),),
                 "precision": (["auto", "bf16", "fp16", "fp32"], {"default": "bf16", "tooltip": "Compute dtype of the GEMM operands (fp32 = parity mode on fp32 MFMA; auto = detect from checkpoint)"}),
-                "quantization": (["none", "fp8_e4m3fn", "fp8_e5m2", "auto"], {"default": "auto", "tooltip": "FP8 weight-only storage of the checkpoint (values are rounded through fp8 like the reference, compute stays bf16)"}),
+                "quantization": (["none", "fp8_e4m3fn", "fp8_e5m2", "auto"], {"default": "auto", "tooltip": "FP8 weight-only storage of the checkpoint (values are rounded through fp8 like the reference, compute stays bf16 / fp16)"}),
             },
         }
 
@@ -181,13 +181,15 @@ class HunyuanModelLoader:
 
     @staticmethod
     def pack_state_dict(state_dict, precision="bf16", quantization="auto", device=None, cfg=None, dac_cfg=None):
-        """state dict -> FoleyModel.  fp16 is served by the bf16 kernels (same MFMA rate, fp32 accumulate)."""
+        """state dict -> FoleyModel.  precision=fp16 (and `auto` on an fp16 checkpoint) computes in fp16 like the
+        reference does (parameters .to(float16), torch.autocast(float16): nodes.py:89-106, utils.py:229-234) - the
+        v_mfma_f32_32x32x16_f16 instantiation of the same kernels."""
         cfg = cfg or _cfg.load_yaml_config(os.path.join(_PKG_DIR, "configs", "hunyuanvideo-foley-xxl.yaml"))
-        dtype = {"bf16": torch.bfloat16, "fp16": torch.bfloat16, "fp32": torch.float32}.get(precision)
+        dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}.get(precision)
         detected = detect_ckpt_fp8(state_dict)
         if precision == "auto" or dtype is None:
             major = detect_ckpt_major_precision(state_dict)
-            dtype = torch.float32 if major == torch.float32 else torch.bfloat16
+            dtype = major       # the checkpoint's dominant dtype: fp32, bf16 or fp16 (utils.py:507-515)
         qmode = resolve_quantization(quantization, detected)
         param_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}.get(precision, dtype)
         sd = round_params(state_dict, param_dtype)

@@ -35,13 +35,14 @@
 extern "C" {
 #endif
 
-#define FOLEY_ABI_VERSION 6   /* 6: foley_rowbcast.Ls (mode 2: nearest-exact up-sampled operand); 5: reference-keyed loading (foley_weights_*, foley_load_tensor, foley_bcast_weights); 4: fp8 weight storage (dtype codes 3/4, foley_gemm_desc.ldw/.wfmt); 3: foley_profile_forward; 2: foley_gemm_desc gained partials / qkv / rstride; foley_op_ln_mod_pending, foley_dac_encode */
+#define FOLEY_ABI_VERSION 7   /* 7: FOLEY_DT_F16 as a compute dtype (foley_config.compute_dtype, op descriptors); 6: foley_rowbcast.Ls (mode 2: nearest-exact up-sampled operand); 5: reference-keyed loading (foley_weights_*, foley_load_tensor, foley_bcast_weights); 4: fp8 weight storage (dtype codes 3/4, foley_gemm_desc.ldw/.wfmt); 3: foley_profile_forward; 2: foley_gemm_desc gained partials / qkv / rstride; foley_op_ln_mod_pending, foley_dac_encode */
 
 enum foley_dtype {
   FOLEY_DT_F32 = 0, FOLEY_DT_BF16 = 1, FOLEY_DT_I32 = 2,
   FOLEY_DT_F8E4M3 = 3,  /* OCP e4m3fn, weight storage only (reference FP8WeightWrapper, utils.py:316-366: plain cast, no scales) */
   FOLEY_DT_F8E5M2 = 4,  /* OCP e5m2,   weight storage only */
-  FOLEY_DT_F16 = 5      /* accepted by foley_load_tensor as a CHECKPOINT dtype only */
+  FOLEY_DT_F16 = 5      /* IEEE fp16: a checkpoint dtype, and a compute dtype (the loader's precision=fp16, which the reference
+                           runs under torch.autocast(float16): nodes.py:89-106, utils.py:229-234) */
 };
 
 enum foley_status {
@@ -61,7 +62,7 @@ typedef struct foley_config {
   int32_t conv_hidden;   /* single-block ConvMLP hidden (mlp_layers.py:141-142)     */
   int32_t sync_hidden;   /* sync_in ConvMLP hidden                                 */
   int32_t cond_dim, clip_dim, sync_dim, latent_dim, time_freq_dim;
-  int32_t compute_dtype; /* FOLEY_DT_F32 (parity mode) or FOLEY_DT_BF16 (throughput) for DiT GEMM operands */
+  int32_t compute_dtype; /* FOLEY_DT_F32 (parity mode), FOLEY_DT_BF16 or FOLEY_DT_F16 (throughput) for DiT GEMM operands */
   int32_t dac_dim;       /* decoder width (2048)                                    */
   int32_t dac_n_rates;   /* 5                                                       */
   int32_t dac_rates[8];  /* 8,5,4,3,2                                               */

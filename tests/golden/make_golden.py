@@ -584,7 +584,57 @@ def g12():
     save("g12_bf16_ref", **out)
 
 
-ALL = {"g12": g12, "g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11}
+def g13():
+    """fp16 compute (the loader's `precision=fp16`, or `auto` on an fp16 checkpoint: nodes.py:89-106 loads the
+    parameters as float16 and utils.py:229-234 runs the model under torch.autocast(float16)), pinned to the
+    reference itself like g12 pins bf16: parameters `.to(float16)`, inputs in the parameter dtype, autocast fp16, on
+    this container's CPU - one tiny-config forward on g5's inputs and the 10-step CFG 4.5 Euler run (noise drawn in
+    fp16, utils.py:114-121), each next to the fp32 run on the same inputs."""
+    c = C.TINY
+    sd = synth.synth_dit_state_dict(c)
+    dsd = synth.synth_dac_state_dict(C.DAC_TINY)
+    out = {}
+    m32 = build_ref_dit(c, sd)
+    m16 = build_ref_dit(c, sd).to(torch.float16)
+    hf = lambda t: t.to(torch.float16)
+    g = torch.Generator().manual_seed(5)
+    La, Lv, Ls = C.lengths(1.0, c)
+    x = torch.randn(2, 128, La, generator=g)
+    t = torch.tensor([980.0, 980.0])
+    cond = torch.randn(2, 77, 768, generator=g)
+    clip = torch.randn(2, Lv, 768, generator=g)
+    sync = torch.randn(2, Ls, 768, generator=g)
+    with torch.inference_mode():
+        y32 = m32(x=x, t=t, cond=cond, clip_feat=clip, sync_feat=sync)["x"]
+        with torch.autocast("cpu", dtype=torch.float16):
+            y16 = m16(x=hf(x), t=t, cond=hf(cond), clip_feat=hf(clip), sync_feat=hf(sync))["x"]
+    print(f"    forward: reference fp16 vs its own fp32: rel {rel(y16.float(), y32):.3e}")
+    out["fwd_y32"], out["fwd_y16"] = y32, y16.float()
+    dac = build_ref_dac(C.DAC_TINY, dsd)
+    cnd = synth.synth_conditioning(c, 1.0, t2a=False, sd=sd)
+    gen = torch.Generator("cpu").manual_seed(1234)
+    noise16 = torch.randn((2, 128, 50), generator=gen, dtype=torch.float16)
+    orig_prep = NS.utils.prepare_latents_with_generator
+    for tag, m in (("f16", m16), ("f32", m32)):
+        if hasattr(m, "_text_len_fixed"):
+            del m._text_len_fixed
+        md = ModelDict(foley_model=m, dac_model=dac, device=torch.device("cpu"))
+        gen = torch.Generator("cpu").manual_seed(1234)
+        if tag == "f32":
+            NS.utils.prepare_latents_with_generator = lambda *a, **k: noise16.float().clone()
+        try:
+            with torch.inference_mode():
+                audio, lat = run_ref_sampler(md, c, cnd, 1.0, 4.5, 10, 2, "euler", gen)
+        finally:
+            NS.utils.prepare_latents_with_generator = orig_prep
+        out[f"cfg_{tag}_latents"], out[f"cfg_{tag}_wave_s5"] = lat, audio.float()[..., ::5]
+    out["cfg_noise_f16"] = noise16.float()
+    print(f"    10-step CFG on the same noise: reference fp16 vs fp32: latents rel {rel(out['cfg_f16_latents'], out['cfg_f32_latents']):.3e}, "
+          f"waveform rel {rel(out['cfg_f16_wave_s5'], out['cfg_f32_wave_s5']):.3e}")
+    save("g13_fp16_ref", **out)
+
+
+ALL = {"g13": g13, "g12": g12, "g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11}
 
 
 def main():

@@ -808,6 +808,56 @@ def test_bf16_mode_against_reference_bf16(dev):
     assert rel_err(y8, g12["c5_y16"]) > e8          # the fp8-rounded weights are really what runs
 
 
+def test_fp16_mode_against_reference_fp16(dev):
+    """precision=fp16 computes in fp16 (v_mfma_f32_32x32x16_f16 instantiation of every 16-bit kernel), pinned to the
+    REFERENCE's own fp16 execution (golden g13: parameters .to(float16), inputs in the parameter dtype,
+    torch.autocast(float16) - nodes.py:89-106, utils.py:229-234 - run on the build container's CPU).  Gates as for
+    bf16 (g12), against the reference's own fp16-vs-fp32 distance d0 on the same inputs: within 1.5 d0 of the
+    reference's fp16 output and within 1.5 d0 of its fp32 output.  d0 is ~8x smaller than bf16's (8.8e-4 forward,
+    1.2e-3 latents, 5.2e-3 waveform), so a run that silently took the bf16 kernels (d ~ 7e-3) fails these gates."""
+    from foley_amd import nodes
+    c = C.TINY
+    sd = synth.synth_dit_state_dict(c)
+    dsd = synth.synth_dac_state_dict(C.DAC_TINY)
+    g13, g12, g5 = golden("g13_fp16_ref"), golden("g12_bf16_ref"), golden("g5_dit_tiny")
+    model = nodes.HunyuanModelLoader.pack_state_dict(sd, "fp16", "none", device=dev, cfg=c, dac_cfg=C.DAC_TINY)
+    assert model.dtype == torch.float16
+    r16 = lambda t: t.to(torch.float16).float()
+    x, t, cond, clip, sync = (g5["a_" + k] for k in ("x", "t", "cond", "clip", "sync"))
+    y = _forward(model, r16(x), t, r16(cond), r16(clip), r16(sync))
+    assert torch.equal(g13["fwd_y32"], g12["fwd_y32"])                       # same inputs as the bf16 fixture
+    d0 = rel_err(g13["fwd_y16"], g13["fwd_y32"])
+    e16, e32 = rel_err(y, g13["fwd_y16"]), rel_err(y, g13["fwd_y32"])
+    print("forward: d0 %.2e, vs reference fp16 %.2e, vs reference fp32 %.2e" % (d0, e16, e32))
+    assert 5e-4 < d0 < 2e-3 and e16 < 1.5 * d0 and e32 < 1.5 * d0
+    dac = sampler.FoleyDAC(dsd, dev, C.DAC_TINY)
+    cnd = synth.synth_conditioning(c, 1.0, t2a=False, sd=sd)
+    gen = torch.Generator("cpu").manual_seed(1234)
+    audio, _sr, lat = sampler.denoise_process_with_generator(
+        {"siglip2_feat": cnd["clip"], "syncformer_feat": cnd["sync"]},
+        {"text_feat": cnd["text"], "uncond_text_feat": cnd["uncond_text"]}, 1.0, model, dac, 4.5, 10, 2, "euler",
+        generator=gen, return_latents=True)
+    gen = torch.Generator("cpu").manual_seed(1234)
+    assert torch.equal(sampler.draw_noise(2, 128, 50, torch.float16, gen).float(), g13["cfg_noise_f16"])
+    dl = rel_err(g13["cfg_f16_latents"], g13["cfg_f32_latents"])
+    dw = rel_err(g13["cfg_f16_wave_s5"], g13["cfg_f32_wave_s5"])
+    el16, el32 = rel_err(lat, g13["cfg_f16_latents"]), rel_err(lat, g13["cfg_f32_latents"])
+    ew16, ew32 = rel_err(audio[..., ::5], g13["cfg_f16_wave_s5"]), rel_err(audio[..., ::5], g13["cfg_f32_wave_s5"])
+    print("10-step CFG: latents d0 %.2e (ours vs ref-fp16 %.2e, vs ref-fp32 %.2e); waveform d0 %.2e (%.2e, %.2e)"
+          % (dl, el16, el32, dw, ew16, ew32))
+    assert el16 < 1.5 * dl and el32 < 1.5 * dl and ew16 < 1.5 * dw and ew32 < 1.5 * dw
+    # precision=auto on an fp16 checkpoint resolves to fp16 compute as well (utils.py:507-515)
+    sd16 = {k: v.to(torch.float16) for k, v in sd.items()}
+    m_auto = nodes.HunyuanModelLoader.pack_state_dict(sd16, "auto", "none", device=dev, cfg=c, dac_cfg=C.DAC_TINY)
+    assert m_auto.dtype == torch.float16
+    # fp8 weight storage under fp16 compute (quantization widget + precision=fp16): stays fp8 in the arena, widened to fp16
+    # in registers; equals the same model with the fp8-rounded weights stored as fp16
+    m8 = nodes.HunyuanModelLoader.pack_state_dict(sd, "fp16", "fp8_e4m3fn", device=dev, cfg=c, dac_cfg=C.DAC_TINY)
+    assert m8.dtype == torch.float16 and m8.arena.view("t0.a_qkv.w").dtype == torch.float8_e4m3fn
+    y8 = _forward(m8, r16(x), t, r16(cond), r16(clip), r16(sync))
+    assert 1e-3 < rel_err(y8, y) < 0.2
+
+
 def _legacy_wn(dsd):
     """The same DAC checkpoint spelled with legacy weight_g / weight_v keys, and fully folded."""
     g = {k.replace(".parametrizations.weight.original0", ".weight_g").replace(".parametrizations.weight.original1", ".weight_v"): v

@@ -17,6 +17,7 @@ pytestmark = pytest.mark.gpu
 
 F32_TOL = 2e-6
 BF16_TOL = 6e-3
+F16_TOL = 8e-4      # fp16 operands (precision=fp16): three more mantissa bits than bf16
 
 
 def _g(seed):
@@ -28,7 +29,7 @@ def _rand(shape, seed, scale=1.0):
 
 
 def _tol(dtype):
-    return F32_TOL if dtype == torch.float32 else BF16_TOL
+    return {torch.float32: F32_TOL, torch.bfloat16: BF16_TOL, torch.float16: F16_TOL}[dtype]
 
 
 def _q(t, dtype):   # round a CPU reference operand through the compute dtype
@@ -36,7 +37,7 @@ def _q(t, dtype):   # round a CPU reference operand through the compute dtype
 
 
 # ----------------------------------------------------------------------------- GEMM: plain linear
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K,tile", [
     (500, 1536, 1536, 0), (500, 1536, 1536, 1), (500, 1536, 1536, 2), (500, 1536, 1536, 3),
     (37, 200, 256, 0), (130, 128, 128, 0), (10, 13824, 1536, 0), (4000, 64, 128, 4), (77, 3072, 768, 0),
@@ -58,7 +59,7 @@ def test_gemm_linear(dev, dtype, M, N, K, tile):
     assert rel_err(out, ref) < _tol(dtype)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("tile", [0, 3, 5, 6])
 def test_gemm_transpose_detecting(dev, dtype, tile):
     """A = I with an asymmetric W: catches a swapped C/D row/column mapping (and, for the
@@ -71,7 +72,7 @@ def test_gemm_transpose_detecting(dev, dtype, tile):
     assert torch.equal(out.cpu(), W.t().contiguous())
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("tile", [0, 15, 19, 25, 29])
 @pytest.mark.parametrize("epi", ["store_t", "silu", "gelu", "silugate", "gate_res_vec", "gate_res_tok", "addend"])
 def test_gemm_epilogues(dev, dtype, epi, tile):
@@ -87,7 +88,7 @@ def test_gemm_epilogues(dev, dtype, epi, tile):
         code = {"store_t": rt.EPI_STORE_T, "silu": rt.EPI_SILU_T, "gelu": rt.EPI_GELU_T}[epi]
         rt.op_gemm(Ad, Wd, bd, out0=out, epilogue=code, tile=tile)
         ref = {"store_t": y, "silu": F.silu(y), "gelu": F.gelu(y, approximate="tanh")}[epi]
-        assert rel_err(out.float(), ref) < max(_tol(dtype), 4e-3 if dtype == torch.bfloat16 else 0)
+        assert rel_err(out.float(), ref) < _tol(dtype)
     elif epi == "silugate":
         w1, w3 = W[: N // 2], W[N // 2:]
         Wp = packers.interleave_gate(w1, w3)
@@ -118,7 +119,8 @@ def test_gemm_epilogues(dev, dtype, epi, tile):
 @pytest.mark.parametrize("fmt", [torch.float8_e4m3fn, torch.float8_e5m2])
 @pytest.mark.parametrize("tile", [15, 19, 21, 23])
 @pytest.mark.parametrize("case", ["linear", "ragged", "conv3", "gelu", "silugate", "gate_res_split", "qkv_split"])
-def test_gemm_fp8_weight_storage(dev, fmt, tile, case):
+@pytest.mark.parametrize("act", [torch.bfloat16, torch.float16])
+def test_gemm_fp8_weight_storage(dev, fmt, tile, case, act):
     """In-kernel fp8 weight storage (reference FP8WeightWrapper, utils.py:316-366: weight kept in fp8, plain
     cast, `w.to(x.dtype)` per call): the loaders move 64-byte fp8 K-slices, the consumers widen to bf16 in
     registers.  Widening is exact and both kernels use the same K order, so the result must be BIT-IDENTICAL
@@ -129,9 +131,9 @@ def test_gemm_fp8_weight_storage(dev, fmt, tile, case):
     M, N, K = {"linear": (500, 1536, 1536), "ragged": (257, 1408, 320), "conv3": (500, 512, 3 * 256), "gelu": (300, 512, 256),
                "silugate": (300, 512, 256), "gate_res_split": (500, 1536, 3 * 512), "qkv_split": (500, 3 * 2 * 128, 256)}[case]
     conv = (250, K // 3, 3, 1) if case in ("conv3", "gate_res_split") else None
-    A = _rand((M, K // 3 if conv else K), 21).to(dev, torch.bfloat16)
+    A = _rand((M, K // 3 if conv else K), 21).to(dev, act)
     W8 = _rand((N, K), 22, 1 / math.sqrt(K)).to(fmt)
-    Wq = W8.to(torch.bfloat16)                       # exact: every fp8 value is a bf16 value
+    Wq = W8.to(act)                       # exact: every fp8 value is a bf16 value and an fp16 value
     assert torch.equal(Wq.float(), W8.float())
     b = _rand((N,), 23, 0.1).to(dev)
     W8d, Wqd = W8.to(dev), Wq.to(dev)
@@ -143,11 +145,11 @@ def test_gemm_fp8_weight_storage(dev, fmt, tile, case):
             rt.op_gemm(A, W, b, out0=out, tile=tile, **kw)
             return out
         if case == "gelu":
-            out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            out = torch.empty(M, N, device=dev, dtype=act)
             rt.op_gemm(A, W, b, out0=out, epilogue=rt.EPI_GELU_T, tile=tile)
             return out
         if case == "silugate":
-            out = torch.empty(M, N // 2, device=dev, dtype=torch.bfloat16)
+            out = torch.empty(M, N // 2, device=dev, dtype=act)
             rt.op_gemm(A, W, None, out0=out, epilogue=rt.EPI_SILUGATE_T, tile=tile)
             return out
         if case == "gate_res_split":
@@ -158,8 +160,8 @@ def test_gemm_fp8_weight_storage(dev, fmt, tile, case):
                             partials=slabs, **kw)
             return torch.cat([x, slabs[:ks].sum(0)])
         H, L = 2, 250
-        dq, dk = (torch.zeros(M // L, H, L, 128, device=dev, dtype=torch.bfloat16) for _ in range(2))
-        dvt = torch.zeros(M // L, H, 128, 256, device=dev, dtype=torch.bfloat16)
+        dq, dk = (torch.zeros(M // L, H, L, 128, device=dev, dtype=act) for _ in range(2))
+        dvt = torch.zeros(M // L, H, 128, 256, device=dev, dtype=act)
         cos, sin = (t.to(dev) for t in tables.rope_table(L + 1))
         gq = (1 + 0.1 * _rand((128,), 26)).to(dev)
         pos = torch.arange(L, dtype=torch.int32, device=dev)
@@ -170,7 +172,7 @@ def test_gemm_fp8_weight_storage(dev, fmt, tile, case):
     y8, yq = run(W8d), run(Wqd)
     assert torch.isfinite(y8.float()).all() and torch.equal(y8, yq)
     if case in ("linear", "ragged"):
-        assert rel_err(y8, F.linear(A.float().cpu(), W8.float(), b.cpu())) < BF16_TOL
+        assert rel_err(y8, F.linear(A.float().cpu(), W8.float(), b.cpu())) < _tol(act)
 
 
 def test_gemm_fp8_rejects_unsupported(dev):
@@ -255,7 +257,7 @@ def test_gemm_deferred_split_k(dev, ksplit, conv, tok_gate):
 
 
 # ----------------------------------------------------------------------------- GEMM: conv addressing
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("tile", [0, 3, 5, 6, 11, 13, 15, 19, 21, 22, 23])
 @pytest.mark.parametrize("B,L,Cin,Cout", [(2, 50, 256, 384), (3, 7, 128, 64), (1, 250, 1536, 256), (5, 33, 128, 200), (2, 250, 64, 128),
                                           (4, 129, 192, 320)])
@@ -272,13 +274,13 @@ def test_conv3_channels_last(dev, dtype, tile, B, L, Cin, Cout):
     assert rel_err(out, ref) < _tol(dtype)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("stride,B,Tin,Cin,Cout", [(2, 2, 60, 64, 128), (3, 1, 51, 32, 64), (5, 2, 40, 128, 96), (8, 1, 64, 64, 128)])
 def test_strided_conv_as_gemm(dev, dtype, stride, B, Tin, Cin, Cout):
     """DAC EncoderBlock down-sampling conv (dac.py:55-61): k = 2s, stride s, pad ceil(s/2), as a GEMM
     whose virtual rows advance s source rows (zero padding through the operand range check)."""
-    if dtype == torch.bfloat16 and Cin % 64:
-        pytest.skip("bf16 K-slices are 64 channels wide")
+    if dtype != torch.float32 and Cin % 64:
+        pytest.skip("16-bit K-slices are 64 channels wide")
     x, w, b = _rand((B, Cin, Tin), 40), _rand((Cout, Cin, 2 * stride), 41, 1 / math.sqrt(2 * stride * Cin)), _rand((Cout,), 42, 0.1)
     ref = F.conv1d(_q(x, dtype), _q(w, dtype), b, stride=stride, padding=math.ceil(stride / 2)).transpose(1, 2)
     Tout = Tin // stride
@@ -330,7 +332,7 @@ def test_dac_conv_transpose(dev, s):
 
 
 # ----------------------------------------------------------------------------- attention
-@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,H,Sq,Skv,split,kv_bdiv", [
     (2, 2, 58, 58, 8, 1), (4, 3, 290, 77, 40, 2), (2, 12, 250, 250, 0, 1), (1, 1, 33, 31, 5, 1)])
 def test_attention(dev, out_dtype, B, H, Sq, Skv, split, kv_bdiv):
@@ -340,7 +342,7 @@ def test_attention(dev, out_dtype, B, H, Sq, Skv, split, kv_bdiv):
     oa = torch.full((B, max(split, 1), H * 128), float("nan"), device=dev, dtype=out_dtype)
     ob = torch.full((B, Sq - split, H * 128), float("nan"), device=dev, dtype=out_dtype)
     rt.op_attention(q.to(dev), k.to(dev), v.to(dev), oa, ob, split, kv_bdiv)
-    tol = 3e-6 if out_dtype == torch.float32 else 4e-3
+    tol = {torch.float32: 3e-6, torch.bfloat16: 4e-3, torch.float16: 5e-4}[out_dtype]
     if split:
         assert rel_err(oa.float(), ref[:, :split]) < tol
     assert rel_err(ob.float(), ref[:, split:]) < tol
@@ -353,22 +355,23 @@ def test_attention(dev, out_dtype, B, H, Sq, Skv, split, kv_bdiv):
     # config C5 (30 s, CFG pair): the wide kernel at its real key-tile counts - 55 / 47 tiles of online-softmax
     # rescaling with a ragged last tile (1740 = 54*32 + 12, 1500 = 46*32 + 28), and the 77 cached text keys
     (2, 12, 1740, 1740, 240, 1), (2, 12, 1500, 1500, 0, 1), (2, 12, 1740, 77, 240, 1)])
-def test_attention_bf16(dev, B, H, Sq, Skv, split, kv_bdiv):
+@pytest.mark.parametrize("half", [torch.bfloat16, torch.float16])
+def test_attention_bf16(dev, B, H, Sq, Skv, split, kv_bdiv, half):
     """Throughput kernels: bf16 Q/K, transposed bf16 V with a padded pitch; 4-wave key split for
     small grids, 128-query workgroups with LDS-staged key tiles for large ones."""
     q, k, v = _rand((B, H, Sq, 128), 30), _rand((B // kv_bdiv, H, Skv, 128), 31), _rand((B // kv_bdiv, H, Skv, 128), 32)
-    qb, kb, vb = (t.to(torch.bfloat16) for t in (q, k, v))
+    qb, kb, vb = (t.to(half) for t in (q, k, v))
     ke, ve = kb.float().repeat_interleave(kv_bdiv, 0), vb.float().repeat_interleave(kv_bdiv, 0)
     ref = O.sdpa(qb.float(), ke, ve).transpose(1, 2).reshape(B, Sq, H * 128)
     pitch = (Skv + 31) // 32 * 32
-    vt = torch.full((B // kv_bdiv, H, 128, pitch), 7.0, dtype=torch.bfloat16)       # finite garbage in the pad
+    vt = torch.full((B // kv_bdiv, H, 128, pitch), 7.0, dtype=half)       # finite garbage in the pad
     vt[..., :Skv] = vb.transpose(2, 3)
-    oa = torch.full((B, max(split, 1), H * 128), float("nan"), device=dev, dtype=torch.bfloat16)
-    ob = torch.full((B, Sq - split, H * 128), float("nan"), device=dev, dtype=torch.bfloat16)
+    oa = torch.full((B, max(split, 1), H * 128), float("nan"), device=dev, dtype=half)
+    ob = torch.full((B, Sq - split, H * 128), float("nan"), device=dev, dtype=half)
     rt.op_attention(qb.to(dev), kb.to(dev), vt.to(dev), oa, ob, split, kv_bdiv)
     if split:
-        assert rel_err(oa.float(), ref[:, :split]) < 1e-2
-    assert rel_err(ob.float(), ref[:, split:]) < 1e-2
+        assert rel_err(oa.float(), ref[:, :split]) < (1e-2 if half == torch.bfloat16 else 2e-3)
+    assert rel_err(ob.float(), ref[:, split:]) < (1e-2 if half == torch.bfloat16 else 2e-3)
 
 
 def test_attention_bf16_spiky(dev):
@@ -396,13 +399,13 @@ def test_attention_spiky_scores(dev):
 
 
 # ----------------------------------------------------------------------------- row kernels
-@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("D,eps", [(1536, 1e-6), (256, 1e-5), (1408, 1e-6)])
 def test_ln_mod(dev, out_dtype, D, eps):
     clips, L = 2, 13
     M = 2 * clips * L
     x = _rand((M, D), 40) * 3 + 0.5
-    tol = 2e-6 if out_dtype == torch.float32 else 4e-3
+    tol = {torch.float32: 2e-6, torch.bfloat16: 4e-3, torch.float16: 5e-4}[out_dtype]
     # plain LayerNorm
     out = torch.empty(M, D, device=dev, dtype=out_dtype)
     rt.op_ln_mod(x.to(dev), eps, None, None, out)
@@ -522,7 +525,7 @@ def test_qkv_split_bf16_transposed_v(dev):
     assert float(dv[..., :Lv].abs().max()) == 0.0 and float(dv[..., S:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,L,H,Lv,tile", [(2, 11, 3, 4, 0), (2, 250, 2, 40, 0), (3, 70, 2, 3, 5), (2, 250, 1, 40, 9),
                                            (2, 250, 2, 40, 15), (3, 70, 1, 3, 19), (2, 250, 2, 40, 25), (3, 70, 1, 3, 29),
                                            (4, 37, 2, 8, 2), (2, 250, 2, 40, 27), (3, 70, 1, 3, 27), (2, 250, 2, 40, 26), (3, 70, 1, 3, 26), (2, 250, 2, 40, 28), (3, 70, 1, 3, 28)])
@@ -543,13 +546,13 @@ def test_gemm_fused_head_split(dev, dtype, B, L, H, Lv, tile):
     c2, s2 = cos[pos.long()].repeat_interleave(2, 1), sin[pos.long()].repeat_interleave(2, 1)
     rq = O.apply_rope(O.rms_norm(q, gq, 1e-6), c2, s2).transpose(1, 2)
     rk = O.apply_rope(O.rms_norm(k, gk, 1e-6), c2, s2).transpose(1, 2)
-    bf = dtype == torch.bfloat16
+    bf = dtype != torch.float32          # 16-bit operands: V leaves transposed
     dq, dk = (torch.zeros(B, H, S, 128, device=dev, dtype=dtype) for _ in range(2))
     dv = torch.zeros((B, H, 128, pitch) if bf else (B, H, S, 128), device=dev, dtype=dtype)
     desc = rt.qkv_split_desc(L, H, [gq.to(dev), gk.to(dev), None], [pos.to(dev), pos.to(dev), None], [dq, dk, dv], S, Lv,
                              1e-6, cos.to(dev), sin.to(dev), vt_pitch=pitch if bf else 0)
     rt.op_gemm(x.to(dev, dtype), w.to(dev, dtype), b.to(dev), epilogue=rt.EPI_QKV_SPLIT, qkv=desc, tile=tile)
-    tol = 4e-3 if bf else 1e-5
+    tol = {torch.float32: 1e-5, torch.bfloat16: 4e-3, torch.float16: 6e-4}[dtype]
     assert rel_err(dq[:, :, Lv:].float(), rq) < tol and rel_err(dk[:, :, Lv:].float(), rk) < tol
     assert float(dq[:, :, :Lv].float().abs().max()) == 0.0
     if bf:
