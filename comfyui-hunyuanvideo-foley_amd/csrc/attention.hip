@@ -14,7 +14,8 @@
 
 namespace {
 
-constexpr int HD = 128;
+// head dim: 128 (the Foley DiT) or 64 (the conditioning encoders: Synchformer / SigLIP2 ViT-B, host/encoders.py) - a template
+// parameter of the fp32 kernel and of the 16-bit wide kernel
 
 // 1-D grid -> (query tile, head, batch) with a bijective XCD-aware remap: workgroup id i runs on XCD
 // i % 8, so ids are regrouped such that all query tiles of one (batch, head) - which read the same
@@ -54,7 +55,7 @@ template <> struct Pack4Out<f16_t> {
   }
 };
 
-template <typename OutT>
+template <typename OutT, int HD>
 __global__ __launch_bounds__(64) void attn_kernel(const AttnArgs a) {
   const int lane = threadIdx.x;
   const int j = lane & 31, kh = lane >> 5;
@@ -64,23 +65,25 @@ __global__ __launch_bounds__(64) void attn_kernel(const AttnArgs a) {
   const float* __restrict__ Q = (const float*)a.q + ((long)(b * a.H + h) * a.Sq) * HD;
   const float* __restrict__ K = (const float*)a.k + ((long)(bk * a.H + h) * a.Skv) * HD;
   const float* __restrict__ V = (const float*)a.v + ((long)(bk * a.H + h) * a.Skv) * HD;
-  const float scale = 0.08838834764831845f;  // 1/sqrt(128)
+  const float scale = HD == 128 ? 0.08838834764831845f : 0.125f;  // 1/sqrt(HD)
 
-  // B operand of S^T = K Q^T: lane (j, kh) holds Q[q0 + j][kh*64 .. kh*64+63]
-  float qr[64];
+  // B operand of S^T = K Q^T: lane (j, kh) holds Q[q0 + j][kh*HD/2 .. +HD/2-1]
+  constexpr int HH = HD / 2, NC = HD / 8;   // floats / float4 chunks of a half head
+  float qr[HH];
   {
     const int qrow = min(q0 + j, a.Sq - 1);
-    const f32x4* p = (const f32x4*)(Q + (long)qrow * HD + kh * 64);
+    const f32x4* p = (const f32x4*)(Q + (long)qrow * HD + kh * HH);
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
+    for (int c = 0; c < NC; ++c) {
       const f32x4 v = p[c];
       qr[c * 4 + 0] = v[0]; qr[c * 4 + 1] = v[1]; qr[c * 4 + 2] = v[2]; qr[c * 4 + 3] = v[3];
     }
   }
 
-  f32x16 o[4];
+  constexpr int ND = HD / 32;   // 32-wide output fragments
+  f32x16 o[ND];
 #pragma unroll
-  for (int d = 0; d < 4; ++d)
+  for (int d = 0; d < ND; ++d)
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
@@ -92,9 +95,9 @@ __global__ __launch_bounds__(64) void attn_kernel(const AttnArgs a) {
     for (int e = 0; e < 16; ++e) s[e] = 0.f;
     {
       const int krow = min(kt + j, a.Skv - 1);
-      const f32x4* p = (const f32x4*)(K + (long)krow * HD + kh * 64);
+      const f32x4* p = (const f32x4*)(K + (long)krow * HD + kh * HH);
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
+      for (int c = 0; c < NC; ++c) {
         const f32x4 v = p[c];
         s = __builtin_amdgcn_mfma_f32_32x32x2f32(v[0], qr[c * 4 + 0], s, 0, 0, 0);
         s = __builtin_amdgcn_mfma_f32_32x32x2f32(v[1], qr[c * 4 + 1], s, 0, 0, 0);
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(64) void attn_kernel(const AttnArgs a) {
     l_run = l_run * alpha + ps;
     m_run = m_new;
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
+    for (int d = 0; d < ND; ++d)
 #pragma unroll
       for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
     // O^T[d][q] += sum_key V[key][d] * P[q][key]: A operand lane (i = j, kh) = V[kt + r(t)][d0 + i],
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(64) void attn_kernel(const AttnArgs a) {
       const int vrow = min(kt + (t & 3) + 8 * (t >> 2) + 4 * kh, a.Skv - 1);
       const float* vp = V + (long)vrow * HD + j;
 #pragma unroll
-      for (int d = 0; d < 4; ++d)
+      for (int d = 0; d < ND; ++d)
         o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[d * 32], s[t], o[d], 0, 0, 0);
     }
   }
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(64) void attn_kernel(const AttnArgs a) {
   else dst = (OutT*)a.outB + ((long)b * (a.Sq - a.split) + (tok - a.split)) * (a.H * HD);
   dst += h * HD;
 #pragma unroll
-  for (int d = 0; d < 4; ++d)
+  for (int d = 0; d < ND; ++d)
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const int c = d * 32 + 8 * g4 + 4 * kh;
@@ -166,6 +169,7 @@ __global__ __launch_bounds__(64) void attn_kernel(const AttnArgs a) {
 // key-contiguous B operand of the second MFMA, and V^T rows are plain 16-byte loads.
 template <typename T, typename OutT>
 __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
+  constexpr int HD = 128;
   __shared__ float sO[4][3][16][64];  // partial O of the d-fragments a wave does not finalise itself
   __shared__ float sM[4][32], sL[4][32];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -357,10 +361,12 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
 // the operands are read from L2 once per 128 queries instead of once per 32 (the narrow kernel above
 // re-reads them for each of its 32-query workgroups: ~10x at S = 290).  No cross-wave merge.
 // LDS rows are padded (K: 272 B, V^T: 80 B) so the 16-lane groups of ds_read_b128 hit distinct banks.
-template <typename T, typename OutT>
+template <typename T, typename OutT, int HD>
 __global__ __launch_bounds__(256) void attn_bf16_wide_kernel(const AttnArgs a) {
-  constexpr int KP = 272, VP = 80;                       // LDS row pitches in bytes
-  constexpr int STG = 32 * KP + 128 * VP;                // one stage: K tile + V^T tile
+  constexpr int KP = 2 * HD + 16, VP = 80;               // LDS row pitches in bytes
+  constexpr int STG = 32 * KP + HD * VP;                 // one stage: K tile + V^T tile
+  constexpr int NS = HD / 16, ND = HD / 32;              // k-steps of Q K^T, 32-wide output fragments
+  constexpr int CK = HD / 8, NP = HD / 64;               // 16-byte chunks per K row, staging pieces per thread and tile
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STG];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int j = lane & 31, kh = lane >> 5;
@@ -371,39 +377,39 @@ __global__ __launch_bounds__(256) void attn_bf16_wide_kernel(const AttnArgs a) {
   const T* __restrict__ Q = (const T*)a.q + ((long)(b * a.H + h) * a.Sq) * HD;
   const T* __restrict__ K = (const T*)a.k + ((long)(bk * a.H + h) * a.Skv) * HD;
   const T* __restrict__ VT = (const T*)a.v + ((long)(bk * a.H + h) * HD) * a.vt_pitch;
-  const float scale2 = 0.08838834764831845f * 1.4426950408889634f;   // log2(e) / sqrt(128)
+  const float scale2 = (HD == 128 ? 0.08838834764831845f : 0.125f) * 1.4426950408889634f;   // log2(e) / sqrt(HD)
 
-  bf16x8 qf[8];
+  bf16x8 qf[NS];
   {
     const T* p = Q + (long)min(q0 + j, a.Sq - 1) * HD + 8 * kh;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) qf[s] = *(const bf16x8*)(p + 16 * s);
+    for (int s = 0; s < NS; ++s) qf[s] = *(const bf16x8*)(p + 16 * s);
   }
-  f32x16 o[4];
+  f32x16 o[ND];
 #pragma unroll
-  for (int d = 0; d < 4; ++d)
+  for (int d = 0; d < ND; ++d)
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  // staging: 512 + 512 pieces of 16 B per tile, 2 + 2 per thread
-  const int k_row[2] = {tid >> 4, (tid >> 4) + 16}, k_col = tid & 15;   // K tile: 32 rows x 16 chunks
-  const int v_row[2] = {tid >> 2, (tid >> 2) + 64}, v_col = tid & 3;    // V^T tile: 128 rows x 4 chunks
-  u32x4 rk[2], rv[2];
+  // staging: 4*HD + 4*HD pieces of 16 B per tile, NP + NP per thread
+  const int k_row0 = tid / CK, k_col = tid % CK;       // K tile: 32 rows x CK chunks, 256 / CK rows per pass
+  const int v_row0 = tid >> 2, v_col = tid & 3;        // V^T tile: HD rows x 4 chunks, 64 rows per pass
+  u32x4 rk[NP], rv[NP];
   auto gload = [&](int t) {
     const int kt = t * 32;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      rk[i] = *(const u32x4*)(K + (long)min(kt + k_row[i], a.Skv - 1) * HD + k_col * 8);
-      rv[i] = *(const u32x4*)(VT + (long)v_row[i] * a.vt_pitch + kt + v_col * 8);
+    for (int i = 0; i < NP; ++i) {
+      rk[i] = *(const u32x4*)(K + (long)min(kt + k_row0 + i * (256 / CK), a.Skv - 1) * HD + k_col * 8);
+      rv[i] = *(const u32x4*)(VT + (long)(v_row0 + i * 64) * a.vt_pitch + kt + v_col * 8);
     }
   };
   auto lstore = [&](int stage) {
     unsigned char* base = lds + stage * STG;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *(u32x4*)(base + k_row[i] * KP + k_col * 16) = rk[i];
-      *(u32x4*)(base + 32 * KP + v_row[i] * VP + v_col * 16) = rv[i];
+    for (int i = 0; i < NP; ++i) {
+      *(u32x4*)(base + (k_row0 + i * (256 / CK)) * KP + k_col * 16) = rk[i];
+      *(u32x4*)(base + 32 * KP + (v_row0 + i * 64) * VP + v_col * 16) = rv[i];
     }
   };
   const int nt = (a.Skv + 31) >> 5;
@@ -423,7 +429,7 @@ __global__ __launch_bounds__(256) void attn_bf16_wide_kernel(const AttnArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) s[e] = 0.f;
 #pragma unroll
-    for (int st = 0; st < 8; ++st)
+    for (int st = 0; st < NS; ++st)
       s = mfma16<T>(*(const bf16x8*)(Ks + pi * KP + (16 * st + 8 * kh) * 2), qf[st], s);
     // s[e] = score(key kt + 16*kh + e, query q0 + j), kept in the log2 domain (scale2 = log2(e)/sqrt(128)):
     // the exponentials are single v_exp_f32 instructions
@@ -452,7 +458,7 @@ __global__ __launch_bounds__(256) void attn_bf16_wide_kernel(const AttnArgs a) {
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // exp2(-inf) = 0 on the first tile
       l_run *= alpha;
 #pragma unroll
-      for (int d = 0; d < 4; ++d)
+      for (int d = 0; d < ND; ++d)
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
     }
@@ -461,7 +467,7 @@ __global__ __launch_bounds__(256) void attn_bf16_wide_kernel(const AttnArgs a) {
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int d = 0; d < 4; ++d)
+      for (int d = 0; d < ND; ++d)
         o[d] = mfma16<T>(*(const bf16x8*)(Vs + (d * 32 + j) * VP + (16 * kh + 8 * u) * 2), pb[u], o[d]);
     const long long cb = acct ? (long long)__builtin_readcyclecounter() : 0;
     if (t + 1 < nt) {
@@ -490,7 +496,7 @@ __global__ __launch_bounds__(256) void attn_bf16_wide_kernel(const AttnArgs a) {
   dst += h * HD;
   // lane (j, kh) holds dims d*32 + 8*g4 + 4*kh + {0..3} of query j: 4 consecutive outputs per store
 #pragma unroll
-  for (int d = 0; d < 4; ++d)
+  for (int d = 0; d < ND; ++d)
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const f32x4 v = {o[d][g4 * 4 + 0] * inv, o[d][g4 * 4 + 1] * inv, o[d][g4 * 4 + 2] * inv, o[d][g4 * 4 + 3] * inv};
@@ -510,20 +516,24 @@ int launch_attention(const AttnArgs& a_in, int out_dtype, hipStream_t st) {
   a.no_preload = no_preload;
   a.dbg = g_attn_dbg;
   if (a.Sq <= 0 || a.Skv <= 0) return foley_set_err("attention: empty sequence", __FILE__, __LINE__);
+  const int hd = a.head_dim > 0 ? a.head_dim : 128;
+  if (hd != 128 && hd != 64) return foley_set_err("attention: head_dim must be 128 or 64", __FILE__, __LINE__);
   dim3 grid((a.Sq + 31) / 32, a.H, a.Bq), block(64);
-  const dim3 grid1(grid.x * grid.y * grid.z);   // bf16 kernels: 1-D grid, XCD-aware remap inside
+  const dim3 grid1(grid.x * grid.y * grid.z);   // 16-bit kernels: 1-D grid, XCD-aware remap inside
   if (foley_is_half(a.in_dtype)) {
     if (a.vt_pitch < ((a.Skv + 31) & ~31) || (a.vt_pitch & 7))
       return foley_set_err("attention: V^T pitch must cover Skv rounded up to 32 (multiple of 8)", __FILE__, __LINE__);
     if (out_dtype != a.in_dtype && out_dtype != FOLEY_F32)
       return foley_set_err("attention: 16-bit operands produce the same type or fp32", __FILE__, __LINE__);
-    // enough 128-query workgroups to cover the chip => the wide kernel (operands read once per 128 queries)
+    // enough 128-query workgroups to cover the chip => the wide kernel (operands read once per 128 queries); head dim 64
+    // (the conditioning encoders) exists in the wide form only
     const dim3 gw(((a.Sq + 127) / 128) * a.H * a.Bq);
-    const bool wide = (long)gw.x >= 256, h16 = a.in_dtype == FOLEY_F16, o32 = out_dtype == FOLEY_F32;
-#define FOLEY_ATTN16(T, O)                                                                 \
-    do {                                                                                     \
-      if (wide) FOLEY_LAUNCH((attn_bf16_wide_kernel<T, O>), gw, dim3(256), 0, st, a);         \
-      else FOLEY_LAUNCH((attn_bf16_kernel<T, O>), grid1, dim3(256), 0, st, a);                \
+    const bool wide = (long)gw.x >= 256 || hd == 64, h16 = a.in_dtype == FOLEY_F16, o32 = out_dtype == FOLEY_F32;
+#define FOLEY_ATTN16(T, O)                                                                         \
+    do {                                                                                             \
+      if (wide && hd == 64) FOLEY_LAUNCH((attn_bf16_wide_kernel<T, O, 64>), gw, dim3(256), 0, st, a);  \
+      else if (wide) FOLEY_LAUNCH((attn_bf16_wide_kernel<T, O, 128>), gw, dim3(256), 0, st, a);        \
+      else FOLEY_LAUNCH((attn_bf16_kernel<T, O>), grid1, dim3(256), 0, st, a);                         \
     } while (0)
     if (h16) { if (o32) FOLEY_ATTN16(f16_t, float); else FOLEY_ATTN16(f16_t, f16_t); }
     else { if (o32) FOLEY_ATTN16(bf16_t, float); else FOLEY_ATTN16(bf16_t, bf16_t); }
@@ -532,10 +542,16 @@ int launch_attention(const AttnArgs& a_in, int out_dtype, hipStream_t st) {
     if (e2 != hipSuccess) return foley_set_err(hipGetErrorString(e2), __FILE__, __LINE__);
     return 0;
   }
-  if (out_dtype == FOLEY_F32) FOLEY_LAUNCH(attn_kernel<float>, grid, block, 0, st, a);
-  else if (out_dtype == FOLEY_BF16) FOLEY_LAUNCH(attn_kernel<bf16_t>, grid, block, 0, st, a);
-  else if (out_dtype == FOLEY_F16) FOLEY_LAUNCH(attn_kernel<f16_t>, grid, block, 0, st, a);
+#define FOLEY_ATTN32(O)                                                          \
+  do {                                                                           \
+    if (hd == 64) FOLEY_LAUNCH((attn_kernel<O, 64>), grid, block, 0, st, a);     \
+    else FOLEY_LAUNCH((attn_kernel<O, 128>), grid, block, 0, st, a);             \
+  } while (0)
+  if (out_dtype == FOLEY_F32) FOLEY_ATTN32(float);
+  else if (out_dtype == FOLEY_BF16) FOLEY_ATTN32(bf16_t);
+  else if (out_dtype == FOLEY_F16) FOLEY_ATTN32(f16_t);
   else return foley_set_err("attention: bad output dtype", __FILE__, __LINE__);
+#undef FOLEY_ATTN32
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);
   return 0;

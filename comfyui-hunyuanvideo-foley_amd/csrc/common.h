@@ -94,6 +94,8 @@ __device__ __forceinline__ float gelu_tanh_fast(float x) {
   return 0.5f * x * (1.0f + t);
 }
 template <typename OutT> __device__ __forceinline__ float silu_o(float x) { return sizeof(OutT) == 2 ? silu_fast(x) : silu_f(x); }
+// exact GELU: 0.5 x (1 + erf(x / sqrt(2)))  (torch nn.GELU() default)
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 template <typename OutT> __device__ __forceinline__ float gelu_o(float x) { return sizeof(OutT) == 2 ? gelu_tanh_fast(x) : gelu_tanh_f(x); }
 
 // DAC snake: x + (alpha + 1e-9)^-1 * sin(alpha x)^2

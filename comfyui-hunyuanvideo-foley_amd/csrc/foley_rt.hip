@@ -1267,6 +1267,7 @@ extern "C" int foley_op_gemm(const foley_gemm_desc* d, void* stream) {
   g.rstride = d->rstride;
   g.ldw = d->ldw;
   g.wfmt = d->wfmt;
+  g.gelu_erf = d->gelu_erf;
   if (d->partials) {
     if (d->partial_slabs < 1) return FAIL(FOLEY_ERR_INVALID, "partials need partial_slabs >= 1");
     g.partials = d->partials; g.partial_stride = (long)d->M * d->N; g.partial_cap = d->partial_slabs;
@@ -1288,11 +1289,17 @@ extern "C" int foley_op_gemm(const foley_gemm_desc* d, void* stream) {
   return rc;
 }
 
+extern "C" int foley_op_attention_hd(const void* q, const void* k, const void* v, int in_dtype, int vt_pitch, int Bq,
+                                     int H, int Sq, int Skv, int kv_bdiv, void* outA, void* outB, int split,
+                                     int out_dtype, int head_dim, void* stream) {
+  AttnArgs a{q, k, v, Bq, H, Sq, Skv, kv_bdiv > 0 ? kv_bdiv : 1, outA, outB, split, in_dtype, vt_pitch, head_dim};
+  return launch_attention(a, out_dtype, (hipStream_t)stream);
+}
+
 extern "C" int foley_op_attention(const void* q, const void* k, const void* v, int in_dtype, int vt_pitch, int Bq,
                                   int H, int Sq, int Skv, int kv_bdiv, void* outA, void* outB, int split,
                                   int out_dtype, void* stream) {
-  AttnArgs a{q, k, v, Bq, H, Sq, Skv, kv_bdiv > 0 ? kv_bdiv : 1, outA, outB, split, in_dtype, vt_pitch};
-  return launch_attention(a, out_dtype, (hipStream_t)stream);
+  return foley_op_attention_hd(q, k, v, in_dtype, vt_pitch, Bq, H, Sq, Skv, kv_bdiv, outA, outB, split, out_dtype, 128, stream);
 }
 
 extern "C" int foley_op_ln_mod(const float* x, int M, int D, float eps, const foley_rowbcast* shift,

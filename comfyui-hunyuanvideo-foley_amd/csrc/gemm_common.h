@@ -34,9 +34,9 @@ __device__ __forceinline__ void tl_stamp(const GemmArgs& g, int slot) {
   }
 }
 
-__device__ __forceinline__ float act_epi(float v, int epi) {
+__device__ __forceinline__ float act_epi(float v, int epi, int gelu_erf = 0) {
   if (epi == EPI_SILU_T) return silu_f(v);
-  if (epi == EPI_GELU_T) return gelu_tanh_f(v);
+  if (epi == EPI_GELU_T) return gelu_erf ? gelu_erf_f(v) : gelu_tanh_f(v);
   return v;
 }
 
@@ -109,7 +109,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[F
             if (g.out0) ((float*)g.out0)[off] = v;
             if (g.out1) ((float*)g.out1)[off] = snake_f(v, sn_a[j], sn_ia[j]);
           } else {
-            ((T*)g.out0)[off] = Cvt<T>::to(act_epi(v, EPI));
+            ((T*)g.out0)[off] = Cvt<T>::to(act_epi(v, EPI, g.gelu_erf));
           }
         }
       }
@@ -309,7 +309,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
 #pragma unroll
           for (int w = 0; w < 4; ++w) {
             const float t = a[w] + bias_a[u + w];
-            v[u + w] = EPI == EPI_SILU_T ? silu_o<OutT>(t) : (EPI == EPI_GELU_T ? gelu_o<OutT>(t) : t);
+            if constexpr (EPI == EPI_GELU_T) v[u + w] = g.gelu_erf ? gelu_erf_f(t) : gelu_o<OutT>(t);   // workgroup-uniform flag
+            else v[u + w] = EPI == EPI_SILU_T ? silu_o<OutT>(t) : t;
           }
         }
       }

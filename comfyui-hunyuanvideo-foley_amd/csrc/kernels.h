@@ -79,6 +79,7 @@ struct GemmArgs {
   int vec_out;        // set by the launcher: the problem qualifies for the LDS-transposed vector epilogue
   int wfmt;           // storage of W: 0 = the operand dtype, 1 = fp8 e4m3fn, 2 = fp8 e5m2 (bf16 activations; wave-specialised
                       // tiles only - widened to bf16 in registers, reference FP8WeightWrapper utils.py:316-366)
+  int gelu_erf;       // EPI_GELU_T: exact (erf) GELU instead of the tanh form (the conditioning encoders' nn.GELU())
   int pf_dist;        // wave-specialised mainloop: L2 prefetch distance in K-slices beyond the LDS ring (0 = off; set by the launcher)
   int dbg_mode;
   long long* dbg;     // tools/gemm_timeline.py: 4 wall-clock stamps per workgroup (entry, first slice
@@ -99,7 +100,7 @@ int launch_gemm_ws_bf16(const GemmArgs& g, const GemmArgs* g1, int epi, int tile
 int launch_gemm_ws_f16(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
-// Attention: O = softmax(Q K^T / sqrt(128)) V, no mask.  Q [Bq, H, Sq, 128], K/V [Bkv, H, Skv, 128]
+// Attention: O = softmax(Q K^T / sqrt(hd)) V, no mask, hd = 128 (or 64: AttnArgs::head_dim).  Q [Bq, H, Sq, hd], K/V [Bkv, H, Skv, hd]
 // fp32.  Query batch b reads K/V batch b / kv_bdiv.  Output rows are token-major [.., H*128] in
 // dtype `out_dtype`; tokens [0, split) go to outA (clip-major rows of `split` tokens), the rest
 // to outB.
@@ -116,6 +117,7 @@ struct AttnArgs {
   int split;
   int in_dtype;
   int vt_pitch;
+  int head_dim;     // 0 / 128: the Foley DiT; 64: the conditioning encoders (fp32 kernel and the 16-bit wide kernel)
   int no_preload;   // set by the launcher (A/B switch FOLEY_ATTN_PRELOAD=0): small-grid kernel without the up-front operand requests
   long long* dbg;   // tools/attn_timeline.py: 5 wall-clock stamps per workgroup of the small-grid bf16 kernel; null in production
 };

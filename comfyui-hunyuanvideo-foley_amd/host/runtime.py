@@ -71,6 +71,7 @@ class GemmDescC(C.Structure):
         ("dtype", C.c_int32), ("epilogue", C.c_int32), ("tile", C.c_int32), ("ksplit", C.c_int32),
         ("partials", C.c_void_p), ("partial_slabs", C.c_int32), ("ksplit_used", C.POINTER(C.c_int32)),
         ("qkv", C.POINTER(QkvSplitDescC)), ("rstride", C.c_int32), ("ldw", C.c_int64), ("wfmt", C.c_int32),
+        ("gelu_erf", C.c_int32),
     ]
 
 
@@ -106,6 +107,8 @@ _SIGNATURES = {
     "foley_op_gemm": (C.c_int, [C.POINTER(GemmDescC), C.c_void_p]),
     "foley_op_attention": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                                                         C.c_void_p]),
+    "foley_op_attention_hd": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                                           C.c_void_p]),
     "foley_op_ln_mod_pending": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.POINTER(RowBcastC),
                                           C.POINTER(RowBcastC), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                           C.POINTER(RowBcastC), C.c_void_p]),
@@ -361,7 +364,7 @@ def rowbcast(t: Optional[torch.Tensor], mode: int = 0, rows_per_cfg: int = 1, L:
 def op_gemm(A, W, bias=None, *, M=None, epilogue=EPI_STORE_F32, out0=None, out1=None, ldc=None, conv=None,
             convT=None, rb: Optional[RowBcastC] = None, res=None, alpha=None, alphaC=1, tile=0, ksplit=0,
             partials=None, qkv: Optional["QkvSplitDescC"] = None, sconv=None, lda: Optional[int] = None,
-            ldw: Optional[int] = None, NK=None) -> int:
+            ldw: Optional[int] = None, NK=None, gelu_erf: bool = False) -> int:
     """Thin wrapper over foley_op_gemm.  conv=(seg, C, taps, dil) ; convT=(Tin, Cin, stride, Cout) ;
     sconv=(Tin, Cin, stride): strided conv k=2*stride, pad ceil(stride/2) over clips of Tin rows.
     partials: fp32 [slabs, M, N] workspace for the deferred split-K of the gated-residual epilogue.
@@ -376,6 +379,7 @@ def op_gemm(A, W, bias=None, *, M=None, epilogue=EPI_STORE_F32, out0=None, out1=
     else:
         d.dtype = dt_of(W)
     d.epilogue, d.tile, d.ksplit = epilogue, tile, ksplit
+    d.gelu_erf = 1 if gelu_erf else 0
     if convT is not None:
         Tin, Cin, s, Cout = convT
         clips = A.numel() // (Tin * Cin)
@@ -425,13 +429,13 @@ def op_gemm(A, W, bias=None, *, M=None, epilogue=EPI_STORE_F32, out0=None, out1=
 
 
 def op_attention(q, k, v, outA, outB, split: int, kv_bdiv: int = 1):
-    """fp32 q/k/v [B,H,S,128], or bf16 / fp16 q/k [B,H,S,128] with v transposed [B,H,128,pitch]."""
+    """fp32 q/k/v [B,H,S,hd], or bf16 / fp16 q/k [B,H,S,hd] with v transposed [B,H,hd,pitch]; hd = 128 or 64."""
     lib = load_library()
-    Bq, H, Sq, _ = q.shape
+    Bq, H, Sq, hd = q.shape
     Skv = k.shape[2]
     vt_pitch = v.shape[3] if q.dtype in (torch.bfloat16, torch.float16) else 0
-    _check(lib, lib.foley_op_attention(_ptr(q), _ptr(k), _ptr(v), dt_of(q), vt_pitch, Bq, H, Sq, Skv, kv_bdiv,
-                                       _ptr(outA), _ptr(outB), split, dt_of(outB), _stream()), "foley_op_attention")
+    _check(lib, lib.foley_op_attention_hd(_ptr(q), _ptr(k), _ptr(v), dt_of(q), vt_pitch, Bq, H, Sq, Skv, kv_bdiv,
+                                          _ptr(outA), _ptr(outB), split, dt_of(outB), hd, _stream()), "foley_op_attention_hd")
 
 
 def op_ln_mod(x, eps, shift: Optional[RowBcastC], scale: Optional[RowBcastC], out):

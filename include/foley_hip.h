@@ -222,6 +222,8 @@ typedef struct foley_gemm_desc {
   int64_t ldw;     /* elements between rows of W (0 = K); > K for row-padded weight storage (wave-specialised tiles) */
   int32_t wfmt;    /* storage of W: 0 = `dtype`; 1 = fp8 e4m3fn, 2 = fp8 e5m2 with bf16 activations - widened to bf16
                     * in registers by the wave-specialised tiles (15, 19), bit-identical to widening at load time */
+  int32_t gelu_erf;/* epilogue 3 only: 1 = exact GELU (erf) instead of the tanh form - nn.GELU() of the conditioning
+                    * encoders (reference models/synchformer/vit_helper.py:108-125 Mlp, nn.TransformerEncoderLayer) */
 } foley_gemm_desc;
 
 int foley_op_gemm(const foley_gemm_desc* d, void* stream);
@@ -230,6 +232,11 @@ int foley_op_gemm(const foley_gemm_desc* d, void* stream);
 int foley_op_attention(const void* q, const void* k, const void* v, int in_dtype, int vt_pitch, int Bq, int H,
                        int Sq, int Skv, int kv_bdiv, void* outA, void* outB, int split, int out_dtype,
                        void* stream);
+/* the same with head_dim 128 or 64 (the ViT-B conditioning encoders, feature_utils.py:63-108): fp32 operands, or 16-bit
+ * operands through the LDS-staged 128-query kernel (v transposed [B,H,head_dim,vt_pitch]) */
+int foley_op_attention_hd(const void* q, const void* k, const void* v, int in_dtype, int vt_pitch, int Bq, int H,
+                          int Sq, int Skv, int kv_bdiv, void* outA, void* outB, int split, int out_dtype,
+                          int head_dim, void* stream);
 int foley_op_ln_mod(const float* x, int M, int D, float eps, const foley_rowbcast* shift,
                     const foley_rowbcast* scale, void* out, int out_dtype, void* stream);
 /* LayerNorm (+ modulation) of a residual stream that first receives the pending update of a deferred
