@@ -223,9 +223,9 @@ def siglip_image_features_hip(sd: SD, pixels: Tensor, dtype: torch.dtype = torch
     GELU-tanh -> fc2 -> +x), post LayerNorm, and the attention-pooling head (a learned probe attending to all tokens
     through nn.MultiheadAttention, then LayerNorm -> MLP residual).  pixels [T, 3, S, S] fp32 on the GPU -> [T, D] fp32.
     Called by feature_utils.py:63-78's counterpart (encoders.encode_video_with_siglip2) when the engine path is on."""
-    p = prefix
+    p = prefix if (prefix + "embeddings.patch_embedding.weight") in sd else ""     # SiglipModel vs SiglipVisionModel state dicts
     if pixels.shape[0] > batch_size:
-        return torch.cat([siglip_image_features_hip(sd, pixels[i:i + batch_size], dtype, prefix, heads, eps, batch_size)
+        return torch.cat([siglip_image_features_hip(sd, pixels[i:i + batch_size].contiguous(), dtype, prefix, heads, eps, batch_size)
                           for i in range(0, pixels.shape[0], batch_size)])
     E = _engine_for(sd, pixels.device, dtype)
     w = sd[p + "embeddings.patch_embedding.weight"]                   # [D, 3, P, P]
@@ -256,25 +256,11 @@ def siglip_image_features_hip(sd: SD, pixels: Tensor, dtype: torch.dtype = torch
     hp = p + "head"
     Wi, bi = sd[hp + ".attention.in_proj_weight"], sd[hp + ".attention.in_proj_bias"]
     probe = sd[hp + ".probe"].to(E.dev, E.dtype).reshape(1, D)
-    sdh = {"wq": Wi[:D], "bq": bi[:D], "wkv": Wi[D:], "bkv": bi[D:]}
-    Eh = _engine_for(sdh_key(sd, sdh), pixels.device, dtype)
-    qp = Eh.linear(probe, sdh, "wq", "bq").view(1, 1, heads, hd).permute(0, 2, 1, 3).expand(B, heads, 1, hd)
-    kv = Eh.linear(hs, sdh, "wkv", "bkv").view(B, N, 2, heads, hd).permute(2, 0, 3, 1, 4)
+    sdh = {hp + "#wq": Wi[:D], hp + "#bq": bi[:D], hp + "#wkv": Wi[D:], hp + "#bkv": bi[D:]}    # staged once under these keys
+    qp = E.linear(probe, sdh, hp + "#wq", hp + "#bq").view(1, 1, heads, hd).permute(0, 2, 1, 3).expand(B, heads, 1, hd)
+    kv = E.linear(hs, sdh, hp + "#wkv", hp + "#bkv").view(B, N, 2, heads, hd).permute(2, 0, 3, 1, 4)
     pooled = E.attention(qp, kv[0], kv[1]).reshape(B, D)
     y = E.linear(pooled, sd, hp + ".attention.out_proj.weight", hp + ".attention.out_proj.bias", out_f32=True)
     hid = E.linear(E.ln(y, sd, hp + ".layernorm", eps), sd, hp + ".mlp.fc1.weight", hp + ".mlp.fc1.bias", act="gelu_tanh")
     E.linear_residual(y, hid, sd, hp + ".mlp.fc2.weight", hp + ".mlp.fc2.bias")
     return y
-
-
-_HEAD_SPLITS: Dict = {}
-
-
-def sdh_key(sd: SD, sdh: SD) -> SD:
-    """One split in_proj dict per model state dict (so the staged-weight cache keys on a stable object)."""
-    k = id(sd)
-    cur = _HEAD_SPLITS.get(k)
-    if cur is None or cur[0] is not sd:
-        _HEAD_SPLITS[k] = cur = (sd, sdh)
-    sdh.update(cur[1])
-    return cur[1]

@@ -1,0 +1,82 @@
+"""The conditioning encoders ON THE HIP ENGINE (SURVEY 8f N2 stage 2, host/encoders_hip.py): Synchformer against the
+golden frozen from the reference's own MotionFormer (tests/golden/g11_v2a.npz - NOT against torch running the same
+restatement), the SigLIP vision tower against `transformers`' SiglipVisionModel on the CPU, and the GPU branch of the
+uint8 resize against the CPU uint8 kernel torchvision's v2.Resize dispatches to."""
+import pytest
+import torch
+
+from conftest import golden, rel_err
+from foley_amd.host import encoders as E, encoders_hip as EH, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_synchformer_on_the_engine_matches_reference_golden(dev):
+    """Every GEMM / attention / LayerNorm of the Synchformer visual extractor through libfoley_hip.so (12 divided
+    space-time blocks, final norm, spatial aggregation layer) on golden g11's two overlapping segments.  fp32 operands
+    (parity mode) against the reference's fp32 CPU output: 2e-5; fp16 operands - what the reference's GPU path computes
+    in (feature_utils.py:99-104, autocast fp16) - and bf16 to their rounding levels."""
+    g = golden("g11_v2a")
+    sd = {k: v.to(dev) for k, v in synth.materialize(E.synchformer_schema()).items()}
+    frames = synth.synth_tensor("g11.frames", (24, 3, 224, 224), 0.55).to(dev)
+    f32 = EH.encode_video_with_sync_hip(sd, frames, torch.float32)
+    assert f32.shape == (1, 16, 768)
+    e32 = rel_err(f32, g["sync_feat"])
+    f16 = EH.encode_video_with_sync_hip(sd, frames, torch.float16)
+    b16 = EH.encode_video_with_sync_hip(sd, frames, torch.bfloat16)
+    e16, eb = rel_err(f16, g["sync_feat"]), rel_err(b16, g["sync_feat"])
+    print("Synchformer on the HIP engine vs the reference's MotionFormer: fp32 %.2e, fp16 %.2e, bf16 %.2e" % (e32, e16, eb))
+    assert e32 < 2e-5 and e16 < 5e-3 and eb < 4e-2
+    # batches of segments are independent: one segment alone equals its rows of the pair
+    one = EH.encode_video_with_sync_hip(sd, frames[:16].contiguous(), torch.float32)
+    assert rel_err(one, f32[:, :8]) < 1e-5
+    with pytest.raises(ValueError):
+        EH.encode_video_with_sync_hip(sd, frames[:15], torch.float32)
+
+
+def _small_siglip(layers=2, image=128, patch=16):
+    from transformers import SiglipVisionConfig, SiglipVisionModel
+    torch.manual_seed(0)
+    cfg = SiglipVisionConfig(hidden_size=768, num_hidden_layers=layers, num_attention_heads=12, intermediate_size=3072,
+                             image_size=image, patch_size=patch)
+    m = SiglipVisionModel(cfg).eval()
+    with torch.no_grad():      # default init leaves several tensors at zero / one: give every parameter a value
+        gen = torch.Generator().manual_seed(1)
+        for n, p_ in m.named_parameters():
+            if p_.dim() == 1 and ("norm" in n and n.endswith("weight")):
+                p_.copy_(1 + 0.1 * torch.randn(p_.shape, generator=gen))
+            elif p_.dim() == 1:
+                p_.copy_(0.05 * torch.randn(p_.shape, generator=gen))
+    return m
+
+
+def test_siglip_vision_tower_on_the_engine(dev):
+    """`get_image_features` of transformers' SigLIP vision model (what feature_utils.py:63-78 calls per 8 fps frame) as
+    restated on the engine over the model's state dict - ViT-B width (768, 12 heads of 64, MLP 3072, GELU-tanh), pre-norm
+    encoder, attention-pooling head - against the HF module itself on the CPU in fp32."""
+    m = _small_siglip()
+    sd = {k: v.detach().to(dev) for k, v in m.state_dict().items()}
+    px = torch.randn(3, 3, 128, 128, generator=torch.Generator().manual_seed(2))
+    with torch.inference_mode():
+        ref = m(pixel_values=px).pooler_output
+    f32 = EH.siglip_image_features_hip(sd, px.to(dev), torch.float32)
+    f16 = EH.siglip_image_features_hip(sd, px.to(dev), torch.float16)
+    b16 = EH.siglip_image_features_hip(sd, px.to(dev), torch.bfloat16)
+    e32, e16, eb = rel_err(f32, ref), rel_err(f16, ref), rel_err(b16, ref)
+    print("SigLIP vision tower on the HIP engine vs transformers (CPU fp32): fp32 %.2e, fp16 %.2e, bf16 %.2e" % (e32, e16, eb))
+    assert f32.shape == ref.shape and e32 < 2e-5 and e16 < 5e-3 and eb < 4e-2
+
+
+def test_gpu_uint8_resize_matches_the_cpu_uint8_kernel(dev):
+    """torchvision's v2.Resize(bicubic, antialias) runs the native uint8 kernel on the CPU (where the reference
+    pre-processes, utils.py:262-283); encoders._resize_u8 on the GPU goes through float32 + round + clamp.  torchvision
+    is not in the image, so the reference is the very CPU kernel v2.Resize dispatches to: F.interpolate on uint8.  The
+    two may differ by one grey level where the uint8 kernel's fixed-point weights round the other way."""
+    g = torch.Generator().manual_seed(5)
+    for shape, size in (((4, 3, 96, 160), (224, 373)), ((2, 3, 480, 640), (512, 512)), ((2, 3, 300, 224), (300, 224))):
+        fr = torch.randint(0, 256, shape, generator=g, dtype=torch.uint8)
+        cpu = E._resize_u8(fr, size)
+        gpu = E._resize_u8(fr.to(dev), size).cpu()
+        assert gpu.dtype == torch.uint8 and gpu.shape == cpu.shape
+        d = (gpu.int() - cpu.int()).abs()
+        assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 0.08, (int(d.max()), float((d > 0).float().mean()))

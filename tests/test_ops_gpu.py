@@ -374,6 +374,48 @@ def test_attention_bf16(dev, B, H, Sq, Skv, split, kv_bdiv, half):
     assert rel_err(ob.float(), ref[:, split:]) < (1e-2 if half == torch.bfloat16 else 2e-3)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,Sq,Skv,kv_bdiv", [
+    # head dim 64, the shapes of the conditioning encoders (host/encoders_hip.py): Synchformer time groups (8 queries x 9
+    # keys), space groups (196 x 197), the CLS query over all 1569 tokens, the spatial aggregation layer (197 x 197),
+    # SigLIP2 (1024 x 1024) and its pooling probe (1 x 1024)
+    (392, 12, 8, 9, 1), (16, 12, 196, 197, 1), (2, 12, 1, 1569, 1), (16, 12, 197, 197, 1), (2, 12, 1024, 1024, 1), (3, 12, 1, 1024, 1),
+    (5, 3, 37, 70, 1), (4, 2, 130, 33, 2)])
+def test_attention_head_dim_64(dev, dtype, B, H, Sq, Skv, kv_bdiv):
+    """foley_op_attention_hd with head_dim 64 (ViT-B encoders; reference feature_utils.py:63-108): the fp32 MFMA kernel
+    and the LDS-staged 16-bit kernel templated on the head dim, against softmax(Q K^T / 8) V."""
+    q, k, v = _rand((B, H, Sq, 64), 50), _rand((B // kv_bdiv, H, Skv, 64), 51), _rand((B // kv_bdiv, H, Skv, 64), 52)
+    qq, kq, vq = (_q(t, dtype) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qq, kq.repeat_interleave(kv_bdiv, 0), vq.repeat_interleave(kv_bdiv, 0))
+    ref = ref.transpose(1, 2).reshape(B, Sq, H * 64)
+    if dtype == torch.float32:
+        vd = v.to(dev)
+    else:
+        pitch = (Skv + 31) // 32 * 32
+        vd = torch.full((B // kv_bdiv, H, 64, pitch), 3.0, dtype=dtype)
+        vd[..., :Skv] = v.to(dtype).transpose(2, 3)
+        vd = vd.to(dev)
+    out = torch.full((B, Sq, H * 64), float("nan"), device=dev, dtype=dtype)
+    rt.op_attention(q.to(dev, dtype), k.to(dev, dtype), vd, out, out, 0, kv_bdiv)
+    tol = {torch.float32: 3e-6, torch.bfloat16: 1e-2, torch.float16: 2e-3}[dtype]
+    assert rel_err(out.float(), ref) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("tile", [0, 15, 25])
+def test_gemm_exact_gelu_epilogue(dev, dtype, tile):
+    """foley_gemm_desc.gelu_erf: nn.GELU() (erf form) of the encoders' MLPs instead of the DiT's tanh form."""
+    if tile and dtype == torch.float32:
+        pytest.skip("wave-specialised tiles are 16-bit only")
+    M, N, K = 300, 512, 256
+    A, W, b = _rand((M, K), 4), _rand((N, K), 5, 1 / math.sqrt(K)), _rand((N,), 6, 0.5)
+    y = F.linear(_q(A, dtype), _q(W, dtype), b)
+    out = torch.empty(M, N, device=dev, dtype=dtype)
+    rt.op_gemm(A.to(dev, dtype), W.to(dev, dtype), b.to(dev), out0=out, epilogue=rt.EPI_GELU_T, tile=tile, gelu_erf=True)
+    assert rel_err(out.float(), F.gelu(y)) < _tol(dtype)
+    assert rel_err(out.float(), F.gelu(y, approximate="tanh")) > rel_err(out.float(), F.gelu(y)) or dtype == torch.bfloat16
+
+
 def test_attention_bf16_spiky(dev):
     q, k, v = _rand((1, 1, 64, 128), 33), _rand((1, 1, 200, 128), 34), _rand((1, 1, 200, 128), 35)
     k[0, 0, 150] = q[0, 0, 7] * 5.0
