@@ -120,6 +120,38 @@ def cpu_baseline(sd_gpu, dsd_gpu, cfg, cond, noise, duration, threads=16):
                       f"{avail} available) + the DAC decode ({t_dec:.2f}s) of the same {duration:g} s clip, extrapolated"}
 
 
+def encoder_pass(cfg, duration, dev, dtype, frame_rate=16.0, hw=(480, 640), repeats=2):
+    """BASELINE configs[2]: 'SigLIP2 + Synchformer conditioning' from synthetic frames (uint8
+    [int(dur*fr), H, W, 3] uniform noise, seed 3) - frame selection, the two v2 pipelines, the SigLIP2 vision tower
+    (google/siglip2-base-patch16-512's architecture: ViT-B/16 at 512 px, random init - no checkpoints in the image) and
+    the Synchformer visual extractor (synthesised weights), all on the GPU, both encoders on the HIP engine
+    (host/encoders_hip.py).  Returns (visual features, per-stage milliseconds of the last of `repeats` passes)."""
+    from transformers import SiglipVisionConfig, SiglipVisionModel
+    from foley_amd.host import encoders as E
+    torch.manual_seed(0)
+    sig = SiglipVisionModel(SiglipVisionConfig(hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                                               intermediate_size=3072, image_size=512, patch_size=16)).eval().to(dev, dtype)
+    sync_sd = {k: v.to(dev, dtype) for k, v in synth.materialize(E.synchformer_schema()).items()}
+    g = torch.Generator().manual_seed(3)
+    n = int(duration * frame_rate)
+    image = torch.randint(0, 256, (n, hw[0], hw[1], 3), generator=g, dtype=torch.uint8).float() / 255.0   # a ComfyUI IMAGE batch
+    tm = {}
+    for _ in range(repeats):
+        tm = {}
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        f8, f25 = E.select_frames(image, duration, frame_rate)
+        tm["select_frames_ms"] = 1e3 * (time.perf_counter() - t0)
+        feats, alen = E.video_features(f8, f25, sig, sync_sd, dev, model_dtype=dtype, timings=tm)
+        torch.cuda.synchronize(dev)
+        tm["total_ms"] = 1e3 * (time.perf_counter() - t0)
+    assert abs(alen - duration) < 1e-6 and all(bool(torch.isfinite(v).all()) for v in feats.values())
+    tm = {k: round(v, 2) for k, v in tm.items()}
+    tm["frames"] = f"{n} frames {hw[0]}x{hw[1]} uint8 noise (seed 3) at {frame_rate:g} fps -> {f8.shape[0]} @ 8 fps (SigLIP2 512 px) + {f25.shape[0]} @ 25 fps (Synchformer 224 px)"
+    tm["weights"] = "SigLIP2 ViT-B/16-512 random init; Synchformer synthesised; both on libfoley_hip.so"
+    return feats, tm
+
+
 # ----------------------------------------------------------------------------- self-launch
 def _free_port() -> int:
     s = socket.socket()
@@ -173,6 +205,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the per-kernel profile pass and the bs=8 measurement")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--with-encoders", action="store_true",
+                    help="c3 / c4: compute the conditioning from synthetic uint8 frames (seed 3) through the full-size SigLIP2 "
+                         "vision tower and Synchformer on the HIP engine (random-init / synthesised weights) and report encoder_ms")
     ap.add_argument("--progress", action="store_true",
                     help="time the path a ComfyUI run takes: a host progress callback after every loop iteration "
                          "(graph replay + D2D copy + stream synchronise per iteration, foley_rt.hip foley_sample)")
@@ -278,6 +313,12 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
     visual = {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]}
     text = {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]}
     graph = not a.no_graph
+    encoders = None
+    if a.with_encoders:
+        if conf["t2a"]:
+            print("bench.py: --with-encoders needs a video-to-audio configuration (c3 / c4)", file=sys.stderr)
+            return 2
+        visual, encoders = encoder_pass(cfg, duration, dev, dtype)     # every rank encodes the same synthetic clip
 
     def barrier():
         torch.cuda.synchronize()
@@ -380,6 +421,10 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
                                        "(the path a ComfyUI run takes)", progress=True)
         if world == 1:
             extra["c3"] = extra_line(1, duration, f"c3: {CONFIGS['c3']['desc']}", visual=vis3)
+            # BASELINE configs[2] end to end: conditioning from synthetic frames through the encoders on the HIP engine
+            _v, enc = encoder_pass(cfg, duration, dev, dtype)
+            extra["c3"]["encoder_ms"] = enc
+            extra["c3"]["end_to_end_ms"] = round(enc["total_ms"] + extra["c3"]["ms_per_step"], 1)
             from foley_amd import nodes
             m5 = nodes.HunyuanModelLoader.pack_state_dict(sd, "bf16", "fp8_e4m3fn", device=dev, cfg=cfg, dac_cfg=dac_cfg)
             c5c = synth.synth_conditioning(cfg, CONFIGS["c5"]["duration"], t2a=True, sd=sd, device=dev, seed=1)
@@ -425,6 +470,9 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
                        "collectives": 1 if use_dist else 0, "broadcast_s": bcast_s, "bundle_bytes": spec.total},
             "roofline": roof,
         }
+        if encoders is not None:
+            out["encoder_ms"] = encoders
+            out["end_to_end_ms_per_step"] = encoders["total_ms"] + 1e3 * dt / a.steps
         if extra:
             out["extra"] = extra
         if world == 1 and not a.no_cpu_baseline and a.model == "xxl" and a.config != "c5":

@@ -58,14 +58,23 @@ def select_frames(image: Tensor, duration: float, frame_rate: float) -> Tuple[Te
 
 # ----------------------------------------------------------------------------- pre-processing
 def _resize_u8(frames: Tensor, size: Tuple[int, int]) -> Tensor:
-    """v2.Resize(bicubic, antialias=True) on uint8 [T,C,H,W]: torchvision resizes uint8 images with the
-    native uint8 kernel on CPU and through float32 + round + clamp elsewhere; both are reproduced."""
+    """v2.Resize(bicubic, antialias=True) on uint8 [T,C,H,W] as the reference runs it - on the CPU (utils.py:262-283
+    pre-processes before the encoders' `.to(device)`), where torchvision dispatches to ATen's native uint8 kernel.  That
+    kernel is separable with a uint8 intermediate: a horizontal pass, rounded and clamped to [0, 255], then the vertical
+    pass (PIL's scheme).  On the GPU the same two passes are taken in float32 with the same intermediate rounding, which
+    reproduces the CPU result up to the uint8 kernel's fixed-point weights (<= 1 grey level on a few per cent of the
+    pixels; `tests/test_encoders_gpu.py`) - a single 2-D float interpolation differs by tens of levels on textured
+    frames because overshoots are not clamped between the passes."""
     if tuple(frames.shape[-2:]) == tuple(size):
         return frames
     if frames.device.type == "cpu":
         return F.interpolate(frames, size=size, mode="bicubic", antialias=True)
-    out = F.interpolate(frames.float(), size=size, mode="bicubic", antialias=True)
-    return out.round_().clamp_(0, 255).to(torch.uint8)
+    x = frames.float()
+    if x.shape[-1] != size[1]:
+        x = F.interpolate(x, size=(x.shape[-2], size[1]), mode="bicubic", antialias=True).round_().clamp_(0, 255)
+    if x.shape[-2] != size[0]:
+        x = F.interpolate(x, size=size, mode="bicubic", antialias=True).round_().clamp_(0, 255)
+    return x.to(torch.uint8)
 
 
 def _scale_normalize(frames_u8: Tensor) -> Tensor:
@@ -267,13 +276,54 @@ def encode_text_feat(tokenizer, model, prompts, device) -> Tensor:
 
 @torch.inference_mode()
 def video_features(frames_8fps: Tensor, frames_25fps: Tensor, siglip2_model, sync_sd: SD, device,
-                   model_dtype: Optional[torch.dtype] = None):
-    """feature_process_from_tensors' visual half (utils.py:262-283): pre-processing on the frames'
-    device (CPU in the reference), encoders on `device`.  Returns (features, audio_len_in_s)."""
-    p8 = siglip2_preprocess(frames_8fps)
-    p25 = synchformer_preprocess(frames_25fps)
+                   model_dtype: Optional[torch.dtype] = None, timings: Optional[dict] = None):
+    """feature_process_from_tensors' visual half (utils.py:262-283).  Returns (features, audio_len_in_s).
+
+    On a HIP device the selected uint8 frames are moved to the GPU first, pre-processed there (`_resize_u8`'s two-pass
+    branch reproduces the reference's CPU uint8 resize) and BOTH encoders run on libfoley_hip.so
+    (host/encoders_hip.py: SigLIP2 in the model dtype like the reference's `siglip2_model.to(device, dtype)`,
+    Synchformer with fp16 operands like its fp16 autocast, feature_utils.py:63-108).  On the CPU (tests) the torch
+    restatement / the `transformers` module run instead.  `timings` (optional dict) receives per-stage milliseconds."""
+    import time
+    device = torch.device(device)
+    on_gpu = device.type == "cuda"
     if model_dtype is None:
         model_dtype = next(siglip2_model.parameters()).dtype
-    feats = {"siglip2_feat": encode_video_with_siglip2(siglip2_model, p8.to(device=device, dtype=model_dtype)),
-             "syncformer_feat": encode_video_with_sync(sync_sd, p25.to(device))}
+
+    def lap(name, t0):
+        if timings is not None:
+            if on_gpu:
+                torch.cuda.synchronize(device)
+            timings[name] = timings.get(name, 0.0) + 1e3 * (time.perf_counter() - t0)
+
+    t0 = time.perf_counter()
+    if on_gpu:
+        frames_8fps, frames_25fps = frames_8fps.to(device), frames_25fps.to(device)
+    p8 = siglip2_preprocess(frames_8fps)
+    p25 = synchformer_preprocess(frames_25fps)
+    lap("preprocess_ms", t0)
+    if on_gpu:
+        from . import encoders_hip as EH
+        t0 = time.perf_counter()
+        sig_sd = _siglip_state(siglip2_model, device)
+        sig = EH.siglip_image_features_hip(sig_sd, p8, model_dtype).unsqueeze(0)
+        lap("siglip2_ms", t0)
+        t0 = time.perf_counter()
+        sync = EH.encode_video_with_sync_hip(sync_sd, p25, torch.float16)
+        lap("synchformer_ms", t0)
+        feats = {"siglip2_feat": sig, "syncformer_feat": sync}
+    else:
+        feats = {"siglip2_feat": encode_video_with_siglip2(siglip2_model, p8.to(device=device, dtype=model_dtype)),
+                 "syncformer_feat": encode_video_with_sync(sync_sd, p25.to(device))}
     return feats, frames_25fps.shape[0] / float(FPS_SYNC)
+
+
+def _siglip_state(model, device) -> SD:
+    """State dict of the HF SigLIP model's vision tower on `device`, cached on the module (the engine stages its own
+    compute-dtype copies of the matrices once per state dict object)."""
+    cur = getattr(model, "_foley_vision_sd", None)
+    if cur is None or next(iter(cur.values())).device != torch.device(device):
+        sd = {k: v.detach().to(device) for k, v in model.state_dict().items()
+              if k.startswith("vision_model.") or k.startswith(("embeddings.", "encoder.", "post_layernorm.", "head."))}
+        model._foley_vision_sd = cur = sd
+    return cur

@@ -70,8 +70,10 @@ def test_siglip_vision_tower_on_the_engine(dev):
 def test_gpu_uint8_resize_matches_the_cpu_uint8_kernel(dev):
     """torchvision's v2.Resize(bicubic, antialias) runs the native uint8 kernel on the CPU (where the reference
     pre-processes, utils.py:262-283); encoders._resize_u8 on the GPU goes through float32 + round + clamp.  torchvision
-    is not in the image, so the reference is the very CPU kernel v2.Resize dispatches to: F.interpolate on uint8.  The
-    two may differ by one grey level where the uint8 kernel's fixed-point weights round the other way."""
+    is not in the image, so the reference is the very CPU kernel v2.Resize dispatches to: F.interpolate on uint8 - a
+    separable kernel with a uint8 intermediate, which the GPU branch reproduces pass by pass.  The two may differ where
+    the uint8 kernel's fixed-point weights round the other way: one grey level per pass, on < 2 % of the pixels of
+    pure-noise frames (measured 0.6 %; a single 2-D float interpolation is off by up to 22 levels on 20 % of them)."""
     g = torch.Generator().manual_seed(5)
     for shape, size in (((4, 3, 96, 160), (224, 373)), ((2, 3, 480, 640), (512, 512)), ((2, 3, 300, 224), (300, 224))):
         fr = torch.randint(0, 256, shape, generator=g, dtype=torch.uint8)
@@ -79,4 +81,4 @@ def test_gpu_uint8_resize_matches_the_cpu_uint8_kernel(dev):
         gpu = E._resize_u8(fr.to(dev), size).cpu()
         assert gpu.dtype == torch.uint8 and gpu.shape == cpu.shape
         d = (gpu.int() - cpu.int()).abs()
-        assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 0.08, (int(d.max()), float((d > 0).float().mean()))
+        assert int(d.max()) <= 2 and float((d > 0).float().mean()) < 0.02, (int(d.max()), float((d > 0).float().mean()))

@@ -733,15 +733,19 @@ def test_v2a_node_with_image_input(dev):
     first, batch = nodes.HunyuanFoleySampler().generate_audio(model, deps, **kw)
     assert batch["waveform"].shape == (1, 1, 2 * 48000) and first["sample_rate"] == 48000
     assert torch.isfinite(batch["waveform"]).all()
-    # features as the node computed them (GPU, Synchformer under fp16 autocast) vs an fp32 CPU evaluation
+    # features as the node computed them (GPU: frames pre-processed on the device, both encoders on the HIP engine - SigLIP2 in
+    # the model dtype, Synchformer with fp16 operands) vs an fp32 CPU evaluation through transformers / the torch restatement
+    # (CPU uint8 resize: the GPU resize differs by a grey level on < 1 % of the pixels, hence 5e-3 on the SigLIP2 features)
     cpu_deps = nodes.AttributeDict(siglip2_model=tiny_siglip(), syncformer_model=sync_sd, clap_tokenizer=tok, clap_model=tiny_clap()[1])
     vis_c, txt_c, alen = nodes.HunyuanFoleySampler._video_features(image, 2.0, 24.0, kw["prompt"], kw["negative_prompt"],
                                                                    cpu_deps, torch.device("cpu"), torch.float32)
     vis_g, txt_g, alen_g = nodes.HunyuanFoleySampler._video_features(image, 2.0, 24.0, kw["prompt"], kw["negative_prompt"],
                                                                      deps, dev, torch.float32)
     assert alen == alen_g == 2.0 and vis_g["siglip2_feat"].shape == (1, 16, 768) and vis_g["syncformer_feat"].shape == (1, 40, 768)
-    assert rel_err(vis_g["siglip2_feat"], vis_c["siglip2_feat"]) < 1e-3
-    assert rel_err(vis_g["syncformer_feat"], vis_c["syncformer_feat"]) < 2e-2      # fp16 autocast, like the reference
+    e_sig, e_syn = rel_err(vis_g["siglip2_feat"], vis_c["siglip2_feat"]), rel_err(vis_g["syncformer_feat"], vis_c["syncformer_feat"])
+    print("node features GPU engine vs CPU: siglip2 %.2e, synchformer %.2e" % (e_sig, e_syn))
+    assert e_sig < 5e-3
+    assert e_syn < 2e-2      # fp16 operands, like the reference's fp16 autocast
     assert rel_err(txt_g["text_feat"], txt_c["text_feat"]) < 1e-3
     # the whole node against the oracle on the node's own (GPU) features: isolates the HIP sampler from encoder precision
     noise = torch.randn((1, 128, 100), generator=torch.Generator("cpu").manual_seed(55574), dtype=torch.float32)
