@@ -140,7 +140,7 @@ def encoder_pass(cfg, duration, dev, dtype, frame_rate=16.0, hw=(480, 640), repe
         tm = {}
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        f8, f25 = E.select_frames(image, duration, frame_rate)
+        f8, f25 = E.select_frames(image, duration, frame_rate, device=dev)      # incl. the H2D copy of the selected frames
         tm["select_frames_ms"] = 1e3 * (time.perf_counter() - t0)
         feats, alen = E.video_features(f8, f25, sig, sync_sd, dev, model_dtype=dtype, timings=tm)
         torch.cuda.synchronize(dev)

@@ -373,7 +373,7 @@ class HunyuanFoleySampler:
         8 fps / 25 fps, run SigLIP2 and the Synchformer visual extractor, CLAP for the two prompts.  The
         audio length follows the sync stream: len(frames_25fps) / 25."""
         _ensure_visual_encoders(deps, device, dtype)
-        f8, f25 = _enc.select_frames(image, duration, frame_rate)
+        f8, f25 = _enc.select_frames(image, duration, frame_rate, device=device if torch.device(device).type == "cuda" else None)
         visual, audio_len_in_s = _enc.video_features(f8, f25, deps["siglip2_model"], deps["syncformer_model"], device,
                                                      model_dtype=dtype)
         res = encode_text_feat([negative_prompt, prompt], deps, device, dtype)
