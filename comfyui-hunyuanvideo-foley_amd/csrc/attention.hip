@@ -355,6 +355,232 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
   if (stamp) a.dbg[(long)blockIdx.x * 8 + 4] = wall_clock64();
 }
 
+// The same kernel with its operands staged through LDS by direct-to-LDS DMA (small grids, Skv * 256 + V^T image + Q tile
+// within 160 KiB: the single-stream blocks' self-attention at 5 s and the cross-attention to the 77 text keys).
+__device__ __forceinline__ void attn_buf_lds16(const void* base, unsigned bytes, unsigned char* lds_wave_base, int voff) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, 0);
+}
+
+template <typename T, typename OutT>
+__global__ __launch_bounds__(256) void attn_lds_kernel(const AttnArgs a, const int merge_off) {
+  constexpr int HD = 128;
+  // ONE dynamic LDS array (a second __shared__ object makes hipcc drain vmcnt in front of every ds_read of a direct-to-LDS
+  // pipeline): [K image | V^T image | Q image], and the merge area of the four key ranges at `merge_off` - behind the
+  // images when that fits 160 KiB, else aliased onto them (offset 0) after a barrier
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  float (*sO)[3][16][64] = (float (*)[3][16][64])(dsm + merge_off);   // partial O of the d-fragments a wave does not finalise itself
+  float (*sM)[32] = (float (*)[32])(dsm + merge_off + 4 * 3 * 16 * 64 * 4);
+  float (*sL)[32] = (float (*)[32])(dsm + merge_off + 4 * 3 * 16 * 64 * 4 + 4 * 32 * 4);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int j = lane & 31, kh = lane >> 5;
+  int qt, h, b;
+  attn_block_coords(a, 32, qt, h, b);
+  const int q0 = qt * 32;
+  const int bk = b / a.kv_bdiv;
+  const T* __restrict__ Q = (const T*)a.q + ((long)(b * a.H + h) * a.Sq) * HD;
+  const T* __restrict__ K = (const T*)a.k + ((long)(bk * a.H + h) * a.Skv) * HD;
+  const T* __restrict__ VT = (const T*)a.v + ((long)(bk * a.H + h) * HD) * a.vt_pitch;
+  const float scale2 = 0.08838834764831845f * 1.4426950408889634f;   // log2(e) / sqrt(128)
+
+  const bool stamp = a.dbg && threadIdx.x == 0;
+  if (stamp) a.dbg[(long)blockIdx.x * 8 + 0] = wall_clock64();
+  // ---- staging: every wave issues its share of 1 KiB direct-to-LDS pieces (full 128-byte lines; the fragment-shaped
+  // global loads of attn_bf16_kernel touch 32 bytes of each line, which is what its operand phase is bound by).  LDS rows are
+  // unpadded powers of two; bank conflicts are avoided by permuting the SOURCE chunk (p ^ f(row)) and applying the same XOR
+  // at fragment-read time.  Rows past the end of an operand lie beyond the buffer range and arrive as zeros.
+  const int nt = (a.Skv + 31) >> 5;
+  const int lgCV = a.vt_pitch > 128 ? 5 : 4;                    // 16-byte chunks per LDS row of the V^T image (16 or 32)
+  unsigned char* const Ks = dsm;
+  unsigned char* const Vs = Ks + nt * 32 * 256;
+  unsigned char* const Qs = Vs + (128 << (lgCV + 4));
+  const int wv = __builtin_amdgcn_readfirstlane(w);
+  {
+    const int r4 = lane >> 4, c16 = lane & 15;
+    for (int p = wv; p < nt * 8; p += 4) {                       // K: pieces of 4 rows x 256 B
+      const int row = 4 * p + r4;
+      const int g = c16 ^ ((row & 7) | ((row >> 1) & 8));
+      attn_buf_lds16(K, (unsigned)a.Skv * 256u, Ks + p * 1024, row * 256 + g * 16);
+    }
+    const int vchunks = a.vt_pitch >> 3;                         // 16-byte chunks per V^T row in memory
+    for (int p = wv; p < (128 << lgCV) >> 6; p += 4) {           // V^T: 128 rows x (16 << lgCV) B
+      const int pos = p * 64 + lane;
+      const int row = pos >> lgCV, g = (pos & ((1 << lgCV) - 1)) ^ (row & 15);
+      attn_buf_lds16(VT, (unsigned)(HD * a.vt_pitch * 2), Vs + p * 1024, g < vchunks ? (row * a.vt_pitch + g * 8) * 2 : 0x7ffffff0);
+    }
+    for (int p = wv; p < 8; p += 4) {                            // Q tile: 32 rows x 256 B
+      const int row = 4 * p + r4;
+      attn_buf_lds16(Q + (long)q0 * HD, (unsigned)(a.Sq - q0) * 256u, Qs + p * 1024, row * 256 + ((c16 ^ (row & 15)) << 4));
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (stamp) a.dbg[(long)blockIdx.x * 8 + 1] = wall_clock64();
+  bf16x8 qf[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) qf[s] = *(const bf16x8*)(Qs + j * 256 + (((2 * s + kh) ^ (j & 15)) << 4));
+  f32x16 o[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int t0 = (nt * w) >> 2, t1 = (nt * (w + 1)) >> 2;
+  const int pi = 16 * ((j >> 2) & 1) + (j & 3) + 4 * (j >> 3);  // A-row j carries key kt + pi
+  // one 32-key tile: scores (K fragments kf), online softmax, P V (V^T fragments vf)
+  auto tile = [&](int kt, const bf16x8 (&kf)[8], const bf16x8 (&vf)[2][4]) {
+    f32x16 s;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 8; ++st) s = mfma16<T>(kf[st], qf[st], s);
+    // s[e] = score(key kt + 16*kh + e, query q0 + j), kept in the log2 domain (scale2 = log2(e)/sqrt(128)):
+    // the exponentials are single v_exp_f32 instructions
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      s[e] = (kt + 16 * kh + e < a.Skv) ? s[e] * scale2 : -INFINITY;
+      mx = fmaxf(mx, s[e]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    float ps = 0.f;
+    bf16x8 pb[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float pv = __builtin_amdgcn_exp2f(s[e] - m_new);
+      ps += pv;
+      pb[e >> 3][e & 7] = to_carrier<T>(pv);
+    }
+    ps += __shfl_xor(ps, 32, 64);
+    // the 64 accumulator rescales only when some query's running maximum moved (rare after the first tiles)
+    if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // exp2(-inf) = 0 on the first tile
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+    }
+    l_run += ps;
+    m_run = m_new;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) o[d] = mfma16<T>(vf[u][d], pb[u], o[d]);
+  };
+  const int pk = (pi & 7) | ((pi >> 1) & 8);                    // source permutation of key row kt + pi (kt is a multiple of 32)
+  auto read_k = [&](int kt, bf16x8 (&kf)[8]) {
+    const unsigned char* kr = Ks + (kt + pi) * 256;
+#pragma unroll
+    for (int st = 0; st < 8; ++st) kf[st] = *(const bf16x8*)(kr + (((2 * st + kh) ^ pk) << 4));
+  };
+  auto read_v = [&](int kt, bf16x8 (&vf)[2][4]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int row = d * 32 + j;
+        vf[u][d] = *(const bf16x8*)(Vs + (row << (lgCV + 4)) + ((((kt >> 3) + 2 * kh + u) ^ (row & 15)) << 4));
+      }
+  };
+  if (t1 - t0 <= 2) {
+    // the usual case (<= 8 key tiles): the fragments of both tiles are requested before the first MFMA - one LDS round trip
+    bf16x8 k0[8], k1[8], v0[2][4], v1[2][4];
+    const int kta = t0 * 32, ktb = min(t0 + 1, nt - 1) * 32;
+    if (t1 > t0) {
+      read_k(kta, k0);
+      read_k(ktb, k1);
+      read_v(kta, v0);
+      read_v(ktb, v1);
+      tile(kta, k0, v0);
+      if (t1 - t0 == 2) tile(ktb, k1, v1);
+    }
+  } else {
+    for (int t = t0; t < t1; ++t) {
+      bf16x8 kf[8], vf[2][4];
+      read_k(t * 32, kf);
+      read_v(t * 32, vf);
+      tile(t * 32, kf, vf);
+    }
+  }
+
+  if (stamp) a.dbg[(long)blockIdx.x * 8 + 2] = wall_clock64();
+  // merge the four key ranges: wave w finalises d-fragment w
+  if (merge_off == 0) __syncthreads();   // the merge area aliases the images: every wave is done reading them
+  if (kh == 0) {
+    sM[w][j] = m_run;
+    sL[w][j] = l_run;
+  }
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    if (d == w) continue;
+    const int slot = d < w ? d : d - 1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sO[w][slot][e][lane] = o[d][e];
+  }
+  __syncthreads();
+  if (stamp) a.dbg[(long)blockIdx.x * 8 + 3] = wall_clock64();
+  float mstar = -INFINITY;
+#pragma unroll
+  for (int x = 0; x < 4; ++x) mstar = fmaxf(mstar, sM[x][j]);
+  float wt[4], L = 0.f;
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    wt[x] = __builtin_amdgcn_exp2f(sM[x][j] - mstar);   // running maxima live in the log2 domain
+    L += wt[x] * sL[x][j];
+  }
+  const int tok = q0 + j;
+  if (tok >= a.Sq) return;
+  const float inv = 1.0f / L;
+  OutT* dst;
+  if (tok < a.split) dst = (OutT*)a.outA + ((long)b * a.split + tok) * (a.H * HD);
+  else dst = (OutT*)a.outB + ((long)b * (a.Sq - a.split) + (tok - a.split)) * (a.H * HD);
+  dst += h * HD + w * 32;
+  const int slot_mine = 0;  // unused for own fragment
+  (void)slot_mine;
+  // four consecutive output dims ((e & 3) of one e >> 2 group) leave as ONE 8-byte (bf16) / 16-byte (fp32) store:
+  // sixteen 2-byte stores per lane made this tail 3.6 us of a 12 us kernel (tools/attn_timeline.py)
+  // One straight-line body per wave index (the index is wave-uniform): with `x == w` tested per element the 48 LDS
+  // reads of the partner fragments sat in 48 conditional regions, each waiting for its own read - 2.7 us of latency.
+  auto finish = [&](auto wc) {
+    constexpr int W = decltype(wc)::value;
+    float part[3][16];   // the other waves' partial O of d-fragment W
+#pragma unroll
+    for (int x = 0, n = 0; x < 4; ++x) {
+      if (x == W) continue;
+      const int slot = W < x ? W : W - 1;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) part[n][e] = sO[x][slot][e][lane];
+      ++n;
+    }
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      f32x4 r;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = g4 * 4 + u;
+        float acc = 0.f;
+#pragma unroll
+        for (int x = 0, n = 0; x < 4; ++x) {   // same summation order as before: x = 0..3
+          if (x == W) acc += wt[x] * o[W][e];
+          else acc += wt[x] * part[n++][e];
+        }
+        r[u] = acc * inv;
+      }
+      Pack4Out<OutT>::store(dst + 8 * g4 + 4 * kh, r);
+    }
+  };
+  switch (__builtin_amdgcn_readfirstlane(w)) {
+    case 0: finish(std::integral_constant<int, 0>{}); break;
+    case 1: finish(std::integral_constant<int, 1>{}); break;
+    case 2: finish(std::integral_constant<int, 2>{}); break;
+    default: finish(std::integral_constant<int, 3>{}); break;
+  }
+  if (stamp) a.dbg[(long)blockIdx.x * 8 + 4] = wall_clock64();
+}
+
 // ---------------------------------------------------------------------------------------------
 // bf16, large grids: a workgroup = 4 waves x 32 queries = 128 queries; every wave walks ALL key tiles
 // and the K / V^T tiles are staged once per workgroup in LDS (register-staged double buffer), so
@@ -529,8 +755,25 @@ int launch_attention(const AttnArgs& a_in, int out_dtype, hipStream_t st) {
     // (the conditioning encoders) exists in the wide form only
     const dim3 gw(((a.Sq + 127) / 128) * a.H * a.Bq);
     const bool wide = (long)gw.x >= 256 || hd == 64, h16 = a.in_dtype == FOLEY_F16, o32 = out_dtype == FOLEY_F32;
+    // small grids whose operands fit the LDS: the DMA-staged form (FOLEY_ATTN_LDS=0 keeps the register-loaded kernel)
+    static const bool lds_on = []() { const char* e = getenv("FOLEY_ATTN_LDS"); return !(e && e[0] == '0'); }();
+    const int nt = (a.Skv + 31) >> 5;
+    const long img = (long)nt * 32 * 256 + (128L << ((a.vt_pitch > 128 ? 5 : 4) + 4)) + 32 * 256, mrg = 4 * 3 * 16 * 64 * 4 + 2 * 4 * 32 * 4;
+    // (three key tiles or fewer - the 77 text keys - are a wash: 5.95 vs 6.2 us in the loop; single-block self-attention 8.4 -> 7.3 us)
+    const bool staged = lds_on && !wide && hd == 128 && nt >= 4 && a.vt_pitch <= 256 && img <= 160 * 1024;
+    const int merge_off = staged && img + mrg <= 160 * 1024 ? (int)img : 0;
+    const size_t lds16 = staged ? (size_t)(merge_off ? img + mrg : (img > mrg ? img : mrg)) : 0;
 #define FOLEY_ATTN16(T, O)                                                                         \
     do {                                                                                             \
+      if (staged) {                                                                                  \
+        static bool raised = false;                                                                  \
+        if (!raised) {                                                                               \
+          hipError_t e_ = hipFuncSetAttribute((const void*)attn_lds_kernel<T, O>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+          if (e_ != hipSuccess) return foley_set_err(hipGetErrorString(e_), __FILE__, __LINE__);     \
+          raised = true;                                                                             \
+        }                                                                                            \
+        FOLEY_LAUNCH((attn_lds_kernel<T, O>), grid1, dim3(256), lds16, st, a, merge_off);            \
+      } else                                                                                         \
       if (wide && hd == 64) FOLEY_LAUNCH((attn_bf16_wide_kernel<T, O, 64>), gw, dim3(256), 0, st, a);  \
       else if (wide) FOLEY_LAUNCH((attn_bf16_wide_kernel<T, O, 128>), gw, dim3(256), 0, st, a);        \
       else FOLEY_LAUNCH((attn_bf16_kernel<T, O>), grid1, dim3(256), 0, st, a);                         \
