@@ -588,7 +588,10 @@ __global__ __launch_bounds__(256) void attn_lds_kernel(const AttnArgs a, const i
 // re-reads them for each of its 32-query workgroups: ~10x at S = 290).  No cross-wave merge.
 // LDS rows are padded (K: 272 B, V^T: 80 B) so the 16-lane groups of ds_read_b128 hit distinct banks.
 template <typename T, typename OutT, int HD>
-__global__ __launch_bounds__(256) void attn_bf16_wide_kernel(const AttnArgs a) {
+// Three waves per SIMD: left to itself the compiler takes 166 VGPRs + 80 AGPRs (two waves per SIMD); capped at 168 registers the
+// kernel needs no AGPRs and no scratch, and three resident workgroups per CU hide each other's LDS / MFMA / softmax latencies:
+// S = 290, 16 clips: 39.0 -> 29.3 us; S = 1740 (30 s clip): 99 -> 77 us (tools/attn_bench.py).  Four (128 registers) spills.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bf16_wide_kernel(const AttnArgs a) {
   constexpr int KP = 2 * HD + 16, VP = 80;               // LDS row pitches in bytes
   constexpr int STG = 32 * KP + HD * VP;                 // one stage: K tile + V^T tile
   constexpr int NS = HD / 16, ND = HD / 32;              // k-steps of Q K^T, 32-wide output fragments
