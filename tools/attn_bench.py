@@ -39,5 +39,5 @@ for name, B, H, Sq, Skv, bdiv in SHAPES:
     torch.cuda.synchronize()
     us = 1e3 * e0.elapsed_time(e1) / n
     gf = 4.0 * B * H * Sq * Skv * 128 / 1e9
-        tf = gf / us * 1e3
+    tf = gf / us * 1e3
     print(f"{name:18s} B{B:3d} Sq{Sq:5d} Skv{Skv:5d}: {us:8.1f} us  {tf:7.1f} TFLOP/s ({tf / 2500:.3f} of the bf16 peak)")
