@@ -144,6 +144,10 @@ struct foley_ctx {
   void* hid_v = nullptr;            // T [Mv, mlp_hidden]
   void* svec = nullptr;             // T [ncfg*Ls, D]
   float* smod = nullptr;            // [ncfg*Ls, n_single*6D]
+  // the same table for EVERY loop iteration, built by foley_prepare when it fits (it depends on the iteration index only):
+  // [n_iter][ncfg*P][n_single*6D] fp32, P = sync_per or Ls; consumers add step * smod_step to their row address
+  DevBuf smod_tab, svec_tab;
+  bool smod_hoisted = false;
   float* pred = nullptr;            // [M, C]
   float *part_a = nullptr, *part_v = nullptr;   // deferred split-K partial products [PART_CAP][M | Mv][D]
   float* x_saved = nullptr;         // [clips, C, La]
@@ -268,6 +272,7 @@ static const void* zero_page() {
 
 // --------------------------------------------------------------------------- launch helpers
 static RowBcast rb_none() { return RowBcast{nullptr, 0, 0, 1, 1, nullptr, 0}; }
+static RowBcast rb_vec(const float* base, long step_stride, const int* step_ptr);
 
 // K ranges whose partial products a gated-residual GEMM may leave for the next LayerNorm to sum
 // (deferred split-K, kernels.h GemmArgs::partials)
@@ -351,7 +356,7 @@ extern "C" void foley_ctx_destroy(foley_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   ctx_free_plan(c);
-  for (DevBuf* b : {&c->dacP, &c->dacQ, &c->dacR, &c->dacZ})
+  for (DevBuf* b : {&c->dacP, &c->dacQ, &c->dacR, &c->dacZ, &c->smod_tab, &c->svec_tab})
     if (b->p) hipFree(b->p);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
@@ -633,6 +638,37 @@ extern "C" int foley_prepare(foley_ctx* c, const foley_plan* pl, void* stream_v)
     if (c->graph_exec && per != c->sync_per) ctx_drop_graph(c);   // the captured modulation GEMM has another M
     c->sync_per = per;
   }
+  if (!c->fw.ok) TRY(resolve_forward_weights(c));
+  {
+    // 6. The single-stream blocks' modulation, Linear(SiLU(add_sync + vec)) (hifi_foley.py:366, 866-867), depends on the loop
+    // iteration only (vec) and on the sync tokens - not on the latents.  Like the two-stream blocks' AdaLN tables it is therefore
+    // computed HERE for all n_iter iterations in one GEMM ([n_iter*ncfg*P, D] x [n_single*6D, D]^T; the 1.02 GB weight panel is
+    // streamed once per run instead of once per iteration: 0.21 ms x 50 -> ~1 ms at 5 s text-to-audio) when the table fits
+    // FOLEY_SMOD_TABLE_GB (default 24; 1.06 GB for the 16 distinct rows of text-to-audio, 14.9 GB for the 224 rows of a 5 s
+    // video clip); longer clips keep the per-iteration GEMM of run_forward.
+    static const double cap_gb = []() { const char* e = getenv("FOLEY_SMOD_TABLE_GB"); return e ? atof(e) : 24.0; }();
+    const int P = c->sync_per ? c->sync_per : Ls;
+    const size_t ncol = (size_t)f.depth_single * 6 * D;
+    const size_t tab_bytes = (size_t)NI * ncfg * P * ncol * 4;
+    // ... and only where the weight stream is what the per-iteration GEMM costs (a few distinct rows: the 8-periodic empty sync
+    // features).  With the 224 dense rows of a video clip the batched GEMM costs what the 50 small ones do (18.3 vs 19 ms).
+    const bool hoist = f.depth_single > 0 && ncfg * P <= 64 && (double)tab_bytes <= cap_gb * 1073741824.0;
+    if (c->graph_exec && hoist != c->smod_hoisted) ctx_drop_graph(c);
+    c->smod_hoisted = false;
+    if (hoist) {
+      const void* old_tab = c->smod_tab.p;
+      TRY(grow(c->smod_tab, tab_bytes));
+      TRY(grow(c->svec_tab, (size_t)NI * ncfg * Ls * D * es));
+      if (c->graph_exec && old_tab != c->smod_tab.p) ctx_drop_graph(c);   // captured kernels hold the table's address
+      for (int it = 0; it < NI; ++it)
+        TRY(launch_rows_add_act(c->sync_tok, rb_vec(c->vec_table + (size_t)it * D, 0, nullptr), ncfg * Ls, D, 1,
+                                (char*)c->svec_tab.p + (size_t)it * ncfg * Ls * D * es, T, st));
+      GemmArgs gm = gemm_plain(c->svec_tab.p, NI * ncfg * P, c->fw.smod, c->smod_tab.p, (long)ncol);
+      gm.segV = P; gm.segS = Ls;     // virtual rows: row r of the product is token r % P of (iteration, half) r / P
+      TRY(launch_gemm(gm, T, EPI_STORE_F32, 0, st));
+      c->smod_hoisted = true;
+    }
+  }
   {
     // the plan's table must be the nearest-exact map the kernels compute in their addressing
     std::vector<int> tab((size_t)La);
@@ -641,7 +677,6 @@ extern "C" int foley_prepare(foley_ctx* c, const foley_plan* pl, void* stream_v)
     for (int l = 0; l < La; ++l)
       if (tab[l] != rb_nearest_exact(l, scale, Ls)) return FAIL(FOLEY_ERR_INVALID, "plan.sync_gather is not the nearest-exact up-sampling table");
   }
-  if (!c->fw.ok) TRY(resolve_forward_weights(c));
   c->prepared = true;
   return 0;
 }
@@ -714,7 +749,7 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
   // and every single block's modulation GEMM (hifi_foley.py:366).  They depend on the iteration only, are
   // identical for every clip of a CFG half, and - add_sync being an up-sampling of the Ls sync tokens - have
   // only Ls distinct rows per half: M = ncfg*Ls (224 instead of 500 at 5 s).  In line by default (smod_inline()).
-  {
+  if (!c->smod_hoisted) {
     const bool inl = c->prof.on || smod_inline();
     hipStream_t sd = inl ? st : c->side;
     if (!inl) {
@@ -844,12 +879,19 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
   }
 
   // join: the single blocks' modulation table is ready (profiling ran it in line)
-  if (!c->prof.on && !smod_inline()) HIPTRY(hipStreamWaitEvent(st, c->ev_mod[0], 0));
+  if (!c->smod_hoisted && !c->prof.on && !smod_inline()) HIPTRY(hipStreamWaitEvent(st, c->ev_mod[0], 0));
   const int Hc = f.conv_hidden;
   for (int blk = 0; blk < f.depth_single; ++blk) {
     const SingleW& w = W.s[blk];
-    const float* smod_b = c->smod + (size_t)blk * 6 * D;   // column block of the fused table
-    auto sm = [&](int chunk) { return rb_up(smod_b + (size_t)chunk * D, 6L * D * f.depth_single, clips * La, La, Ls, c->sync_per); };
+    const float* smod_b = (c->smod_hoisted ? (const float*)c->smod_tab.p : c->smod) + (size_t)blk * 6 * D;   // column block of the fused table
+    auto sm = [&](int chunk) {
+      RowBcast r = rb_up(smod_b + (size_t)chunk * D, 6L * D * f.depth_single, clips * La, La, Ls, c->sync_per);
+      if (c->smod_hoisted) {   // the table of every iteration: this iteration's rows start at step * ncfg*P*ld
+        r.step_ptr = sp;
+        r.step_stride = (long)ncfg * (c->sync_per ? c->sync_per : Ls) * 6L * D * f.depth_single;
+      }
+      return r;
+    };
     PROF("single.layernorm+modulate (+pending split-K sum)", 0.0, ln_bytes_s,
          launch_ln_mod_pending(c->audio, M, D, 1e-5f, sm(0), sm(1), c->xn_a, T, pend[0], st));
     pend[0] = LnPending{};

@@ -479,7 +479,10 @@ int launch_one(const GemmArgs& g, const GemmArgs* g1, hipStream_t st) {
   const int tiles = pr.tiles0 + (g1 ? ntiles(*g1) : 0);
   constexpr size_t lds = GLDS ? (size_t)NS * (BM + BN) * 128 : 2 * (size_t)(BM + BN) * LDS_PITCH;
   void (*k)(const GemmPair);
-  const bool conv = g.taps > 1 || (g1 && g1->taps > 1);
+  // CONV = the row -> (segment, position) mapping is live: taps, a strided walk, or virtual rows that skip source rows
+  // (segV != segS: the modulation GEMM over the first P tokens of every (iteration, half) segment)
+  auto mapped = [](const GemmArgs& q) { return q.taps > 1 || q.rstride > 1 || (q.segV != q.segS && q.segV < q.M); };
+  const bool conv = mapped(g) || (g1 && mapped(*g1));
   if constexpr (GLDS) k = gemm_glds_kernel<T, BM, BN, WM, WN, NS, EPI>;
   else k = conv ? gemm_kernel<T, BM, BN, WM, WN, NS, EPI, true> : gemm_kernel<T, BM, BN, WM, WN, NS, EPI, false>;
   if (lds > 64 * 1024) {

@@ -364,8 +364,8 @@ def rowbcast(t: Optional[torch.Tensor], mode: int = 0, rows_per_cfg: int = 1, L:
 def op_gemm(A, W, bias=None, *, M=None, epilogue=EPI_STORE_F32, out0=None, out1=None, ldc=None, conv=None,
             convT=None, rb: Optional[RowBcastC] = None, res=None, alpha=None, alphaC=1, tile=0, ksplit=0,
             partials=None, qkv: Optional["QkvSplitDescC"] = None, sconv=None, lda: Optional[int] = None,
-            ldw: Optional[int] = None, NK=None, gelu_erf: bool = False) -> int:
-    """Thin wrapper over foley_op_gemm.  conv=(seg, C, taps, dil) ; convT=(Tin, Cin, stride, Cout) ;
+            ldw: Optional[int] = None, NK=None, gelu_erf: bool = False, vrows=None) -> int:
+    """Thin wrapper over foley_op_gemm.  conv=(seg, C, taps, dil) ; convT=(Tin, Cin, stride, Cout) ; vrows=(segV, segS) with M ;
     sconv=(Tin, Cin, stride): strided conv k=2*stride, pad ceil(stride/2) over clips of Tin rows.
     partials: fp32 [slabs, M, N] workspace for the deferred split-K of the gated-residual epilogue.
     Returns the K split the launcher used."""
@@ -406,6 +406,8 @@ def op_gemm(A, W, bias=None, *, M=None, epilogue=EPI_STORE_F32, out0=None, out1=
         d.lda = K
         d.segV, d.segS, d.taps, d.tapC, d.dil, d.tap0 = d.M, d.M, 1, K, 1, 0
         d.osegV, d.out_seg, d.out_row, d.out_shift, d.out_check = d.M, 0, (ldc or N), 0, 0
+    if vrows is not None:      # virtual rows: row r of the product reads source row (r // segV) * segS + r % segV
+        d.segV, d.segS = vrows
     if epilogue == EPI_SILUGATE_T and ldc is None and convT is None:
         d.out_row = N // 2
     if lda is not None:

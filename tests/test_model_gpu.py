@@ -580,11 +580,13 @@ def test_profile_forward_brackets(tiny):
     assert by["triple.layernorm+modulate (+pending split-K sum)"]["calls_per_forward"] == 3 * nt
     assert by["triple.self attention"]["calls_per_forward"] == nt and by["final.linear"]["calls_per_forward"] == 1
     assert all(e["avg_us"] > 0 for e in prof) and 0 <= bracket_us < 100
-    # bracketed FLOPs == the per-forward algorithmic count minus the step-invariant (hoisted) part
+    # bracketed FLOPs == the per-forward algorithmic count minus the step-invariant (hoisted) part.  At 1 s the single blocks'
+    # modulation has 2 x 16 distinct rows (the sync tokens): few enough that foley_prepare computes it for ALL iterations in one
+    # GEMM (foley_rt.hip step 6), so it is not part of the forward any more
     D, M, Mv, Lt, H, Hc = 256, 2 * 50, 2 * 8, 77, 2, C.TINY.conv_hidden
-    Ms = 2 * C.lengths(1.0)[2]           # the single blocks' modulation runs on the sync tokens (16 per half at 1 s), not on the audio frames
+    assert "single.modulation (all blocks, one GEMM)" not in by
     lin = (2 * D * D * nt * 14 * (M + Mv) + ns * 2 * M * (6 * D * D + 9 * Hc * D)    # qkv, lin1(k3), w1/w3(k3), w2(k3)
-           + 2 * (M * 128 * D * 2) + 2 * Ms * D * ns * 6 * D)                         # audio_in + final, modulation
+           + 2 * (M * 128 * D * 2))                                                    # audio_in + final
     att = 4 * H * 128 * (nt * 2 * ((50 + 8) ** 2 + (50 + 8) * Lt) + ns * 2 * 50 * 50)
     total = sum(e["flop_per_launch"] * e["calls_per_forward"] for e in prof)
     assert abs(total - (lin + att)) / (lin + att) < 1e-6
@@ -592,18 +594,28 @@ def test_profile_forward_brackets(tiny):
     y1 = model.ctx.dit_forward(lat, 1)
     y2 = model.ctx.dit_forward(lat, 1)
     assert torch.equal(y1, y2)
-    # text-to-audio: both halves carry the empty sync feature, whose tokens repeat every 8 (sync_pos_emb) - foley_prepare
-    # finds that on the data and the modulation GEMM runs on 2 x 8 rows; the forward is still the oracle's
-    cond_t = synth.synth_conditioning(C.TINY, 1.0, t2a=True, sd=sd)
+    # 5 s of video: 2 x 112 dense sync rows - the modulation GEMM stays in the loop, on the sync tokens (not on the 250 audio frames)
+    La5, _lv5, Ls5 = C.lengths(5.0)
+    lat5 = torch.randn(1, 128, La5, device=model.device)
+    cond5 = synth.synth_conditioning(C.TINY, 5.0, t2a=False)
+    plan5 = sampler.build_plan(model, {"siglip2_feat": cond5["clip"], "syncformer_feat": cond5["sync"]},
+                               {"text_feat": cond5["text"], "uncond_text_feat": cond5["uncond_text"]}, La5, 4.5, 4, 1, "euler")
+    model.ctx.prepare(plan5)
+    prof5, _ = model.ctx.profile_forward(lat5, it=1, repeats=1)
+    smod = {e["label"]: e for e in prof5}["single.modulation (all blocks, one GEMM)"]
+    assert abs(smod["flop_per_launch"] - 2 * (2 * Ls5) * D * ns * 6 * D) < 1
+    y5 = model.ctx.dit_forward(lat5, 1)
+    # 5 s text-to-audio: both halves carry the empty sync feature, whose tokens repeat every 8 (sync_pos_emb) - foley_prepare finds
+    # that on the data: 2 x 8 distinct rows, hoisted out of the loop
+    cond_t = synth.synth_conditioning(C.TINY, 5.0, t2a=True, sd=sd)
     plan_t = sampler.build_plan(model, {"siglip2_feat": cond_t["clip"], "syncformer_feat": cond_t["sync"]},
-                                {"text_feat": cond_t["text"], "uncond_text_feat": cond_t["uncond_text"]}, 50, 4.5, 4, 1, "euler")
+                                {"text_feat": cond_t["text"], "uncond_text_feat": cond_t["uncond_text"]}, La5, 4.5, 4, 1, "euler")
     model.ctx.prepare(plan_t)
-    prof_t, _ = model.ctx.profile_forward(lat, it=1, repeats=1)
-    smod = {e["label"]: e for e in prof_t}["single.modulation (all blocks, one GEMM)"]
-    assert abs(smod["flop_per_launch"] - 2 * (2 * 8) * D * ns * 6 * D) < 1
-    model.ctx.prepare(plan)      # back to the video-conditioned plan: the full token set again
-    prof_v, _ = model.ctx.profile_forward(lat, it=1, repeats=1)
-    assert abs({e["label"]: e for e in prof_v}["single.modulation (all blocks, one GEMM)"]["flop_per_launch"] - 2 * Ms * D * ns * 6 * D) < 1
+    prof_t, _ = model.ctx.profile_forward(lat5, it=1, repeats=1)
+    assert "single.modulation (all blocks, one GEMM)" not in {e["label"] for e in prof_t}
+    model.ctx.prepare(plan5)     # back to the video-conditioned plan: the full token set, the in-loop GEMM again
+    assert torch.equal(model.ctx.dit_forward(lat5, 1), y5)
+    model.ctx.prepare(plan)
     assert torch.equal(model.ctx.dit_forward(lat, 1), y1)
 
 

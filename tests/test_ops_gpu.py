@@ -60,6 +60,25 @@ def test_gemm_linear(dev, dtype, M, N, K, tile):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5, 15, 25])
+@pytest.mark.parametrize("segs,segV,segS", [(10, 8, 16), (100, 8, 112), (3, 40, 41)])
+def test_gemm_virtual_rows_skip_source_rows(dev, dtype, tile, segs, segV, segS):
+    """Plain linear layer over VIRTUAL rows (kernels.h): row r of the product reads source row (r // segV) * segS + r % segV -
+    the single-block modulation GEMM runs on the first P tokens of every (iteration, CFG half) segment of Ls tokens
+    (foley_rt.hip foley_prepare step 6 / run_forward).  Every mainloop family must honour the mapping (the register-staged
+    tiles once ignored it for taps == 1: invisible while both CFG halves carried identical rows)."""
+    if tile in (15, 25) and dtype == torch.float32:
+        pytest.skip("wave-specialised tiles are 16-bit only")
+    K, N = 256, 384
+    A, W, b = _rand((segs * segS, K), 71), _rand((N, K), 72, 1 / math.sqrt(K)), _rand((N,), 73, 0.1)
+    idx = (torch.arange(segs)[:, None] * segS + torch.arange(segV)[None]).reshape(-1)
+    ref = F.linear(_q(A, dtype)[idx], _q(W, dtype), b)
+    out = torch.full((segs * segV, N), float("nan"), device=dev)
+    rt.op_gemm(A.to(dev, dtype), W.to(dev, dtype), b.to(dev), out0=out, M=segs * segV, vrows=(segV, segS), tile=tile)
+    assert rel_err(out, ref) < _tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("tile", [0, 3, 5, 6])
 def test_gemm_transpose_detecting(dev, dtype, tile):
     """A = I with an asymmetric W: catches a swapped C/D row/column mapping (and, for the
