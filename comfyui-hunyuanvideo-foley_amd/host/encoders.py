@@ -46,19 +46,19 @@ def select_frames(image: Tensor, duration: float, frame_rate: float, device=None
     `linspace(0, n-1, int(duration*fps)).long()`.
 
     The reference converts the WHOLE padded clip to uint8 on the CPU and then selects; the result only depends on the
-    selected frames, so they are gathered first (an index beyond the clip's end is the held last frame) and - with
-    `device` - converted on the GPU: the same float32 multiply and truncating cast, 0.6 s of CPU time less per 5 s clip."""
+    selected frames, so only the range they span is touched (an index beyond the clip's end is the held last frame) and -
+    with `device` - it is copied to the GPU first and converted there: the same float32 multiply and truncating cast,
+    0.5 s of CPU time less per 5 s clip."""
     total = image.shape[0]
     n = int(duration * frame_rate)
     i8 = torch.linspace(0, n - 1, int(duration * FPS_SIGLIP)).long().clamp_(max=total - 1)
     i25 = torch.linspace(0, n - 1, int(duration * FPS_SYNC)).long().clamp_(max=total - 1)
-    uniq, inv = torch.unique(torch.cat((i8, i25)), return_inverse=True)
-    sel = image.index_select(0, uniq.to(image.device))
+    lo, hi = int(min(i8.min(), i25.min())), int(max(i8.max(), i25.max()))
+    block = image[lo:hi + 1]                       # a view: ONE contiguous host-to-device copy, no gather on the CPU
     if device is not None:
-        sel = sel.to(device)
-    frames = (sel * 255.0).byte().permute(0, 3, 1, 2)
-    inv = inv.to(frames.device)
-    return frames.index_select(0, inv[:i8.numel()]), frames.index_select(0, inv[i8.numel():])
+        block = block.to(device)
+    frames = (block * 255.0).byte().permute(0, 3, 1, 2)
+    return frames.index_select(0, (i8 - lo).to(frames.device)), frames.index_select(0, (i25 - lo).to(frames.device))
 
 
 # ----------------------------------------------------------------------------- pre-processing

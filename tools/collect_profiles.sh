@@ -2,9 +2,9 @@
 # Runs on the GPU box (via gpurun): bench lines, rocprofv3 kernel-trace stats of the bench command and
 # the PMC passes (separate runs, kernel filter - rocprofv3 segfaults in PyTorch's own kernels
 # otherwise), summarised into gpurun_out/ (the raw databases stay in /tmp: too large to ship back).
-#   gpurun --timeout 1800 -- 'bash tools/collect_profiles.sh r02 [tag-suffix]'
+#   gpurun --timeout 1800 -- 'bash tools/collect_profiles.sh r03 [tag-suffix]'
 set -u
-TAG=${1:-r02}${2:+_$2}
+TAG=${1:-r03}${2:+_$2}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out
 mkdir -p $OUT
@@ -13,14 +13,18 @@ FILTER='gemm_|attn_|ln_mod|qkv_split|solver_step|dac_|rows_add|latent_rows|gathe
 
 python $R/bench.py --steps 5 --warmup 2 > $OUT/${TAG}_bench_c2.json 2> $OUT/${TAG}_bench_c2.err
 tail -c 400 $OUT/${TAG}_bench_c2.json
-python $R/bench.py --config c3 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_bench_c3.json 2> $OUT/${TAG}_bench_c3.err
-python $R/bench.py --config c5 --steps 2 --warmup 1 > $OUT/${TAG}_bench_c5.json 2> $OUT/${TAG}_bench_c5.err
+python $R/bench.py --config c3 --with-encoders --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $OUT/${TAG}_bench_c3.json 2> $OUT/${TAG}_bench_c3.err
+python $R/bench.py --config c4 --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $OUT/${TAG}_bench_c4_1gpu.json 2> $OUT/${TAG}_bench_c4.err
+python $R/bench.py --config c5 --steps 2 --warmup 1 --no-extra > $OUT/${TAG}_bench_c5.json 2> $OUT/${TAG}_bench_c5.err
+python $R/bench.py --precision fp16 --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $OUT/${TAG}_bench_c2_fp16.json 2> $OUT/${TAG}_bench_fp16.err
 
 # kernel-trace stats of the bench command itself (1 timed pass + the event-timed loop / decode)
 rocprofv3 --kernel-trace --stats -d /tmp/kt1 -o kt -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > /tmp/kt1.log 2>&1
 python $R/tools/prof_summary.py $(find /tmp/kt1 -name "*.db" | head -1) > $OUT/${TAG}_bench_bs1_kernel_stats.md
 rocprofv3 --kernel-trace --stats -d /tmp/kt8 -o kt -- python $R/bench.py --steps 1 --warmup 0 --bs 8 --no-cpu-baseline --no-extra > /tmp/kt8.log 2>&1
 python $R/tools/prof_summary.py $(find /tmp/kt8 -name "*.db" | head -1) > $OUT/${TAG}_bench_bs8_kernel_stats.md
+rocprofv3 --kernel-trace --stats -d /tmp/kt5 -o kt -- python $R/bench.py --config c5 --steps 1 --warmup 0 --no-cpu-baseline --no-extra > /tmp/kt5.log 2>&1
+python $R/tools/prof_summary.py $(find /tmp/kt5 -name "*.db" | head -1) > $OUT/${TAG}_bench_c5_kernel_stats.md
 
 # PMC passes on 2 loop iterations (profile_run.py --no-dac), one counter set per run (FETCH_SIZE and
 # WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md "rocprofv3 PMC slots")
