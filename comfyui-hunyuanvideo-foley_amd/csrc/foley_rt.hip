@@ -494,7 +494,7 @@ extern "C" int foley_prepare(foley_ctx* c, const foley_plan* pl, void* stream_v)
     ALLOC(c->svec, (size_t)ncfg * Ls * D * es);
     ALLOC(c->smod, (size_t)f.depth_single * ncfg * Ls * 6 * D * 4);
     ALLOC(c->pred, (size_t)M * C * 4);
-    ALLOC(c->part_a, (size_t)PART_CAP * M * D * 4);
+    ALLOC(c->part_a, (size_t)PART_CAP * M * D * 4);     // sized for fp32 slabs; 16-bit slabs (slab16()) use half of it
     ALLOC(c->part_v, (size_t)PART_CAP * Mv * D * 4);
     ALLOC(c->x_saved, (size_t)clips * C * La * 4);
     ALLOC(c->d_acc, (size_t)clips * C * La * 4);
@@ -785,7 +785,12 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
   // residual updates left pending by deferred split-K GEMMs, per stream (audio, visual); the next
   // LayerNorm of that stream applies them
   LnPending pend[2] = {LnPending{}, LnPending{}};
+  // deferred split-K slabs in the operand type (bf16 / fp16 compute): half the bytes the GEMM epilogues write and the next
+  // LayerNorm reads (that kernel runs at the fabric's bandwidth: 22 MB in 3.4 us at M = 500).  FOLEY_SLAB16=0 keeps fp32.
+  static const bool slab16_on = []() { const char* e = getenv("FOLEY_SLAB16"); return !(e && e[0] == '0'); }();
+  const int slab_half = (bf && slab16_on) ? T : 0;
   auto with_partials = [&](GemmArgs& g, float* slabs) {
+    g.partial_half = slab_half ? 1 : 0;
     g.partials = slabs;
     g.partial_stride = (long)g.M * g.N;
     g.partial_cap = PART_CAP;
@@ -819,8 +824,8 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
       PROF(label, gf(M + Mv, la.N, la.K), gb(M + Mv, la.N, la.K, 4) + (double)la.N * la.K * es,
            launch_gemm_pair(g0, g1, T, EPI_GATE_RES, st, &ks));
       if (ks > 1) {
-        pend[0] = LnPending{c->part_a, ks, g0.partial_stride, la.b, g0.rb};
-        pend[1] = LnPending{c->part_v, ks, g1.partial_stride, lv.b, g1.rb};
+        pend[0] = LnPending{c->part_a, ks, g0.partial_stride, la.b, g0.rb, slab_half};
+        pend[1] = LnPending{c->part_v, ks, g1.partial_stride, lv.b, g1.rb, slab_half};
       }
       return 0;
     };
@@ -917,7 +922,7 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
       with_partials(g, c->part_a);
       int ks = 1;
       PROF("single.linear1 conv3 GEMM (gated residual)", gf(M, D, 3 * D), gb(M, D, 3 * D, 4), launch_gemm(g, T, EPI_GATE_RES, 0, st, &ks));
-      if (ks > 1) pend[0] = LnPending{c->part_a, ks, g.partial_stride, w.lin1.b, g.rb};
+      if (ks > 1) pend[0] = LnPending{c->part_a, ks, g.partial_stride, w.lin1.b, g.rb, slab_half};
     }
     PROF("single.layernorm+modulate (+pending split-K sum)", 0.0, ln_bytes_s,
          launch_ln_mod_pending(c->audio, M, D, 1e-5f, sm(3), sm(4), c->xn_a, T, pend[0], st));
@@ -930,7 +935,7 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
       with_partials(g, c->part_a);
       int ks = 1;
       PROF("single.w2 conv3 GEMM (gated residual)", gf(M, D, 3 * Hc), gb(M, D, 3 * Hc, 4), launch_gemm(g, T, EPI_GATE_RES, 0, st, &ks));
-      if (ks > 1) pend[0] = LnPending{c->part_a, ks, g.partial_stride, w.w2.b, g.rb};
+      if (ks > 1) pend[0] = LnPending{c->part_a, ks, g.partial_stride, w.w2.b, g.rb, slab_half};
     }
   }
 
@@ -1313,6 +1318,8 @@ extern "C" int foley_op_gemm(const foley_gemm_desc* d, void* stream) {
   if (d->partials) {
     if (d->partial_slabs < 1) return FAIL(FOLEY_ERR_INVALID, "partials need partial_slabs >= 1");
     g.partials = d->partials; g.partial_stride = (long)d->M * d->N; g.partial_cap = d->partial_slabs;
+    g.partial_half = d->partial_dtype != 0;
+    if (d->partial_dtype != 0 && d->partial_dtype != d->dtype) return FAIL(FOLEY_ERR_INVALID, "partial_dtype must be 0 (fp32) or the operand dtype");
   }
   g.zeros = zero_page();
   if (g.segV < 1 || g.segS < 1 || g.osegV < 1 || g.taps < 1) return FAIL(FOLEY_ERR_INVALID, "bad GEMM descriptor");
@@ -1349,12 +1356,19 @@ extern "C" int foley_op_ln_mod(const float* x, int M, int D, float eps, const fo
   return launch_ln_mod(x, M, D, eps, to_rb(shift), to_rb(scale), out, out_dtype, (hipStream_t)stream);
 }
 
+extern "C" int foley_op_ln_mod_pending2(float* x, int M, int D, float eps, const foley_rowbcast* shift,
+                                        const foley_rowbcast* scale, void* out, int out_dtype, const void* partials,
+                                        int partial_dtype, int k, const float* bias, const foley_rowbcast* gate, void* stream) {
+  if (!partials || k < 1 || !gate) return FAIL(FOLEY_ERR_INVALID, "pending split-K: partials, k >= 1 and a gate are required");
+  if (partial_dtype != 0 && partial_dtype != out_dtype) return FAIL(FOLEY_ERR_INVALID, "pending split-K: 16-bit slabs must have the output dtype");
+  LnPending p{(const float*)partials, k, (long)M * D, bias, to_rb(gate), partial_dtype};
+  return launch_ln_mod_pending(x, M, D, eps, to_rb(shift), to_rb(scale), out, out_dtype, p, (hipStream_t)stream);
+}
+
 extern "C" int foley_op_ln_mod_pending(float* x, int M, int D, float eps, const foley_rowbcast* shift,
                                        const foley_rowbcast* scale, void* out, int out_dtype, const float* partials,
                                        int k, const float* bias, const foley_rowbcast* gate, void* stream) {
-  if (!partials || k < 1 || !gate) return FAIL(FOLEY_ERR_INVALID, "pending split-K: partials, k >= 1 and a gate are required");
-  LnPending p{partials, k, (long)M * D, bias, to_rb(gate)};
-  return launch_ln_mod_pending(x, M, D, eps, to_rb(shift), to_rb(scale), out, out_dtype, p, (hipStream_t)stream);
+  return foley_op_ln_mod_pending2(x, M, D, eps, shift, scale, out, out_dtype, partials, 0, k, bias, gate, stream);
 }
 
 extern "C" int foley_op_qkv_split(const float* qkv, int M, int L, int H, int nK, const float* const* gain,

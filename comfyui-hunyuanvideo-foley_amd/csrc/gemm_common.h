@@ -103,7 +103,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[F
             ((float*)g.out0)[off] = v;
           } else if constexpr (EPI == EPI_GATE_RES) {
             float* x = (float*)g.out0;
-            if (g.ksplit > 1 && g.partials) g.partials[ks * g.partial_stride + (long)row * g.N + col] = v;
+            if (g.ksplit > 1 && g.partials) {
+              const long po = ks * g.partial_stride + (long)row * g.N + col;
+              if (g.partial_half) ((T*)g.partials)[po] = Cvt<T>::to(v);
+              else g.partials[po] = v;
+            }
             else if (g.ksplit > 1) unsafeAtomicAdd(x + off, v * rbp[col]);  // global_atomic_add_f32
             else x[off] = x[off] + v * rbp[col];
           } else if constexpr (EPI == EPI_DAC) {
@@ -247,6 +251,22 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
 
   if constexpr (EPI == EPI_GATE_RES) {
     if (g.ksplit > 1) {   // deferred split-K: raw partial product of this K range
+      if (g.partial_half) {   // slabs in the operand type: 8-byte stores of four rounded partials
+        if constexpr (sizeof(T) == 2) {
+          T* ps = (T*)g.partials + ks * g.partial_stride + gcol;
+#pragma unroll
+          for (int p = 0; p < PASSES; ++p) {
+            const int row = row0 + p * RP;
+            if (!(col_ok && row < g.M)) continue;
+            const f32x4 a = *(const f32x4*)(tile + (p * RP + tr) * BN + ca);
+            uint2 w;
+            w.x = pack_h2<T>(a[0], a[1]);
+            w.y = pack_h2<T>(a[2], a[3]);
+            *(uint2*)(ps + (long)row * g.N) = w;
+          }
+        }
+        return;
+      }
       float* ps = g.partials + ks * g.partial_stride + gcol;
 #pragma unroll
       for (int p = 0; p < PASSES; ++p) {

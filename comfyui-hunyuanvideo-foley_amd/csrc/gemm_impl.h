@@ -554,6 +554,7 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     return foley_set_err("GEMM: K / tap width / lda must be multiples of the 128-byte K-slice", __FILE__, __LINE__);
   if (((uintptr_t)g.A | (uintptr_t)g.W) & 15)
     return foley_set_err("GEMM: operands must be 16-byte aligned", __FILE__, __LINE__);
+  if (g.partial_half && sizeof(T) != 2) return foley_set_err("GEMM: 16-bit partial slabs need 16-bit operands", __FILE__, __LINE__);
   if (g.wfmt && sizeof(T) != 2) return foley_set_err("GEMM: fp8 weight storage needs bf16 operands", __FILE__, __LINE__);
   if (g.wfmt && g1 && g1s.wfmt != g.wfmt) return foley_set_err("GEMM: the two problems of a launch must share the weight format", __FILE__, __LINE__);
   // tap-fused wave-specialised conv3 (tile 21): bf16 operands (any weight storage), dense k=3 'same' conv
@@ -697,7 +698,7 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     if (g1 && !g1s.partials) cap = 1;
     if (g.ksplit > cap) g.ksplit = cap < 1 ? 1 : cap;
   }
-  if (g1) g1s.ksplit = g.ksplit;
+  if (g1) { g1s.ksplit = g.ksplit; g1s.partial_half = g.partial_half; }
   if (ksplit_used) *ksplit_used = g.ksplit;
   {
     // the direct-to-LDS loop addresses its operands through 32-bit buffer offsets

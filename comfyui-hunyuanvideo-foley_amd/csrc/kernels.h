@@ -72,7 +72,9 @@ struct GemmArgs {
   // product to partials + s*partial_stride ([M, N] row-major fp32, vector stores) instead of using
   // atomics; the LayerNorm that consumes the residual stream next finishes
   // x += gate * (sum_s partial_s + bias) (LnPending).  partial_cap = slabs available (caps ksplit).
-  float* partials;
+  float* partials;    // slab base (fp32 view; with partial_half the slabs hold the 16-bit OPERAND type, 2 bytes per element)
+  int partial_half;   // 1: slabs are stored in the operand type T (bf16 / fp16) - half the slab bytes written here and read by
+                      // the LayerNorm; the sum of k rounded partials carries about the error of ONE rounding of the total
   long partial_stride;
   int partial_cap;
   QkvSplitArgs qs;    // EPI_QKV_SPLIT: destination / norm / rotation description (qs.qkv, qs.M unused)
@@ -137,6 +139,7 @@ struct LnPending {
   long stride;
   const float* bias;      // [D] or null
   RowBcast gate;
+  int half;               // 0: fp32 slabs; FOLEY_BF16 / FOLEY_F16: slabs in that 16-bit type (GemmArgs::partial_half)
 };
 struct LnArgs {
   float* x;

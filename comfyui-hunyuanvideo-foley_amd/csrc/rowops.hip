@@ -2,6 +2,7 @@
 // elementwise helpers, the solver update and the DAC output convolution.  All arithmetic fp32;
 // one wavefront per row with 16-byte vector accesses and wave-level (DPP) reductions.
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -38,6 +39,18 @@ template <> struct Pack4<f16_t> {
   }
 };
 
+// four consecutive partial products of a slab row: fp32, or the 16-bit operand type
+template <typename ST> __device__ __forceinline__ f32x4 slab_load4(const void* base, long elem) {
+  if constexpr (sizeof(ST) == 4) {
+    return *(const f32x4*)((const float*)base + elem);
+  } else {
+    const uint2 w = *(const uint2*)((const ST*)base + elem);
+    const ST* h = (const ST*)&w;
+    f32x4 v = {Cvt<ST>::from(h[0]), Cvt<ST>::from(h[1]), Cvt<ST>::from(h[2]), Cvt<ST>::from(h[3])};
+    return v;
+  }
+}
+
 // One wave per row; every global load of the row (x, shift, scale) is issued before the first
 // reduction so the kernel pays one memory round trip, results leave as 8/16-byte vector stores.
 struct LnPair {
@@ -48,8 +61,10 @@ struct LnPair {
 static long long* g_ln_dbg = nullptr;
 extern "C" void foley_debug_ln_timeline(void* p) { g_ln_dbg = (long long*)p; }
 
-template <typename OutT, int MAXV, bool PEND>
+// SLAB16: the pending slabs hold OutT (a 16-bit type) instead of fp32
+template <typename OutT, int MAXV, bool PEND, bool SLAB16 = false>
 __global__ __launch_bounds__(128) void ln_mod_kernel(const LnPair pr, int D, float eps) {
+  using ST = typename std::conditional<SLAB16, OutT, float>::type;   // slab element type
   const int sel = (int)blockIdx.x >= pr.blocks0 ? 1 : 0;
   const LnArgs& A = pr.a[sel];
   float* __restrict__ x = A.x;
@@ -92,9 +107,9 @@ __global__ __launch_bounds__(128) void ln_mod_kernel(const LnPair pr, int D, flo
 #pragma unroll
       for (int u = 0; u < SB; ++u) {
         const int s = min(s0 + u, P.k - 1);
-        const f32x4* pr_ = (const f32x4*)(P.partials + s * P.stride + (long)row * D);
+        const long pe = s * P.stride + (long)row * D;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) t[u][i] = pr_[min(lane + i * 64, nv - 1)];
+        for (int i = 0; i < MAXV; ++i) t[u][i] = slab_load4<ST>(P.partials, pe + 4L * min(lane + i * 64, nv - 1));
       }
 #pragma unroll
       for (int u = 0; u < SB; ++u) {
@@ -148,8 +163,9 @@ __global__ __launch_bounds__(128) void ln_mod_kernel(const LnPair pr, int D, flo
 // SEL (which row set of the pair) is a template parameter: argument fields are then loaded at constant
 // kernel-argument offsets, in a few wide scalar loads at entry, instead of one dependent dword at a time
 // in front of the first global load of this latency-bound kernel (same reason as gemm_ws_body).
-template <typename OutT, int MAXV, bool PEND, int WPR, int SEL>
+template <typename OutT, int MAXV, bool PEND, int WPR, int SEL, bool SLAB16>
 __device__ __forceinline__ void ln_mod_wide_body(const LnPair& pr, int D, float eps) {
+  using ST = typename std::conditional<SLAB16, OutT, float>::type;   // slab element type
   __shared__ float red[2][2][WPR];   // [row of the block][statistic][wave of the row]
   constexpr int sel = SEL;
   const LnArgs& A = pr.a[SEL];
@@ -191,9 +207,9 @@ __device__ __forceinline__ void ln_mod_wide_body(const LnPair& pr, int D, float 
 #pragma unroll
       for (int u = 0; u < SB; ++u) {
         const int s = min(s0 + u, P.k - 1);
-        const f32x4* pr_ = (const f32x4*)(P.partials + s * P.stride + (long)row * D);
+        const long pe = s * P.stride + (long)row * D;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) t[u][i] = pr_[c0 + i * 64];
+        for (int i = 0; i < MAXV; ++i) t[u][i] = slab_load4<ST>(P.partials, pe + 4L * (c0 + i * 64));
       }
 #pragma unroll
       for (int u = 0; u < SB; ++u) {
@@ -261,10 +277,10 @@ __device__ __forceinline__ void ln_mod_wide_body(const LnPair& pr, int D, float 
   if (stamp) pr.dbg[(long)blockIdx.x * 4 + 3] = wall_clock64();
 }
 
-template <typename OutT, int MAXV, bool PEND, int WPR>
+template <typename OutT, int MAXV, bool PEND, int WPR, bool SLAB16 = false>
 __global__ __launch_bounds__(128 * WPR) void ln_mod_wide_kernel(const LnPair pr, int D, float eps) {
-  if ((int)blockIdx.x >= pr.blocks0) ln_mod_wide_body<OutT, MAXV, PEND, WPR, 1>(pr, D, eps);   // workgroup-uniform
-  else ln_mod_wide_body<OutT, MAXV, PEND, WPR, 0>(pr, D, eps);
+  if ((int)blockIdx.x >= pr.blocks0) ln_mod_wide_body<OutT, MAXV, PEND, WPR, 1, SLAB16>(pr, D, eps);   // workgroup-uniform
+  else ln_mod_wide_body<OutT, MAXV, PEND, WPR, 0, SLAB16>(pr, D, eps);
 }
 
 // ------------------------------------------------------------------ q/k RMSNorm + RoPE + head split
@@ -600,11 +616,19 @@ int launch_ln_mod_pair(const LnArgs& a0, const LnArgs& a1, int D, float eps, int
   if (out_dtype != FOLEY_F32 && !foley_is_half(out_dtype)) return foley_set_err("ln_mod: bad dtype", __FILE__, __LINE__);
   const bool f32o = out_dtype == FOLEY_F32, f16o = out_dtype == FOLEY_F16;
   const bool pend = (a0.M > 0 && a0.pend.partials) || (a1.M > 0 && a1.pend.partials);
+  // 16-bit slabs (LnPending::half): both row sets of a launch agree, and the slab type is the output type
+  const int h0 = (a0.M > 0 && a0.pend.partials) ? a0.pend.half : -1, h1 = (a1.M > 0 && a1.pend.partials) ? a1.pend.half : -1;
+  const int slab_dt = h0 >= 0 ? h0 : (h1 >= 0 ? h1 : 0);
+  if ((h0 >= 0 && h1 >= 0 && h0 != h1) || (slab_dt != 0 && slab_dt != out_dtype))
+    return foley_set_err("ln_mod: 16-bit pending slabs must have the output dtype (and agree between the two row sets)", __FILE__, __LINE__);
+  const bool s16 = slab_dt != 0;
 #define FOLEY_LN(V)                                                                                        \
   {                                                                                                        \
     if (pend) {                                                                                            \
       if (f32o) FOLEY_LAUNCH((ln_mod_kernel<float, V, true>), grid, block, 0, st, pr, D, eps);       \
+      else if (f16o && s16) FOLEY_LAUNCH((ln_mod_kernel<f16_t, V, true, true>), grid, block, 0, st, pr, D, eps);  \
       else if (f16o) FOLEY_LAUNCH((ln_mod_kernel<f16_t, V, true>), grid, block, 0, st, pr, D, eps);  \
+      else if (s16) FOLEY_LAUNCH((ln_mod_kernel<bf16_t, V, true, true>), grid, block, 0, st, pr, D, eps);  \
       else FOLEY_LAUNCH((ln_mod_kernel<bf16_t, V, true>), grid, block, 0, st, pr, D, eps);           \
     } else {                                                                                               \
       if (f32o) FOLEY_LAUNCH((ln_mod_kernel<float, V, false>), grid, block, 0, st, pr, D, eps);      \
@@ -621,7 +645,9 @@ int launch_ln_mod_pair(const LnArgs& a0, const LnArgs& a1, int D, float eps, int
       dim3 blk(128 * W);                                                                                               \
       if (pend) {                                                                                                      \
         if (f32o) FOLEY_LAUNCH((ln_mod_wide_kernel<float, V, true, W>), grid, blk, 0, st, pr, D, eps);                \
+        else if (f16o && s16) FOLEY_LAUNCH((ln_mod_wide_kernel<f16_t, V, true, W, true>), grid, blk, 0, st, pr, D, eps);  \
         else if (f16o) FOLEY_LAUNCH((ln_mod_wide_kernel<f16_t, V, true, W>), grid, blk, 0, st, pr, D, eps);           \
+        else if (s16) FOLEY_LAUNCH((ln_mod_wide_kernel<bf16_t, V, true, W, true>), grid, blk, 0, st, pr, D, eps);     \
         else FOLEY_LAUNCH((ln_mod_wide_kernel<bf16_t, V, true, W>), grid, blk, 0, st, pr, D, eps);                    \
       } else {                                                                                                         \
         if (f32o) FOLEY_LAUNCH((ln_mod_wide_kernel<float, V, false, W>), grid, blk, 0, st, pr, D, eps);               \

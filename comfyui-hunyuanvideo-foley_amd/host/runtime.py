@@ -71,7 +71,7 @@ class GemmDescC(C.Structure):
         ("dtype", C.c_int32), ("epilogue", C.c_int32), ("tile", C.c_int32), ("ksplit", C.c_int32),
         ("partials", C.c_void_p), ("partial_slabs", C.c_int32), ("ksplit_used", C.POINTER(C.c_int32)),
         ("qkv", C.POINTER(QkvSplitDescC)), ("rstride", C.c_int32), ("ldw", C.c_int64), ("wfmt", C.c_int32),
-        ("gelu_erf", C.c_int32),
+        ("partial_dtype", C.c_int32), ("gelu_erf", C.c_int32),
     ]
 
 
@@ -112,6 +112,9 @@ _SIGNATURES = {
     "foley_op_ln_mod_pending": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.POINTER(RowBcastC),
                                           C.POINTER(RowBcastC), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                           C.POINTER(RowBcastC), C.c_void_p]),
+    "foley_op_ln_mod_pending2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.POINTER(RowBcastC),
+                                           C.POINTER(RowBcastC), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                           C.POINTER(RowBcastC), C.c_void_p]),
     "foley_op_ln_mod": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.POINTER(RowBcastC),
                                   C.POINTER(RowBcastC), C.c_void_p, C.c_int, C.c_void_p]),
     "foley_op_qkv_split": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
@@ -422,8 +425,9 @@ def op_gemm(A, W, bias=None, *, M=None, epilogue=EPI_STORE_F32, out0=None, out1=
     d.alphaC = alphaC
     used = C.c_int32(1)
     d.ksplit_used = C.pointer(used)
-    if partials is not None:
+    if partials is not None:      # fp32 slabs, or slabs in the (16-bit) operand dtype
         d.partials, d.partial_slabs = _ptr(partials), partials.shape[0]
+        d.partial_dtype = 0 if partials.dtype == torch.float32 else dt_of(partials)
     if qkv is not None:
         d.qkv = C.pointer(qkv)
     _check(lib, lib.foley_op_gemm(C.byref(d), _stream()), "foley_op_gemm")
@@ -468,13 +472,15 @@ def qkv_split_desc(L, H, gains: Sequence, poss: Sequence, dsts: Sequence, S_tot,
 
 def op_ln_mod_pending(x, eps, shift: Optional[RowBcastC], scale: Optional[RowBcastC], out, partials, k: int, bias,
                       gate: RowBcastC):
-    """LayerNorm of x after x += gate * (sum(partials[:k]) + bias), x updated in place."""
+    """LayerNorm of x after x += gate * (sum(partials[:k]) + bias), x updated in place.  `partials`: fp32, or out's
+    16-bit dtype (the slabs a GEMM with 16-bit `partials` left)."""
     lib = load_library()
     M, D = x.shape
-    _check(lib, lib.foley_op_ln_mod_pending(_ptr(x), M, D, eps, C.byref(shift) if shift else None,
-                                            C.byref(scale) if scale else None, _ptr(out), dt_of(out), _ptr(partials),
-                                            k, _ptr(bias) if bias is not None else None, C.byref(gate), _stream()),
-           "foley_op_ln_mod_pending")
+    pdt = 0 if partials.dtype == torch.float32 else dt_of(partials)
+    _check(lib, lib.foley_op_ln_mod_pending2(_ptr(x), M, D, eps, C.byref(shift) if shift else None,
+                                             C.byref(scale) if scale else None, _ptr(out), dt_of(out), _ptr(partials), pdt,
+                                             k, _ptr(bias) if bias is not None else None, C.byref(gate), _stream()),
+           "foley_op_ln_mod_pending2")
 
 
 def op_qkv_split(qkv, L, H, gains: Sequence, poss: Sequence, dsts: Sequence, S_tot, tok_off, eps, cos, sin,

@@ -222,6 +222,9 @@ typedef struct foley_gemm_desc {
   int64_t ldw;     /* elements between rows of W (0 = K); > K for row-padded weight storage (wave-specialised tiles) */
   int32_t wfmt;    /* storage of W: 0 = `dtype`; 1 = fp8 e4m3fn, 2 = fp8 e5m2 with bf16 activations - widened to bf16
                     * in registers by the wave-specialised tiles (15, 19), bit-identical to widening at load time */
+  int32_t partial_dtype; /* dtype of the `partials` slabs: 0 = fp32; or the (16-bit) operand dtype - half the slab traffic, the
+                          * sum of k rounded partials carries about the error of one rounding of the total; pass the same
+                          * value to foley_op_ln_mod_pending2 */
   int32_t gelu_erf;/* epilogue 3 only: 1 = exact GELU (erf) instead of the tanh form - nn.GELU() of the conditioning
                     * encoders (reference models/synchformer/vit_helper.py:108-125 Mlp, nn.TransformerEncoderLayer) */
 } foley_gemm_desc;
@@ -245,6 +248,10 @@ int foley_op_ln_mod_pending(float* x, int M, int D, float eps, const foley_rowbc
                             const foley_rowbcast* scale, void* out, int out_dtype, const float* partials,
                             int k, const float* bias, const foley_rowbcast* gate, void* stream);
 /* vt_pitch > 0: the last operand is written transposed [clips, H, 128, vt_pitch] (see above). */
+/* the same with slabs of `partial_dtype` (0 = fp32, or out_dtype when that is bf16 / fp16: foley_gemm_desc.partial_dtype) */
+int foley_op_ln_mod_pending2(float* x, int M, int D, float eps, const foley_rowbcast* shift,
+                             const foley_rowbcast* scale, void* out, int out_dtype, const void* partials,
+                             int partial_dtype, int k, const float* bias, const foley_rowbcast* gate, void* stream);
 int foley_op_qkv_split(const float* qkv, int M, int L, int H, int nK, const float* const* gain,
                        const int32_t* const* pos, void* const* dst, int out_dtype, int vt_pitch, int S_tot,
                        int tok_off, float eps, const float* cos_tab, const float* sin_tab, void* stream);
