@@ -4,6 +4,8 @@ host/distributed.py directly and through bench.py's OWN rank-spawning code (`pyt
 --gpus 2` with no launcher).  The HIP library is not involved - this checks the collective
 plumbing the 8-GPU bench relies on."""
 import json
+
+import pytest
 import os
 import socket
 import subprocess
@@ -91,18 +93,21 @@ def test_world2_single_broadcast_and_sharding():
     assert tot0 == tot1 and abs((s0 + s1) - tot0) < 1e-9
 
 
-def test_bench_spawns_its_own_ranks():
+@pytest.mark.parametrize("config,bs", [("c2", 1), ("c4", 8)])
+def test_bench_spawns_its_own_ranks(config, bs):
     """`python bench.py --gpus 2` without a launcher: bench.py spawns 2 ranks itself, they rendezvous on
-    127.0.0.1, rank 0 packs and ONE broadcast ships the bundle; exit code 0 and one JSON line."""
+    127.0.0.1, rank 0 packs and ONE broadcast ships the bundle; exit code 0 and one JSON line.  `--config c4`
+    (BASELINE configs[3]: video features in the bundle, 8 clips per GPU) shards 16 clips over the two ranks."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-run",
-                        "--model", "tiny", "--duration", "1"], env=env, capture_output=True, text=True, timeout=300)
+                        "--config", config, "--model", "tiny", "--duration", "1"], env=env, capture_output=True, text=True,
+                       timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["collectives"] == 1 and out["bundle_bytes"] > 0
-    assert [x["shard"] for x in out["ranks"]] == [[0, 1], [1, 2]] and all(x["ok"] for x in out["ranks"])
+    assert [x["shard"] for x in out["ranks"]] == [[0, bs], [bs, 2 * bs]] and all(x["ok"] for x in out["ranks"])
     assert abs(sum(x["noise_sum"] for x in out["ranks"]) - out["noise_total"]) < 1e-9
 
 

@@ -65,6 +65,22 @@ def test_frame_selection_matches_reference_rule():
         assert int(g["idx25_" + tag].max()) == n - 1
 
 
+def test_frame_selection_equals_whole_clip_conversion():
+    """select_frames touches only the frame range the two index sets span (one contiguous copy, converted on the device in
+    the GPU path); the reference converts the whole padded clip and then selects (nodes.py:293-317).  Same result, bit for
+    bit, for clips shorter / longer than duration * frame_rate and fractional rates."""
+    g = torch.Generator().manual_seed(9)
+    for total, dur, fps in ((30, 2.0, 24.0), (200, 5.0, 16.0), (61, 2.5, 29.97), (10, 1.0, 8.0), (400, 3.3, 60.0)):
+        img = torch.rand(total, 6, 7, 3, generator=g)
+        n = int(dur * fps)
+        full = torch.cat((img, img[-1:].repeat(n - total, 1, 1, 1)), dim=0) if n > total else img[:n]
+        frames = (full * 255.0).byte().permute(0, 3, 1, 2)
+        r8 = frames.index_select(0, torch.linspace(0, n - 1, int(dur * 8)).long())
+        r25 = frames.index_select(0, torch.linspace(0, n - 1, int(dur * 25)).long())
+        f8, f25 = E.select_frames(img, dur, fps)
+        assert torch.equal(f8, r8) and torch.equal(f25, r25), (total, dur, fps)
+
+
 def test_preprocess_pipelines():
     """v2.Resize(bicubic, antialias) -> /255 -> Normalize(0.5, 0.5) (nodes.py:184-196): shapes, range, the
     short-edge / centre-crop geometry, constants stay constant, identity when no resize is needed."""
