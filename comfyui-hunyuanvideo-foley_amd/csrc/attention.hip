@@ -769,12 +769,9 @@ int launch_attention(const AttnArgs& a_in, int out_dtype, hipStream_t st) {
 #define FOLEY_ATTN16(T, O)                                                                         \
     do {                                                                                             \
       if (staged) {                                                                                  \
-        static bool raised = false;                                                                  \
-        if (!raised) {                                                                               \
-          hipError_t e_ = hipFuncSetAttribute((const void*)attn_lds_kernel<T, O>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-          if (e_ != hipSuccess) return foley_set_err(hipGetErrorString(e_), __FILE__, __LINE__);     \
-          raised = true;                                                                             \
-        }                                                                                            \
+        static std::atomic<unsigned long long> raised{0};                                            \
+        hipError_t e_ = foley_raise_lds((const void*)attn_lds_kernel<T, O>, 160 * 1024, raised);     \
+        if (e_ != hipSuccess) return foley_set_err(hipGetErrorString(e_), __FILE__, __LINE__);       \
         FOLEY_LAUNCH((attn_lds_kernel<T, O>), grid1, dim3(256), lds16, st, a, merge_off);            \
       } else                                                                                         \
       if (wide && hd == 64) FOLEY_LAUNCH((attn_bf16_wide_kernel<T, O, 64>), gw, dim3(256), 0, st, a);  \

@@ -4,6 +4,8 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
+#include <atomic>
+
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -186,3 +188,14 @@ extern thread_local FoleyProfHook g_foley_prof;
   } while (0)
 
 int foley_set_err(const char* msg, const char* file, int line);
+
+// Opt a kernel into more than 64 KiB of dynamic LDS, once per (call site = kernel instantiation, device): the attribute belongs to
+// the current device's copy of the function, and one process may drive several GPUs (host/sampler.py::denoise_process_multi).
+inline hipError_t foley_raise_lds(const void* fn, int bytes, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
+  if ((done.load(std::memory_order_acquire) >> dev) & 1ull) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.fetch_or(1ull << dev, std::memory_order_release);
+  return e;
+}

@@ -202,11 +202,10 @@ template <typename T, int BM, int BN, int WM, int WN, int NS, int EPI>
 int launch_c3(const GemmArgs& g, hipStream_t st) {
   constexpr size_t lds = 2 * (size_t)(BM + 2 + 3 * BN) * LDS_PITCH;
   auto k = gemm_conv3_kernel<T, BM, BN, WM, WN, NS, EPI>;
-  static bool raised = false;
-  if (lds > 64 * 1024 && !raised) {
-    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static std::atomic<unsigned long long> raised{0};
+  if (lds > 64 * 1024) {
+    hipError_t e = foley_raise_lds((const void*)k, (int)lds, raised);
     if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);
-    raised = true;
   }
   GemmPair pr;
   pr.g[0] = g;

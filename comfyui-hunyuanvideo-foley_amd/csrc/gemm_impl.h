@@ -486,13 +486,9 @@ int launch_one(const GemmArgs& g, const GemmArgs* g1, hipStream_t st) {
   if constexpr (GLDS) k = gemm_glds_kernel<T, BM, BN, WM, WN, NS, EPI>;
   else k = conv ? gemm_kernel<T, BM, BN, WM, WN, NS, EPI, true> : gemm_kernel<T, BM, BN, WM, WN, NS, EPI, false>;
   if (lds > 64 * 1024) {
-    static bool raised[2] = {false, false};   // per instantiation (plain / conv kernel)
-    bool& r_ = raised[conv ? 1 : 0];
-    if (!r_) {
-      hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);
-      r_ = true;
-    }
+    static std::atomic<unsigned long long> raised[2];   // per instantiation (plain / conv kernel), per device
+    hipError_t e = foley_raise_lds((const void*)k, (int)lds, raised[conv ? 1 : 0]);
+    if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);
   }
   FOLEY_LAUNCH(k, dim3(tiles), dim3(WM * WN * 64), lds, st, pr);
   hipError_t e = hipGetLastError();

@@ -685,11 +685,10 @@ int launch_ws_conv3_one(const GemmArgs& g, hipStream_t st) {
   pr.g[1] = g;
   pr.tiles0 = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * (EPI == EPI_GATE_RES ? g.ksplit : 1);
   auto k = gemm_ws_conv3_kernel<T, BM, BN, WM, WN, NSB, NAB, LW, EPI, WF>;
-  static bool raised = false;
-  if (!raised) {
-    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static std::atomic<unsigned long long> raised{0};
+  {
+    hipError_t e = foley_raise_lds((const void*)k, (int)lds, raised);
     if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);
-    raised = true;
   }
   FOLEY_LAUNCH(k, dim3(pr.tiles0), dim3((WM * WN + LW) * 64), lds, st, pr);
   hipError_t e = hipGetLastError();
@@ -712,11 +711,10 @@ int launch_ws_conv3_tall(const GemmArgs& g, hipStream_t st) {
   pr.g[1] = g;
   pr.tiles0 = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * (EPI == EPI_GATE_RES ? g.ksplit : 1);
   auto k = gemm_ws_conv3_kernel<T, BM, BN, WM, WN, NSB, NAB, LW, EPI, 0>;
-  static bool raised = false;
-  if (!raised) {
-    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static std::atomic<unsigned long long> raised{0};
+  {
+    hipError_t e = foley_raise_lds((const void*)k, (int)lds, raised);
     if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);
-    raised = true;
   }
   FOLEY_LAUNCH(k, dim3(pr.tiles0), dim3((WM * WN + LW) * 64), lds, st, pr);
   hipError_t e = hipGetLastError();
@@ -748,11 +746,10 @@ int launch_ws_one(const GemmArgs& g, const GemmArgs* g1, hipStream_t st) {
   constexpr size_t lds_epi = (size_t)BM * BN * 4;            // the epilogues transpose the accumulator tile through LDS
   constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
   auto k = gemm_ws_kernel<T, BM, BN, WM, WN, NS, LW, EPI, WF>;
-  static bool raised = false;
-  if (!raised) {
-    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static std::atomic<unsigned long long> raised{0};
+  {
+    hipError_t e = foley_raise_lds((const void*)k, (int)lds, raised);
     if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);
-    raised = true;
   }
   FOLEY_LAUNCH(k, dim3(tiles), dim3((WM * WN + LW) * 64), lds, st, pr);
   hipError_t e = hipGetLastError();
