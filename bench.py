@@ -135,20 +135,35 @@ def encoder_pass(cfg, duration, dev, dtype, frame_rate=16.0, hw=(480, 640), repe
     g = torch.Generator().manual_seed(3)
     n = int(duration * frame_rate)
     image = torch.randint(0, 256, (n, hw[0], hw[1], 3), generator=g, dtype=torch.uint8).float() / 255.0   # a ComfyUI IMAGE batch
+    # CLAP text encoder (laion/larger_clap_general's architecture: RoBERTa-base, random init) on two synthetic prompts of 12 / 5
+    # tokens (+ <s> </s>), right-padded like the tokenizer does
+    from transformers import ClapTextConfig, ClapTextModelWithProjection
+    from foley_amd.host import encoders_hip as EH
+    clap = ClapTextModelWithProjection(ClapTextConfig()).eval()
+    clap_sd = {k: v.detach().to(dev, dtype) for k, v in clap.state_dict().items() if k.startswith("text_model.") and v.is_floating_point()}
+    ids = torch.ones(2, 14, dtype=torch.long)
+    ids[0] = torch.cat([torch.tensor([0]), torch.randint(3, 50000, (12,), generator=g), torch.tensor([2])])
+    ids[1, :7] = torch.cat([torch.tensor([0]), torch.randint(3, 50000, (5,), generator=g), torch.tensor([2])])
+    ids = ids.to(dev)
     tm = {}
     for _ in range(repeats):
         tm = {}
         torch.cuda.synchronize(dev)
+        tc = time.perf_counter()
+        text = EH.clap_text_hidden_hip(clap_sd, ids, (ids != 1).long(), dtype, eps=clap.config.layer_norm_eps)
+        torch.cuda.synchronize(dev)
+        tm["clap_text_ms"] = 1e3 * (time.perf_counter() - tc)
+        assert text.shape == (2, 14, 768) and bool(torch.isfinite(text).all())
         t0 = time.perf_counter()
         f8, f25 = E.select_frames(image, duration, frame_rate, device=dev)      # incl. the H2D copy of the selected frames
         tm["select_frames_ms"] = 1e3 * (time.perf_counter() - t0)
         feats, alen = E.video_features(f8, f25, sig, sync_sd, dev, model_dtype=dtype, timings=tm)
         torch.cuda.synchronize(dev)
-        tm["total_ms"] = 1e3 * (time.perf_counter() - t0)
+        tm["total_ms"] = 1e3 * (time.perf_counter() - t0) + tm["clap_text_ms"]
     assert abs(alen - duration) < 1e-6 and all(bool(torch.isfinite(v).all()) for v in feats.values())
     tm = {k: round(v, 2) for k, v in tm.items()}
     tm["frames"] = f"{n} frames {hw[0]}x{hw[1]} uint8 noise (seed 3) at {frame_rate:g} fps -> {f8.shape[0]} @ 8 fps (SigLIP2 512 px) + {f25.shape[0]} @ 25 fps (Synchformer 224 px)"
-    tm["weights"] = "SigLIP2 ViT-B/16-512 random init; Synchformer synthesised; both on libfoley_hip.so"
+    tm["weights"] = "SigLIP2 ViT-B/16-512 and CLAP RoBERTa-base random init; Synchformer synthesised; all three on libfoley_hip.so"
     return feats, tm
 
 

@@ -273,8 +273,20 @@ def encode_video_with_siglip2(model, frames: Tensor, batch_size: int = 16) -> Te
 
 @torch.inference_mode()
 def encode_text_feat(tokenizer, model, prompts, device) -> Tensor:
-    """CLAP last_hidden_state for a list of prompts (feature_utils.py:133-138)."""
+    """CLAP last_hidden_state for a list of prompts (feature_utils.py:133-138).  On a HIP device the text encoder runs on
+    libfoley_hip.so (host/encoders_hip.py::clap_text_hidden_hip, over the HF model's state dict, in the model's dtype); on the
+    CPU (tests) the `transformers` module runs."""
     inputs = tokenizer(prompts, padding=True, return_tensors="pt").to(device)
+    if torch.device(device).type == "cuda":
+        from . import encoders_hip as EH
+        cur = getattr(model, "_foley_text_sd", None)
+        if cur is None or next(iter(cur.values())).device != torch.device(device):
+            model._foley_text_sd = cur = {k: v.detach().to(device) for k, v in model.state_dict().items()
+                                          if k.startswith("text_model.") and v.is_floating_point()}
+        cfgm = model.config
+        out = EH.clap_text_hidden_hip(cur, inputs["input_ids"], inputs["attention_mask"], next(model.parameters()).dtype,
+                                      heads=cfgm.num_attention_heads, eps=cfgm.layer_norm_eps, pad_id=cfgm.pad_token_id)
+        return out.to(next(model.parameters()).dtype)
     out = model(**inputs, output_hidden_states=True, return_dict=True)
     return out.last_hidden_state
 

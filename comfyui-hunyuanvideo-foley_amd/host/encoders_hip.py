@@ -58,9 +58,9 @@ class _Engine:
         return t
 
     # ---- ops
-    def ln(self, x: Tensor, sd: SD, key: str, eps: float = 1e-6) -> Tensor:
-        """nn.LayerNorm(D, eps) with affine parameters: x fp32 [M, D] -> compute dtype [M, D]."""
-        out = torch.empty(x.shape, device=self.dev, dtype=self.dtype)
+    def ln(self, x: Tensor, sd: SD, key: str, eps: float = 1e-6, out_dtype: Optional[torch.dtype] = None) -> Tensor:
+        """nn.LayerNorm(D, eps) with affine parameters: x fp32 [M, D] -> compute dtype (or `out_dtype`) [M, D]."""
+        out = torch.empty(x.shape, device=self.dev, dtype=out_dtype or self.dtype)
         rt.op_ln_mod(x, eps, rt.rowbcast(self.vec(key + ".bias", sd[key + ".bias"])),
                      rt.rowbcast(self.vec(key + ".weight", sd[key + ".weight"], minus_one=True)), out)
         return out
@@ -264,3 +264,47 @@ def siglip_image_features_hip(sd: SD, pixels: Tensor, dtype: torch.dtype = torch
     hid = E.linear(E.ln(y, sd, hp + ".layernorm", eps), sd, hp + ".mlp.fc1.weight", hp + ".mlp.fc1.bias", act="gelu_tanh")
     E.linear_residual(y, hid, sd, hp + ".mlp.fc2.weight", hp + ".mlp.fc2.bias")
     return y
+
+
+# ----------------------------------------------------------------------------- CLAP text encoder
+def clap_text_hidden_hip(sd: SD, input_ids: Tensor, attention_mask: Tensor, dtype: torch.dtype = torch.bfloat16,
+                         prefix: str = "text_model.", heads: int = HEADS, eps: float = 1e-12, pad_id: int = 1) -> Tensor:
+    """`ClapTextModelWithProjection(...).last_hidden_state` (what feature_utils.py:133-138 feeds the DiT as text tokens) on the
+    HIP engine, over the HF model's state dict: RoBERTa embeddings (word + token-type + learned positions counted over the
+    non-pad tokens) -> LayerNorm, then post-norm encoder layers  y = LN(x + dense(attn(x)));  x' = LN(y + dense(GELU(dense(y)))).
+    The tokenizer pads on the right, so the additive key mask of the reference equals "prompt i attends to its first len_i
+    keys": attention runs per prompt with Skv = len_i and all T (padded) query rows - the pad rows are part of
+    `last_hidden_state` and reach the DiT like in the reference.  input_ids / attention_mask [B, T] on the GPU -> [B, T, D] fp32."""
+    p = prefix if (prefix + "embeddings.word_embeddings.weight") in sd else ""
+    E = _engine_for(sd, input_ids.device, dtype)
+    B, T = input_ids.shape
+    mask = attention_mask.to(torch.long)
+    lens = mask.sum(1)
+    if not bool((mask == (torch.arange(T, device=mask.device)[None] < lens[:, None]).long()).all()):
+        raise rt.FoleyRuntimeError("the engine's CLAP text encoder expects right-padded prompts")
+    nz = input_ids.ne(pad_id).long()
+    pos_ids = torch.cumsum(nz, dim=1) * nz + pad_id                      # create_position_ids_from_input_ids
+    f32 = lambda k: sd[p + k].to(E.dev, torch.float32)
+    emb = f32("embeddings.word_embeddings.weight")[input_ids] + f32("embeddings.token_type_embeddings.weight")[0] \
+        + f32("embeddings.position_embeddings.weight")[pos_ids]
+    D = emb.shape[-1]
+    hd = D // heads
+    if hd != HD:
+        raise rt.FoleyRuntimeError("the engine's encoder attention serves head_dim 64")
+    x = E.ln(emb.reshape(B * T, D).contiguous(), sd, p + "embeddings.LayerNorm", eps, out_dtype=torch.float32)
+    depth = 1 + max(int(k[len(p) + 14:].split(".")[0]) for k in sd if k.startswith(p + "encoder.layer."))
+    lens_h = [int(v) for v in lens.tolist()]
+    for i in range(depth):
+        l = f"{p}encoder.layer.{i}"
+        xT = x.to(E.dtype)
+        sh = lambda t: t.view(B, T, heads, hd).permute(0, 2, 1, 3)
+        q = sh(E.linear(xT, sd, l + ".attention.self.query.weight", l + ".attention.self.query.bias"))
+        k = sh(E.linear(xT, sd, l + ".attention.self.key.weight", l + ".attention.self.key.bias"))
+        v = sh(E.linear(xT, sd, l + ".attention.self.value.weight", l + ".attention.self.value.bias"))
+        att = torch.cat([E.attention(q[b:b + 1], k[b:b + 1, :, :lens_h[b]], v[b:b + 1, :, :lens_h[b]]) for b in range(B)])
+        E.linear_residual(x, att.reshape(B * T, D), sd, l + ".attention.output.dense.weight", l + ".attention.output.dense.bias")
+        y = E.ln(x, sd, l + ".attention.output.LayerNorm", eps, out_dtype=torch.float32)
+        hid = E.linear(y.to(E.dtype), sd, l + ".intermediate.dense.weight", l + ".intermediate.dense.bias", act="gelu_erf")
+        E.linear_residual(y, hid, sd, l + ".output.dense.weight", l + ".output.dense.bias")
+        x = E.ln(y, sd, l + ".output.LayerNorm", eps, out_dtype=torch.float32)
+    return x.view(B, T, D)

@@ -67,6 +67,35 @@ def test_siglip_vision_tower_on_the_engine(dev):
     assert f32.shape == ref.shape and e32 < 2e-5 and e16 < 5e-3 and eb < 4e-2
 
 
+def test_clap_text_encoder_on_the_engine(dev):
+    """`last_hidden_state` of transformers' ClapTextModelWithProjection (the text tokens of feature_utils.py:133-138) as restated
+    on the engine - RoBERTa embeddings with pad-aware positions, post-norm layers, exact GELU, LayerNorm eps 1e-12 - for two
+    prompts of different length (right-padded: the shorter one's pad rows are part of the output, like in the reference),
+    against the HF module on the CPU in fp32."""
+    from transformers import ClapTextConfig, ClapTextModelWithProjection
+    torch.manual_seed(3)
+    m = ClapTextModelWithProjection(ClapTextConfig(hidden_size=768, num_hidden_layers=2, num_attention_heads=12, intermediate_size=256,
+                                                   vocab_size=300, max_position_embeddings=90, projection_dim=64)).eval()
+    with torch.no_grad():
+        gen = torch.Generator().manual_seed(4)
+        for n, p_ in m.named_parameters():
+            if p_.dim() == 1:
+                p_.copy_((1.0 if "LayerNorm.weight" in n else 0.0) + 0.05 * torch.randn(p_.shape, generator=gen))
+    ids = torch.tensor([[0, 17, 45, 99, 120, 7, 33, 250, 2], [0, 88, 5, 2, 1, 1, 1, 1, 1]])
+    mask = (ids != 1).long()
+    with torch.inference_mode():
+        ref = m(input_ids=ids, attention_mask=mask, return_dict=True).last_hidden_state
+    sd = {k: v.detach().to(dev) for k, v in m.state_dict().items() if v.is_floating_point()}
+    f32 = EH.clap_text_hidden_hip(sd, ids.to(dev), mask.to(dev), torch.float32)
+    f16 = EH.clap_text_hidden_hip(sd, ids.to(dev), mask.to(dev), torch.float16)
+    b16 = EH.clap_text_hidden_hip(sd, ids.to(dev), mask.to(dev), torch.bfloat16)
+    e32, e16, eb = rel_err(f32, ref), rel_err(f16, ref), rel_err(b16, ref)
+    print("CLAP text encoder on the HIP engine vs transformers (CPU fp32): fp32 %.2e, fp16 %.2e, bf16 %.2e" % (e32, e16, eb))
+    assert f32.shape == ref.shape and e32 < 2e-5 and e16 < 5e-3 and eb < 4e-2
+    with pytest.raises(Exception):
+        EH.clap_text_hidden_hip(sd, ids.to(dev), torch.tensor([[0, 1, 1, 1, 1, 1, 1, 1, 1], [1] * 9]).to(dev), torch.float32)   # left padding
+
+
 def test_gpu_uint8_resize_matches_the_cpu_uint8_kernel(dev):
     """torchvision's v2.Resize(bicubic, antialias) runs the native uint8 kernel on the CPU (where the reference
     pre-processes, utils.py:262-283); encoders._resize_u8 on the GPU goes through float32 + round + clamp.  torchvision
