@@ -518,6 +518,11 @@ int launch_tile(const GemmArgs& g, const GemmArgs* g1, int epi, hipStream_t st) 
 }
 
 
+inline bool f32_half_tiles() {
+  static const bool v = []() { const char* e = getenv("FOLEY_F32_HALF_TILES"); return !(e && e[0] == '0'); }();
+  return v;
+}
+
 template <typename T>
 int check_args(const GemmArgs& g) {
   constexpr int BK = 8 * Frag<T>::EPC;
@@ -584,6 +589,10 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
                                                                                          // halve the activation DMA, modulation GEMM at M = 16: 258 -> 227 us)
     else if (deferred && g.N > 64 && b128 <= 256) tile = 5;   // 128x128 tiles, K ranges fill the chip (tools/gemm_timeline.py)
     else if (g.N <= 64 && epi != EPI_SILUGATE_T) tile = nblk(128, 64) >= 192 ? 4 : 3;
+    // fp32 (the DAC decoder): a long-K GEMM whose 128x128 tiles cover half the chip or less runs at the pace of ONE workgroup
+    // (decoder stage 1: M = 2000, N = 1024, K = 7168 -> 128 workgroups, 470 us at 39 % of the fp32 matrix peak); 64x128 tiles
+    // double the workgroups (FOLEY_F32_HALF_TILES=0 keeps 128x128)
+    else if (sizeof(T) == 4 && f32_half_tiles() && b128 >= 100 && b128 <= 160 && nblk(64, 128) <= 320 && g.K >= 1024 && epi != EPI_SILUGATE_T) tile = 8;
     else if (b128 >= 100 && (b128 <= 256 || rem == 0 || rem >= 128 || b128 >= 2048)) tile = 5;
     else if (epi == EPI_SILUGATE_T) tile = nblk(64, 128) >= 192 ? 2 : 5;
     else tile = 3;
