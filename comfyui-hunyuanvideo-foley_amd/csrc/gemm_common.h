@@ -313,6 +313,43 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
         VecStore<float>::store((float*)out + (long)row * g.out_row, v);
       }
     }
+  } else if constexpr (EPI == EPI_DAC) {
+    // DAC residual unit tails (dac.py:28-44): v = acc + bias (+ res); out0 = v; out1 = snake(v) with the consumer's alpha - four
+    // consecutive channels per lane, dwordx4 loads / stores (the scalar form issues 3 x 64 four-byte accesses per lane; the
+    // k=1 convs of the narrow stages are bound by exactly that)
+    float* o0 = g.out0 ? (float*)g.out0 + g.out_shift + gcol : nullptr;
+    float* o1 = g.out1 ? (float*)g.out1 + g.out_shift + gcol : nullptr;
+    const float* rs = g.res ? g.res + g.out_shift + gcol : nullptr;
+    f32x4 al = {1.f, 1.f, 1.f, 1.f}, ia;
+    if (o1 && col_ok) al = *(const f32x4*)(g.alpha + gcol % g.alphaC);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ia[u] = 1.0f / (al[u] + 1e-9f);
+    constexpr int PB = PASSES > 4 ? 4 : PASSES;
+    static_assert(PASSES % PB == 0, "pass batching");
+#pragma unroll
+    for (int p0 = 0; p0 < PASSES; p0 += PB) {
+      f32x4 rv[PB];
+#pragma unroll
+      for (int p = 0; p < PB; ++p) {   // the batch's residual reads first
+        const int row = row0 + (p0 + p) * RP;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        rv[p] = (rs && col_ok && row < g.M) ? *(const f32x4*)(rs + (long)row * g.out_row) : z;
+      }
+#pragma unroll
+      for (int p = 0; p < PB; ++p) {
+        const int row = row0 + (p0 + p) * RP;
+        if (!(col_ok && row < g.M)) continue;
+        const f32x4 a = *(const f32x4*)(tile + ((p0 + p) * RP + tr) * BN + ca);
+        float v[4], sn[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          v[u] = a[u] + bias_a[u] + rv[p][u];
+          sn[u] = snake_f(v[u], al[u], ia[u]);
+        }
+        if (o0) VecStore<float>::store(o0 + (long)row * g.out_row, v);
+        if (o1) VecStore<float>::store(o1 + (long)row * g.out_row, sn);
+      }
+    }
   } else {
     // ERF: the exact GELU of the conditioning encoders (GemmArgs::gelu_erf).  The flag is tested ONCE, outside the pass loop: as
     // a per-element select the compiler evaluated erff() next to the fast form for every output of the DiT's fc1 GEMM
@@ -535,7 +572,12 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&ac
 // Launcher side: can this problem take the vector epilogue?
 template <typename T>
 inline bool gemm_vec_out_ok(const GemmArgs& g, int epi) {
-  if (epi == EPI_DAC || g.osegV < g.M || g.out_check) return false;
+  if (g.osegV < g.M || g.out_check) return false;
+  if (epi == EPI_DAC) {   // residual + snake: vector form for the plain-mapped convs (conv7 / conv1); the strided transposed conv stays scalar
+    if (g.N % 4 || g.out_row % 4 || g.out_shift % 4 || g.alphaC % 4 || (g.out1 && !g.alpha)) return false;
+    const uintptr_t al = (uintptr_t)g.out0 | (uintptr_t)g.out1 | (uintptr_t)g.res | (uintptr_t)g.alpha | (uintptr_t)g.bias;
+    return !(al & 15) && (g.out0 || g.out1);
+  }
   if (epi == EPI_GATE_RES && g.ksplit > 1)   // split-K: atomics are scalar; deferred partials are vector stores
     return g.partials && g.N % 4 == 0 && !((uintptr_t)g.partials & 15) && g.partial_stride % 4 == 0;
   const bool f32 = epi == EPI_STORE_F32 || epi == EPI_GATE_RES || sizeof(T) == 4;
