@@ -317,28 +317,38 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
     // DAC residual unit tails (dac.py:28-44): v = acc + bias (+ res); out0 = v; out1 = snake(v) with the consumer's alpha - four
     // consecutive channels per lane, dwordx4 loads / stores (the scalar form issues 3 x 64 four-byte accesses per lane; the
     // k=1 convs of the narrow stages are bound by exactly that)
-    float* o0 = g.out0 ? (float*)g.out0 + g.out_shift + gcol : nullptr;
-    float* o1 = g.out1 ? (float*)g.out1 + g.out_shift + gcol : nullptr;
-    const float* rs = g.res ? g.res + g.out_shift + gcol : nullptr;
+    float* const o0 = (float*)g.out0;
+    float* const o1 = (float*)g.out1;
+    const float* const rs = g.res;
     f32x4 al = {1.f, 1.f, 1.f, 1.f}, ia;
     if (o1 && col_ok) al = *(const f32x4*)(g.alpha + gcol % g.alphaC);
 #pragma unroll
     for (int u = 0; u < 4; ++u) ia[u] = 1.0f / (al[u] + 1e-9f);
+    const bool plain_out = g.osegV >= g.M;
+    // element offset of (row, gcol) in the outputs, or -1: row beyond M / outside its clip (transposed conv edges)
+    auto out_off = [&](int row) -> long {
+      if (!(col_ok && row < g.M)) return -1;
+      if (plain_out) return (long)row * g.out_row + g.out_shift + gcol;
+      const int b = row / g.osegV, q = row - b * g.osegV;
+      const long rel = (long)q * g.out_row + g.out_shift + gcol;
+      if (g.out_check && (rel < 0 || rel >= g.out_seg)) return -1;
+      return (long)b * g.out_seg + rel;
+    };
     constexpr int PB = PASSES > 4 ? 4 : PASSES;
     static_assert(PASSES % PB == 0, "pass batching");
 #pragma unroll
     for (int p0 = 0; p0 < PASSES; p0 += PB) {
       f32x4 rv[PB];
+      long off[PB];
 #pragma unroll
       for (int p = 0; p < PB; ++p) {   // the batch's residual reads first
-        const int row = row0 + (p0 + p) * RP;
+        off[p] = out_off(row0 + (p0 + p) * RP);
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        rv[p] = (rs && col_ok && row < g.M) ? *(const f32x4*)(rs + (long)row * g.out_row) : z;
+        rv[p] = (rs && off[p] >= 0) ? *(const f32x4*)(rs + off[p]) : z;
       }
 #pragma unroll
       for (int p = 0; p < PB; ++p) {
-        const int row = row0 + (p0 + p) * RP;
-        if (!(col_ok && row < g.M)) continue;
+        if (off[p] < 0) continue;
         const f32x4 a = *(const f32x4*)(tile + ((p0 + p) * RP + tr) * BN + ca);
         float v[4], sn[4];
 #pragma unroll
@@ -346,8 +356,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
           v[u] = a[u] + bias_a[u] + rv[p][u];
           sn[u] = snake_f(v[u], al[u], ia[u]);
         }
-        if (o0) VecStore<float>::store(o0 + (long)row * g.out_row, v);
-        if (o1) VecStore<float>::store(o1 + (long)row * g.out_row, sn);
+        if (o0) VecStore<float>::store(o0 + off[p], v);
+        if (o1) VecStore<float>::store(o1 + off[p], sn);
       }
     }
   } else {
@@ -572,12 +582,14 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&ac
 // Launcher side: can this problem take the vector epilogue?
 template <typename T>
 inline bool gemm_vec_out_ok(const GemmArgs& g, int epi) {
-  if (g.osegV < g.M || g.out_check) return false;
-  if (epi == EPI_DAC) {   // residual + snake: vector form for the plain-mapped convs (conv7 / conv1); the strided transposed conv stays scalar
-    if (g.N % 4 || g.out_row % 4 || g.out_shift % 4 || g.alphaC % 4 || (g.out1 && !g.alpha)) return false;
+  if (epi == EPI_DAC) {   // residual + snake, vector form: plain-mapped convs (conv7 / conv1) and the segment-mapped transposed conv
+                          // (its N axis = (phase, channel) is contiguous in the output; a 4-channel group never straddles the
+                          // clip's ends because the shift and the segment length are multiples of 4)
+    if (g.N % 4 || g.out_row % 4 || g.out_shift % 4 || g.out_seg % 4 || g.alphaC % 4 || (g.out1 && !g.alpha)) return false;
     const uintptr_t al = (uintptr_t)g.out0 | (uintptr_t)g.out1 | (uintptr_t)g.res | (uintptr_t)g.alpha | (uintptr_t)g.bias;
     return !(al & 15) && (g.out0 || g.out1);
   }
+  if (g.osegV < g.M || g.out_check) return false;
   if (epi == EPI_GATE_RES && g.ksplit > 1)   // split-K: atomics are scalar; deferred partials are vector stores
     return g.partials && g.N % 4 == 0 && !((uintptr_t)g.partials & 15) && g.partial_stride % 4 == 0;
   const bool f32 = epi == EPI_STORE_F32 || epi == EPI_GATE_RES || sizeof(T) == 4;
