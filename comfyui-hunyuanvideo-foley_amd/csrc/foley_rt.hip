@@ -1,6 +1,6 @@
 // Runtime of libfoley_hip.so: context, packed-weight registry, step-invariant precompute, the DiT
 // forward, the device-resident sampler loop and the DAC decoder - all as sequences of launches
-// of the kernels in gemm.hip / attention.hip / rowops.hip on the caller's stream.  C ABI in
+// of the kernels in gemm*.hip / attention.hip / rowops.hip on the caller's stream.  C ABI in
 // include/foley_hip.h.  No torch types, no CPU fallback.
 #include "../../include/foley_hip.h"
 #include "kernels.h"

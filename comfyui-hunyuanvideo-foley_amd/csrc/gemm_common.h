@@ -1,4 +1,4 @@
-// Pieces shared by the GEMM mainloop variants (gemm.hip, gemm_conv3.hip): fragment traits, fused
+// Pieces shared by the GEMM mainloop variants (gemm_impl.h, gemm_ws_impl.h, gemm_conv3.hip): fragment traits, fused
 // epilogues, the two-problem kernel argument.
 #pragma once
 #include <type_traits>

@@ -2,14 +2,14 @@
 // ChannelLastConv1d (mlp_layers.py:104-110: single-block linear1 and the ConvMLP w1/w3/w2), which
 // carry two thirds of the model's FLOPs.
 //
-// The generic engine (gemm.hip) walks K tap-major and therefore streams the activation tile once
+// The generic engine (gemm_impl.h) walks K tap-major and therefore streams the activation tile once
 // per tap.  Here K is walked CHANNEL-chunk major: per 128-byte channel chunk the workgroup stages
 // the BM+2 activation rows ONCE (one halo row on each side) plus the three tap slices of the weight
 // tile, and runs all three taps' MFMAs from that stage, the tap being nothing but a row offset
 // (0/1/2) into the staged activation rows.  Per MFMA this moves a third less through L2/LDS and
 // there is one barrier per three tap-slices.  Rows whose neighbour lies outside their sequence
 // (first / last token of a clip) get a zeroed fragment for that tap (the conv's zero padding).
-// Same register-ring / double-buffered-LDS structure and the same fused epilogues as gemm.hip.
+// Same register-ring / double-buffered-LDS structure and the same fused epilogues as gemm_impl.h.
 #include "gemm_common.h"
 
 namespace {

@@ -4,7 +4,7 @@
 // and issue MFMAs; one s_barrier per K-slice couples them.
 //
 // Why (tools/gemm_timeline.py --ablate, tools/ubench/ldsdma_interfere.hip):
-//  * in the single-role loop of gemm.hip every wave runs barrier -> issue loads -> read fragments ->
+//  * in the single-role loop of gemm_impl.h every wave runs barrier -> issue loads -> read fragments ->
 //    MFMA back to back, and the slice time is the SUM of the three (0.73 us per 128x128x64 slice vs
 //    0.52 us loads only and 0.46 us fragment reads + MFMA only);
 //  * a dedicated loader only keeps its rate next to MFMA-saturated SIMDs if issuing a load needs no
@@ -15,7 +15,7 @@
 //   loader wave   : wait(slice kt landed) ; barrier ; issue slice kt+NS-1 into the stage freed by kt-1
 //   consumer wave : barrier ; read fragments of slice kt ; MFMA   (late half of the waves: MFMA of kt-1 first)
 //
-// Same operand addressing as gemm.hip (virtual rows / taps; zero fill through the buffer range
+// Same operand addressing as gemm_impl.h (virtual rows / taps; zero fill through the buffer range
 // check), same source-side XOR swizzle, same epilogues (gemm_common.h).  reference ops: F.linear,
 // ChannelLastConv1d (mlp_layers.py:104-110), see include/foley_hip.h foley_op_gemm.
 #pragma once
@@ -225,7 +225,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmPair& pr) {
     if constexpr (NW == 4) {
       f32x16 none[FM][FN];
       if constexpr (EPI == EPI_QKV_SPLIT) gemm_epilogue_qkv<T, BM, BN, WM, WN, LW>(g, none, lds, m0, n0);
-      else gemm_epilogue_lds<T, EPI, BM, BN, WM, WN, LW>(g, none, lds, m0, n0, ks);   // vector epilogue only (gemm.hip launcher)
+      else gemm_epilogue_lds<T, EPI, BM, BN, WM, WN, LW>(g, none, lds, m0, n0, ks);   // vector epilogue only (gemm_impl.h launcher)
     }
     return;
   }
@@ -779,7 +779,7 @@ int launch_ws_tile(const GemmArgs& g, const GemmArgs* g1, int epi, hipStream_t s
 
 // tile: 21 = tap-fused conv k=3 (128x128, 8 consumer + 4 loader waves); 15 = 128x128 (8 consumer + 4 loader waves), 19 = 256x128 (8 + 4), 25 / 29 = the same tiles with 4
 // consumer waves (64x64 / 128x64 per wave); g / g1 fully resolved
-// (ksplit, vec_out, operand extents) by gemm.hip's launcher
+// (ksplit, vec_out, operand extents) by gemm_impl.h's launcher
 template <typename T>
 int launch_gemm_ws_t(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hipStream_t st) {
   if (g.wfmt < 0 || g.wfmt > 2 || (g1 && g1->wfmt != g.wfmt))

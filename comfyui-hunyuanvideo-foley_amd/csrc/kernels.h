@@ -97,7 +97,7 @@ int launch_gemm(const GemmArgs& g, int dtype, int epi, int tile, hipStream_t st,
 int launch_gemm_pair(const GemmArgs& g0, const GemmArgs& g1, int dtype, int epi, hipStream_t st, int* ksplit_used = nullptr);
 // tap-fused channels-last conv k=3 (gemm_conv3.hip); tile 1 = 128x128, 3 = 64x64; g.ksplit resolved
 int launch_gemm_conv3(const GemmArgs& g, int dtype, int epi, int tile, hipStream_t st);
-// wave-specialised mainloop (gemm_ws.hip, bf16): tile 15 = 128x128, 19 = 256x128; g / g1 resolved by launch_gemm
+// wave-specialised mainloop (gemm_ws_impl.h; one entry per 16-bit operand type): tile 15 = 128x128, 19 = 256x128; g / g1 resolved by launch_gemm
 int launch_gemm_ws_bf16(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hipStream_t st);
 int launch_gemm_ws_f16(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hipStream_t st);
 
