@@ -788,6 +788,7 @@ int launch_gemm_ws_t(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, h
     if (g1 || g.wfmt) return foley_set_err("wave-specialised conv3 256x64: single problem, bf16 weights", __FILE__, __LINE__);
     if (epi == EPI_GATE_RES) return launch_ws_conv3_tall<T, EPI_GATE_RES>(g, st);
     if (epi == EPI_STORE_F32) return launch_ws_conv3_tall<T, EPI_STORE_F32>(g, st);
+    if (epi == EPI_SILUGATE_T) return launch_ws_conv3_tall<T, EPI_SILUGATE_T>(g, st);
     return foley_set_err("wave-specialised conv3 256x64: unsupported epilogue", __FILE__, __LINE__);
   }
   if (tile == 21 || tile == 23) {   // tap-fused conv k=3, 128x128 / 256x128 (the launcher has checked the conv shape)

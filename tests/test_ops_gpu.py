@@ -297,6 +297,23 @@ def test_conv3_channels_last(dev, dtype, tile, B, L, Cin, Cout):
     assert rel_err(out, ref) < _tol(dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("tile", [0, 21, 22, 23])
+@pytest.mark.parametrize("B,L,Cin,Cout", [(2, 250, 1536, 512), (3, 70, 128, 256), (4, 129, 192, 384)])
+def test_conv3_silu_gate(dev, dtype, tile, B, L, Cin, Cout):
+    """ConvMLP w1 / w3 (mlp_layers.py:113-149): silu(conv3(x, w1)) * conv3(x, w3) in one launch over the
+    interleaved weight, on every tap-fused tile form (128x128, 256x64, 256x128)."""
+    x = _rand((B, L, Cin), 60)
+    w1, w3 = (_rand((Cout, Cin, 3), 61 + i, 1 / math.sqrt(3 * Cin)) for i in range(2))
+    c = lambda w: O.conv1d_cl(_q(x, dtype), _q(w, dtype), None, 1).reshape(B * L, Cout)
+    ref = F.silu(c(w1)) * c(w3)
+    Wp = packers.interleave_gate(packers.conv_to_gemm(w1), packers.conv_to_gemm(w3))
+    out = torch.full((B * L, Cout), float("nan"), device=dev, dtype=dtype)
+    rt.op_gemm(x.reshape(B * L, Cin).to(dev, dtype), Wp.to(dev, dtype), None, out0=out, conv=(L, Cin, 3, 1),
+               epilogue=rt.EPI_SILUGATE_T, tile=tile)
+    assert rel_err(out.float(), ref) < _tol(dtype) * 1.5
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("stride,B,Tin,Cin,Cout", [(2, 2, 60, 64, 128), (3, 1, 51, 32, 64), (5, 2, 40, 128, 96), (8, 1, 64, 64, 128)])
 def test_strided_conv_as_gemm(dev, dtype, stride, B, Tin, Cin, Cout):
