@@ -239,7 +239,7 @@ def main(argv=None):
         return 2
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if not launched and a.gpus > 1:
-        if not a.dry_run and torch.cuda.device_count() < a.gpus:
+        if not a.dry_run and torch.cuda.device_count() < a.gpus and not os.environ.get("FOLEY_BENCH_SHARE_DEVICE"):
             print(f"bench.py: --gpus {a.gpus} but only {torch.cuda.device_count()} HIP device(s) are visible",
                   file=sys.stderr)
             return 2
@@ -250,7 +250,31 @@ def main(argv=None):
     if a.gpus != world:
         print(f"bench.py: --gpus {a.gpus} does not match the launcher's WORLD_SIZE={world}", file=sys.stderr)
         return 2
-    return run_rank(a, world, rank, local, launched)
+    # stdout carries the ONE JSON line and nothing else: while the rank runs, file descriptor 1 points at stderr (RCCL's
+    # version banner, gloo's connection notice and anything a library prints land there); emit() writes to the real one
+    global _STDOUT_FD
+    sys.stdout.flush()
+    _STDOUT_FD = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        return run_rank(a, world, rank, local, launched)
+    finally:
+        sys.stdout.flush()
+        os.dup2(_STDOUT_FD, 1)
+        os.close(_STDOUT_FD)
+        _STDOUT_FD = None
+
+
+_STDOUT_FD = None
+
+
+def emit(obj) -> None:
+    line = (json.dumps(obj) + "\n").encode()
+    if _STDOUT_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_STDOUT_FD, line)
 
 
 def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
@@ -263,6 +287,8 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
     duration, quant = conf["duration"], conf["quantization"]
     use_dist = world > 1 or (launched and bool(os.environ.get("FOLEY_BENCH_FORCE_DIST")))
     on_gpu = not a.dry_run
+    if on_gpu and os.environ.get("FOLEY_BENCH_SHARE_DEVICE"):      # tests on a 1-GPU box: the ranks share the visible devices (gloo only)
+        local %= torch.cuda.device_count()
     dev = torch.device("cuda", local) if on_gpu else torch.device("cpu")
     if on_gpu:
         torch.cuda.set_device(dev)
@@ -316,9 +342,9 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
         else:
             recs = [rec]
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "backend": a.backend if use_dist else None,
+            emit({"dry_run": True, "n_gpus": world, "backend": a.backend if use_dist else None,
                               "collectives": 1 if use_dist else 0, "broadcast_s": bcast_s, "bundle_bytes": spec.total,
-                              "ranks": recs, "noise_total": float(noise_all.double().sum())}), flush=True)
+                              "ranks": recs, "noise_total": float(noise_all.double().sum())})
         if use_dist:
             dist.destroy_process_group()
         return 0 if ok else 1
@@ -492,7 +518,7 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
             out["extra"] = extra
         if world == 1 and not a.no_cpu_baseline and a.model == "xxl" and a.config != "c5":
             out["cpu_baseline"] = cpu_baseline(sd, dsd, cfg, cond, noise_all, duration)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if use_dist:
         dist.destroy_process_group()
     return 0

@@ -103,6 +103,7 @@ def test_bench_spawns_its_own_ranks(config, bs):
                         "--config", config, "--model", "tiny", "--duration", "1"], env=env, capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
+    assert len([ln for ln in r.stdout.splitlines() if ln.strip()]) == 1, r.stdout[:500]     # stdout = the ONE JSON line
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     out = json.loads(lines[0])

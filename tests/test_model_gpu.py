@@ -670,7 +670,8 @@ def test_bench_single_rank_forced_dist(dev):
                         "--steps", "1", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
-    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert len([ln for ln in r.stdout.splitlines() if ln.strip()]) == 1, r.stdout[:500]     # RCCL's banner went to stderr
+    out = json.loads(r.stdout)
     assert out["n_gpus"] == 1 and out["config"]["collectives"] == 1 and out["value"] > 0
     assert out["roofline"]["kernels"] and out["roofline"]["frac"] > 0
 
@@ -715,6 +716,24 @@ def test_bench_two_ranks_over_rccl(dev):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "c4", "--model", "tiny",
                         "--duration", "1", "--bs", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extra"],
                        env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["config"]["collectives"] == 1 and out["config"]["clips_per_gpu"] == 2
+    assert out["config"]["workload"].startswith("c4") and out["value"] > 0 and out["config"]["broadcast_s"] > 0
+
+
+def test_bench_two_ranks_sharing_one_gpu(dev):
+    """The spawner + two concurrently sampling ranks on real hardware when only one GPU is visible: both ranks sit on
+    cuda:0 (FOLEY_BENCH_SHARE_DEVICE), the bundle travels by ONE gloo broadcast of the device buffer, the timing
+    all-reduce / barriers run as in the RCCL job.  Everything but RCCL itself (covered at world 1 above and by
+    test_bench_two_ranks_over_rccl on a multi-GPU box)."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["FOLEY_BENCH_SHARE_DEVICE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--config", "c4",
+                        "--model", "tiny", "--duration", "1", "--bs", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-extra"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["config"]["collectives"] == 1 and out["config"]["clips_per_gpu"] == 2
