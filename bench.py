@@ -260,6 +260,11 @@ def main(argv=None):
         return run_rank(a, world, rank, local, launched)
     finally:
         sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)      # RCCL printf()s its banner into the C stdio buffer: drain it while 1 -> stderr
+        except OSError:
+            pass
         os.dup2(_STDOUT_FD, 1)
         os.close(_STDOUT_FD)
         _STDOUT_FD = None
