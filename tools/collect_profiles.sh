@@ -11,6 +11,15 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 FILTER='gemm_|attn_|ln_mod|qkv_split|solver_step|dac_|rows_add|latent_rows|gather_rows|add_periodic|cast_kernel|step_increment|rows_to_planes'
 
+# PMC passes on 2 loop iterations (profile_run.py --no-dac), one counter set per run (FETCH_SIZE and
+# WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md "rocprofv3 PMC slots")
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "$FILTER" -d /tmp/pmc_$c -o p -- python $R/tools/profile_run.py --iters 2 --no-dac > /tmp/pmc_$c.log 2>&1
+done
+python $R/tools/pmc_summary.py --traffic-json $OUT/${TAG}_pmc_traffic.json --iters 2 --workload c2/bs1/bf16/xxl \
+  $(find /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE -name "*.db") > $OUT/${TAG}_pmc_mem.md
+cp $OUT/${TAG}_pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json   # bench.py reports roofline.traffic from the file whose source hash matches
+
 python $R/bench.py --steps 5 --warmup 2 > $OUT/${TAG}_bench_c2.json 2> $OUT/${TAG}_bench_c2.err
 tail -c 400 $OUT/${TAG}_bench_c2.json
 python $R/bench.py --config c3 --with-encoders --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $OUT/${TAG}_bench_c3.json 2> $OUT/${TAG}_bench_c3.err
@@ -26,13 +35,6 @@ python $R/tools/prof_summary.py $(find /tmp/kt8 -name "*.db" | head -1) > $OUT/$
 rocprofv3 --kernel-trace --stats -d /tmp/kt5 -o kt -- python $R/bench.py --config c5 --steps 1 --warmup 0 --no-cpu-baseline --no-extra > /tmp/kt5.log 2>&1
 python $R/tools/prof_summary.py $(find /tmp/kt5 -name "*.db" | head -1) > $OUT/${TAG}_bench_c5_kernel_stats.md
 
-# PMC passes on 2 loop iterations (profile_run.py --no-dac), one counter set per run (FETCH_SIZE and
-# WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md "rocprofv3 PMC slots")
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "$FILTER" -d /tmp/pmc_$c -o p -- python $R/tools/profile_run.py --iters 2 --no-dac > /tmp/pmc_$c.log 2>&1
-done
-python $R/tools/pmc_summary.py --traffic-json $OUT/${TAG}_pmc_traffic.json --iters 2 --workload c2/bs1/bf16/xxl \
-  $(find /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE -name "*.db") > $OUT/${TAG}_pmc_mem.md
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-include-regex "$FILTER" -d /tmp/pmc_sq -o p -- python $R/tools/profile_run.py --iters 2 --no-dac > /tmp/pmc_sq.log 2>&1
 python $R/tools/pmc_summary.py $(find /tmp/pmc_sq -name "*.db") > $OUT/${TAG}_pmc_sq.md
 ls -la $OUT | tail -14
