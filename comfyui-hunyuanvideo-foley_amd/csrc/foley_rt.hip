@@ -863,14 +863,26 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
       GemmArgs g1 = gemm_plain(ss[1].xn, ss[1].rows, w.cq[1], ss[1].qkv, D);
       g0.qs = split_args(0, 1, w.cqn[0], nullptr, pl.pos_linear);
       g1.qs = split_args(1, 1, w.cqn[1], nullptr, pl.pos_linear);
-      PROF("triple.cross q GEMM + head split", gf(M + Mv, D, D), gb(M + Mv, D, D, es) + 1.0 * D * D * es,
-           launch_gemm_pair(g0, g1, T, EPI_QKV_SPLIT, st));
       const int Ltp = (Lt + 31) & ~31;
       const size_t offk = (size_t)blk * ncfg * H * Lt * 128 * es;
       const size_t offv = (size_t)blk * ncfg * H * (bf ? Ltp : Lt) * 128 * es;
-      AttnArgs a{c->Q, (char*)c->txt_k + offk, (char*)c->txt_v + offv, Bc, H, S, Lt, clips, c->att_v, c->att_a, Lv,
-                 T, bf ? Ltp : 0};
-      PROF("triple.cross attention", af(Bc, S, Lt), ab(Bc, S, Lt), launch_attention(a, T, st));
+      // 16-bit modes: the projection may run the attention against the <= 96 cached text keys in its epilogue (small grids:
+      // gemm_impl.h decides and reports through attn_fused); the q tensor and the attention launch are then gone
+      int fused = 0;
+      if (bf && Lt <= 96 && Ltp >= 96) {
+        for (int s = 0; s < 2; ++s) {
+          QkvSplitArgs& q = s ? g1.qs : g0.qs;
+          q.attn_k = (char*)c->txt_k + offk; q.attn_vt = (char*)c->txt_v + offv; q.attn_out = ss[s].att;
+          q.attn_skv = Lt; q.attn_pitch = Ltp; q.attn_bdiv = clips; q.attn_fused = &fused;
+        }
+      }
+      PROF("triple.cross q GEMM + head split (+ cross attention on small grids)", gf(M + Mv, D, D),
+           gb(M + Mv, D, D, es) + 1.0 * D * D * es, launch_gemm_pair(g0, g1, T, EPI_QKV_SPLIT, st));
+      if (!fused) {
+        AttnArgs a{c->Q, (char*)c->txt_k + offk, (char*)c->txt_v + offv, Bc, H, S, Lt, clips, c->att_v, c->att_a, Lv,
+                   T, bf ? Ltp : 0};
+        PROF("triple.cross attention", af(Bc, S, Lt), ab(Bc, S, Lt), launch_attention(a, T, st));
+      }
       TRY(gated2("triple.cross proj GEMM (gated residual)", w.cproj[0], w.cproj[1], false, 5));
     }
     // 3. GELU-tanh MLPs (hifi_foley.py:321-331)
@@ -1331,6 +1343,9 @@ extern "C" int foley_op_gemm(const foley_gemm_desc* d, void* stream) {
     for (int i = 0; i < 3; ++i) { a.gain[i] = q->gain[i]; a.pos[i] = q->pos[i]; a.dst[i] = q->dst[i]; }
     a.S_tot = q->S_tot; a.tok_off = q->tok_off; a.out_dtype = q->out_dtype; a.vt_pitch = q->vt_pitch;
     a.eps = q->eps; a.cos_tab = q->cos_tab; a.sin_tab = q->sin_tab;
+    a.attn_k = q->attn_k; a.attn_vt = q->attn_vt; a.attn_out = q->attn_out;
+    a.attn_skv = q->attn_skv; a.attn_pitch = q->attn_pitch; a.attn_bdiv = q->attn_bdiv; a.attn_fused = q->attn_fused;
+    if (q->attn_fused) *q->attn_fused = 0;
   }
   int ks = 1;
   const int rc = launch_gemm(g, d->dtype, d->epilogue, d->tile, (hipStream_t)stream, &ks);

@@ -408,12 +408,26 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
 // transposed [clip, H, 128, pitch] for the bf16 attention kernel, 8 tokens (16 bytes) per store on
 // destination-aligned groups.  Same math as qkv_split_kernel (rowops.hip), which stays for callers
 // that have the projection in memory.
-template <typename T, int BM, int BN, int WM, int WN, int XW = 0, bool EARLY = true>
+//
+// ATTN (EPI_QKV_ATTN, 16-bit operands, nK = 1): the cross-attention q projection carries the attention itself
+// (hifi_foley.py:271-319: q = [v; a] against the <= 96 cached text keys of the clip's CFG half).  The tile's rotated q rows
+// stay in LDS as a swizzled 16-bit image, the head's K and V^T images (requested as 16-byte register loads BEFORE the
+// transpose barriers, so their latency hides under the head-split math) join them, and one wave per 32-query block runs
+// QK^T -> online softmax -> PV from LDS fragments and writes the attention output rows [M, H*128] - the q tensor, the
+// attention launch and the boundary in front of it are gone (QkvSplitArgs::attn_*).
+template <typename T, int BM, int BN, int WM, int WN, int XW = 0, bool EARLY = true, bool ATTN = false>
 __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&acc)[BM / WM / 32][BN / WN / 32],
                                                   unsigned char* lds_raw, int m0, int n0) {
   static_assert(BN == 128, "one head per tile");
   constexpr int NT = (WM * WN + XW) * 64, TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
   constexpr int CP = VecStore<T>::CP, TPR = 128 / CP, RP = NT / TPR, PASSES = BM / RP;
+  static_assert(!ATTN || (sizeof(T) == 2 && EARLY && BM / 32 <= NT / 64), "fused cross attention: 16-bit operands, one wave per query block");
+  // LDS map of the fused form (the ring is dead): fp32 tile | Q image [BM][256 B] | K image [96][256 B] | V^T image [128][256 B];
+  // 16-byte chunk c of image row r sits at position c ^ (r & 15): every ds_read_b128 lane group meets 16 distinct positions
+  // a tile that straddles the CFG halves keeps its second text set too: K image over the (dead) fp32 tile, V^T image behind
+  constexpr int OFF_Q = BM * BN * 4, OFF_K = OFF_Q + BM * 256, OFF_V = OFF_K + 96 * 256, OFF_K1 = 0, OFF_V1 = OFF_V + 128 * 256;
+  static_assert(!ATTN || 96 * 256 <= BM * BN * 4, "second K image aliases the fp32 tile");
+  constexpr int KVC = (96 * 16 + 128 * 12 + NT - 1) / NT;   // 16-byte chunks of one K / V^T set per thread
   static_assert(NT % TPR == 0 && BM % RP == 0 && PASSES >= 1, "tile / epilogue mismatch");
   static_assert(TPR == 16 || TPR == 32, "head-split epilogue: 16 or 32 lanes per row");
   const QkvSplitArgs& q = g.qs;
@@ -493,6 +507,52 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&ac
     }
   };
   if constexpr (EARLY) request();
+  // fused cross attention: the K / V^T chunks of the tile's (at most two) text sets, requested here
+  u32x4 kv[ATTN ? 2 : 1][ATTN ? KVC : 1];
+  int set0 = 0, set1 = 0;
+  auto kv_request = [&](int which, int set) {
+    if constexpr (ATTN) {
+      const T* Kb = (const T*)q.attn_k + ((long)set * qH + h) * q.attn_skv * 128;
+      const T* Vb = (const T*)q.attn_vt + ((long)set * qH + h) * 128 * q.attn_pitch;
+#pragma unroll
+      for (int i = 0; i < KVC; ++i) {
+        const int c = tid + NT * i;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (c < 96 * 16) {
+          const int row = c >> 4, ch = c & 15;
+          if (row < q.attn_skv) v = *(const u32x4*)(Kb + (long)row * 128 + ch * 8);
+        } else if (c < 96 * 16 + 128 * 12) {
+          const int cc = c - 96 * 16, d = cc / 12, ch = cc - d * 12;
+          v = *(const u32x4*)(Vb + (long)d * q.attn_pitch + ch * 8);
+        }
+        kv[which][i] = v;
+      }
+    }
+  };
+  auto kv_to_lds = [&](int which) {
+    if constexpr (ATTN) {
+#pragma unroll
+      for (int i = 0; i < KVC; ++i) {
+        const int c = tid + NT * i;
+        if (c < 96 * 16) {
+          const int row = c >> 4, ch = c & 15;
+          *(u32x4*)(lds_raw + (which ? OFF_K1 : OFF_K) + row * 256 + ((ch ^ (row & 15)) << 4)) = kv[which][i];
+        } else if (c < 96 * 16 + 128 * 12) {
+          const int cc = c - 96 * 16, d = cc / 12, ch = cc - d * 12;
+          *(u32x4*)(lds_raw + (which ? OFF_V1 : OFF_V) + d * 256 + ((ch ^ (d & 15)) << 4)) = kv[which][i];
+        }
+      }
+    }
+  };
+  if constexpr (ATTN) {
+    const int row_last = min(m0 + BM, gM) - 1;
+    set0 = (m0 / qL) / q.attn_bdiv;
+    set1 = (row_last / qL) / q.attn_bdiv;     // workgroup-uniform; the launcher guarantees set1 <= set0 + 1
+    if (live) {
+      kv_request(0, set0);
+      if (set1 != set0) kv_request(1, set1);
+    }
+  }
   // transposed-V tiles: the thread's channel bias, requested before the barriers too (it used to be a global load
   // inside the item loop, in front of every item's LDS reads)
   const float vbias = (live && vtrans && g.bias) ? g.bias[n0 + (tid & 127)] : 0.f;
@@ -540,7 +600,113 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&ac
           v[2 * w + 1] = y1 * cs[p][w] + y0 * sn[p][w];
         }
       }
-      if (doff[p] >= 0) VecStore<T>::store((T*)dstp + doff[p], v);
+      if constexpr (ATTN) {
+        uint4 w;
+        w.x = pack_h2<T>(v[0], v[1]); w.y = pack_h2<T>(v[2], v[3]); w.z = pack_h2<T>(v[4], v[5]); w.w = pack_h2<T>(v[6], v[7]);
+        *(uint4*)(lds_raw + OFF_Q + rl * 256 + (((tc >> 3) ^ (rl & 15)) << 4)) = w;
+      } else {
+        if (doff[p] >= 0) VecStore<T>::store((T*)dstp + doff[p], v);
+      }
+    }
+    if constexpr (ATTN) {
+      // ---- cross attention of the tile's 32-query blocks against the text set(s), operands from the LDS images
+      const int j = lane & 31;
+      const float scale2 = 0.08838834764831845f * 1.4426950408889634f;   // log2(e) / sqrt(128)
+      const int pi = 16 * ((j >> 2) & 1) + (j & 3) + 4 * (j >> 3);       // A-row j of the score MFMA carries key kt + pi (attention.hip)
+      const int Skv = q.attn_skv;
+      constexpr int QB = BM / 32;
+      static_assert(2 * QB <= NT / 64, "one wave per (query block, text set)");
+      const bool two = set1 != set0;             // workgroup-uniform
+      if (two) __syncthreads();                  // every thread is done with the fp32 tile (the second K image lands on it)
+      kv_to_lds(0);
+      if (two) kv_to_lds(1);
+      __syncthreads();                           // Q image and the K / V^T images are complete
+      {
+        const int second = wave >= QB ? 1 : 0;   // waves QB .. 2 QB - 1 serve the second text set of a straddling tile
+        const int set = second ? set1 : set0;
+        const unsigned char* const Kimg = lds_raw + (second ? OFF_K1 : OFF_K);
+        const unsigned char* const Vimg = lds_raw + (second ? OFF_V1 : OFF_V);
+        if (wave < (two ? 2 * QB : QB)) {
+          const int rl = (wave - second * QB) * 32 + j, row = m0 + rl;
+          const bool mine = row < gM && (row / qL) / q.attn_bdiv == set;
+          if (__builtin_amdgcn_ballot_w64(mine) != 0) {
+            bf16x8 qf[8];
+#pragma unroll
+            for (int st = 0; st < 8; ++st)
+              qf[st] = *(const bf16x8*)(lds_raw + OFF_Q + rl * 256 + (((2 * st + kh) ^ (rl & 15)) << 4));
+            f32x16 o[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+            float m_run = -INFINITY, l_run = 0.f;
+            for (int kt = 0; kt < Skv; kt += 32) {
+              bf16x8 kf[8], vf[2][4];
+              const int kr = kt + pi;
+#pragma unroll
+              for (int st = 0; st < 8; ++st)
+                kf[st] = *(const bf16x8*)(Kimg + kr * 256 + (((2 * st + kh) ^ (kr & 15)) << 4));
+#pragma unroll
+              for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                  const int vr = d * 32 + j;
+                  vf[u][d] = *(const bf16x8*)(Vimg + vr * 256 + ((((kt >> 3) + 2 * kh + u) ^ (vr & 15)) << 4));
+                }
+              f32x16 sc;
+#pragma unroll
+              for (int e = 0; e < 16; ++e) sc[e] = 0.f;
+#pragma unroll
+              for (int st = 0; st < 8; ++st) sc = mfma16<T>(kf[st], qf[st], sc);
+              float mx = -INFINITY;
+#pragma unroll
+              for (int e = 0; e < 16; ++e) {
+                sc[e] = (kt + 16 * kh + e < Skv) ? sc[e] * scale2 : -INFINITY;
+                mx = fmaxf(mx, sc[e]);
+              }
+              mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+              const float m_new = fmaxf(m_run, mx);
+              float ps = 0.f;
+              bf16x8 pb[2];
+#pragma unroll
+              for (int e = 0; e < 16; ++e) {
+                const float pv = __builtin_amdgcn_exp2f(sc[e] - m_new);
+                ps += pv;
+                pb[e >> 3][e & 7] = to_carrier<T>(pv);
+              }
+              ps += __shfl_xor(ps, 32, 64);
+              // the 64 accumulator rescales only when some query's running maximum moved (never on the first tile: o = 0)
+              if (kt > 0 && __builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                l_run *= alpha;
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+#pragma unroll
+                  for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+              }
+              l_run += ps;
+              m_run = m_new;
+#pragma unroll
+              for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) o[d] = mfma16<T>(vf[u][d], pb[u], o[d]);
+            }
+            if (mine) {
+              const float inv = 1.0f / l_run;
+              T* dst = (T*)q.attn_out + (long)row * ((long)qH * 128) + h * 128 + 4 * kh;
+#pragma unroll
+              for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                  uint2 w;
+                  w.x = pack_h2<T>(o[d][g4 * 4 + 0] * inv, o[d][g4 * 4 + 1] * inv);
+                  w.y = pack_h2<T>(o[d][g4 * 4 + 2] * inv, o[d][g4 * 4 + 3] * inv);
+                  *(uint2*)(dst + d * 32 + 8 * g4) = w;
+                }
+            }
+          }
+        }
+      }
     }
   } else {
     // V^T: walk the clip segments of this row tile; an item = (channel d, 8 destination columns)

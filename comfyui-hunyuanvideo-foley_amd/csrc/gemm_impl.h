@@ -740,6 +740,23 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     if (g1) return foley_set_err("conv3 kernel has no two-problem form", __FILE__, __LINE__);
     return launch_gemm_conv3(g, DtCode<T>::v, epi, tile == 11 ? 1 : 3, st);
   }
+  // Cross-attention q projections may carry the attention in their epilogue (QkvSplitArgs::attn_out): taken when the problem
+  // landed on the 64-row head-split tile (small grids, where the attention launch and its boundary cost more than its math);
+  // otherwise the plain head split runs and the caller launches the attention (attn_fused tells).  FOLEY_CROSS_FUSED=0: never.
+  if (epi == EPI_QKV_SPLIT) {
+    static const bool fuse_on = []() { const char* e = getenv("FOLEY_CROSS_FUSED"); return !(e && e[0] == '0'); }();
+    auto fits = [](const GemmArgs& q) {
+      const QkvSplitArgs& s = q.qs;
+      return s.attn_out && s.attn_k && s.attn_vt && s.nK == 1 && s.vt_pitch == 0 && s.attn_skv >= 1 && s.attn_skv <= 96 &&
+             s.attn_pitch >= 96 && s.attn_pitch % 8 == 0 && s.attn_bdiv >= 1 &&
+             ((long)s.L * s.attn_bdiv >= 64 || q.M <= 2L * s.L * s.attn_bdiv) &&   // a 64-row tile meets at most two text sets
+             !(((uintptr_t)s.attn_k | (uintptr_t)s.attn_vt | (uintptr_t)s.attn_out) & 15);
+    };
+    const bool fuse = fuse_on && sizeof(T) == 2 && tile == 27 && fits(g) && (!g1 || fits(g1s));
+    if (g.qs.attn_fused) *g.qs.attn_fused = fuse ? 1 : 0;
+    if (g1 && g1s.qs.attn_fused) *g1s.qs.attn_fused = fuse ? 1 : 0;
+    if (fuse) epi = EPI_QKV_ATTN;
+  }
   if (tile == 15 || tile == 19 || tile == 21 || tile == 22 || tile == 23 || tile == 25 || tile == 26 || tile == 27 || tile == 28 || tile == 29) {
     if constexpr (__is_same(T, bf16_t)) return launch_gemm_ws_bf16(g, g1, epi, tile, st);
     else if constexpr (__is_same(T, f16_t)) return launch_gemm_ws_f16(g, g1, epi, tile, st);

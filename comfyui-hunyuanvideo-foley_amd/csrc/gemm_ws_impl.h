@@ -225,6 +225,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmPair& pr) {
     if constexpr (NW == 4) {
       f32x16 none[FM][FN];
       if constexpr (EPI == EPI_QKV_SPLIT) gemm_epilogue_qkv<T, BM, BN, WM, WN, LW>(g, none, lds, m0, n0);
+      else if constexpr (EPI == EPI_QKV_ATTN) gemm_epilogue_qkv<T, BM, BN, WM, WN, LW, true, true>(g, none, lds, m0, n0);
       else gemm_epilogue_lds<T, EPI, BM, BN, WM, WN, LW>(g, none, lds, m0, n0, ks);   // vector epilogue only (gemm_impl.h launcher)
     }
     return;
@@ -428,6 +429,9 @@ __device__ __forceinline__ void gemm_ws_body(const GemmPair& pr) {
   constexpr int XW = NW == 4 ? LW : 0;   // helper waves of the epilogue (see the loader branch)
   if constexpr (EPI == EPI_QKV_SPLIT) {
     gemm_epilogue_qkv<T, BM, BN, WM, WN, XW, NW == 4 && BM <= 128>(g, acc, lds, m0, n0);
+  } else if constexpr (EPI == EPI_QKV_ATTN) {
+    static_assert(NW == 4 && BM <= 128, "fused cross attention: four-consumer small tiles");
+    gemm_epilogue_qkv<T, BM, BN, WM, WN, XW, true, true>(g, acc, lds, m0, n0);
   } else if constexpr (NW == 4) {
     gemm_epilogue_lds<T, EPI, BM, BN, WM, WN, XW>(g, acc, lds, m0, n0, ks);   // the launcher sends scalar-epilogue problems to the eight-consumer twins
   } else {
@@ -743,8 +747,10 @@ int launch_ws_one(const GemmArgs& g, const GemmArgs* g1, hipStream_t st) {
   pr.tiles0 = ntiles(g);
   const int tiles = pr.tiles0 + (g1 ? ntiles(*g1) : 0);
   constexpr size_t lds_ring = (size_t)NS * (BM * 128 + BN * (WF ? 64 : 128));
-  constexpr size_t lds_epi = (size_t)BM * BN * 4;            // the epilogues transpose the accumulator tile through LDS
+  constexpr size_t lds_epi = (size_t)BM * BN * 4 +           // the epilogues transpose the accumulator tile through LDS
+                             (EPI == EPI_QKV_ATTN ? (size_t)BM * 256 + 96 * 256 + 2 * 128 * 256 : 0);   // + Q / K / V^T images (two V^T: straddling tiles)
   constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
+  static_assert(lds <= 160 * 1024, "LDS budget");
   auto k = gemm_ws_kernel<T, BM, BN, WM, WN, NS, LW, EPI, WF>;
   static std::atomic<unsigned long long> raised{0};
   {
@@ -811,7 +817,8 @@ int launch_gemm_ws_t(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, h
     return launch_ws_one<T, 192, 128, 2, 2, 4, 4, EPI_QKV_SPLIT, 0>(g, g1, st);
   }
   if (tile == 27) {   // 64x128, four consumer waves of 32x64, 6 x 24 KiB ring: the fused head split of small problems only
-    if (g.wfmt != 0 || epi != EPI_QKV_SPLIT) return foley_set_err("wave-specialised GEMM: tile 27 is the bf16 head-split tile", __FILE__, __LINE__);
+    if (g.wfmt != 0 || (epi != EPI_QKV_SPLIT && epi != EPI_QKV_ATTN)) return foley_set_err("wave-specialised GEMM: tile 27 is the bf16 head-split tile", __FILE__, __LINE__);
+    if (epi == EPI_QKV_ATTN) return launch_ws_one<T, 64, 128, 2, 2, 6, 4, EPI_QKV_ATTN, 0>(g, g1, st);   // + cross attention in the epilogue
     return launch_ws_one<T, 64, 128, 2, 2, 6, 4, EPI_QKV_SPLIT, 0>(g, g1, st);
   }
   if (g.wfmt == 0) {

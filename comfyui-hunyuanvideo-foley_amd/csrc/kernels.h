@@ -22,6 +22,8 @@ enum GemmEpi {
   EPI_DAC = 6,        // v = acc + bias (+ res); out0(f32) = v; out1(f32) = snake(v)
   EPI_QKV_SPLIT = 7,  // fused head split: per 128-column head tile RMSNorm + RoPE (q, k) or V^T, written
                       // straight to the attention operands (GemmArgs::qs); needs a 128-wide tile
+  EPI_QKV_ATTN = 8,   // internal (chosen by the launcher for EPI_QKV_SPLIT problems with qs.attn_out): head split of a q
+                      // projection + attention against the cached keys in the same epilogue
   EPI_COUNT
 };
 
@@ -41,6 +43,15 @@ struct QkvSplitArgs {
   // ([L, 64] fp32 each) - one load level instead of two dependent ones in front of the stores
   const float* rcos[3];
   const float* rsin[3];
+  // optional, fused GEMM epilogue only (nK = 1, 16-bit operands, 64-row tiles: the cross-attention q projection): run the
+  // attention against <= 96 cached keys inside the epilogue and write its output rows instead of q.
+  const void* attn_k;    // [sets, H, attn_skv, 128] operand type
+  const void* attn_vt;   // [sets, H, 128, attn_pitch] operand type, finite beyond attn_skv
+  void* attn_out;        // [M, H * 128] operand type; null => plain head split
+  int attn_skv, attn_pitch;
+  int attn_bdiv;         // text set of row r: (r / L) / attn_bdiv
+  int* attn_fused;       // HOST pointer (never read by the device), may be null: the launcher stores 1 when the fused form ran,
+                         // 0 when the problem took the plain head split (q in dst[0]; the caller launches the attention)
 };
 struct GemmArgs {
   const void* A;

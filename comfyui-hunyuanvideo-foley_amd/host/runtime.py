@@ -55,7 +55,17 @@ class QkvSplitDescC(C.Structure):
         ("gain", C.c_void_p * 3), ("pos", C.c_void_p * 3), ("dst", C.c_void_p * 3),
         ("out_dtype", C.c_int32), ("vt_pitch", C.c_int32), ("S_tot", C.c_int32), ("tok_off", C.c_int32),
         ("eps", C.c_float), ("cos_tab", C.c_void_p), ("sin_tab", C.c_void_p),
+        ("attn_k", C.c_void_p), ("attn_vt", C.c_void_p), ("attn_out", C.c_void_p),
+        ("attn_skv", C.c_int32), ("attn_pitch", C.c_int32), ("attn_bdiv", C.c_int32),
+        ("attn_fused", C.POINTER(C.c_int32)),
     ]
+
+
+def _qkv_fused(self) -> bool:
+    return bool(getattr(self, "_flag", C.c_int32(0)).value)
+
+
+QkvSplitDescC.fused = _qkv_fused
 
 
 class GemmDescC(C.Structure):
@@ -81,7 +91,7 @@ class ProfEntryC(C.Structure):
 
 
 PROGRESS_CB = C.CFUNCTYPE(None, C.c_int32, C.c_int32, C.c_void_p)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _SIGNATURES = {
     "foley_abi_version": (C.c_uint32, []),
@@ -456,8 +466,10 @@ EPI_QKV_SPLIT = 7
 
 
 def qkv_split_desc(L, H, gains: Sequence, poss: Sequence, dsts: Sequence, S_tot, tok_off, eps, cos, sin,
-                   vt_pitch: int = 0) -> QkvSplitDescC:
-    """Descriptor of the fused head-split epilogue (op_gemm(..., epilogue=EPI_QKV_SPLIT, qkv=desc))."""
+                   vt_pitch: int = 0, attn=None) -> QkvSplitDescC:
+    """Descriptor of the fused head-split epilogue (op_gemm(..., epilogue=EPI_QKV_SPLIT, qkv=desc)).
+    attn = (k [sets,H,Skv,128], vt [sets,H,128,pitch], out [M,H*128], bdiv): ask for the attention against those cached
+    keys in the same epilogue; desc.fused() tells after the launch whether the library took that form."""
     q = QkvSplitDescC()
     q.L, q.H, q.nK = L, H, len(dsts)
     for i in range(len(dsts)):
@@ -467,6 +479,13 @@ def qkv_split_desc(L, H, gains: Sequence, poss: Sequence, dsts: Sequence, S_tot,
     q.out_dtype, q.vt_pitch, q.S_tot, q.tok_off, q.eps = dt_of(dsts[0]), vt_pitch, S_tot, tok_off, eps
     q.cos_tab, q.sin_tab = _ptr(cos), _ptr(sin)
     q._keepalive = (list(gains), list(poss), list(dsts), cos, sin)
+    if attn is not None:
+        k, vt, out, bdiv = attn
+        q.attn_k, q.attn_vt, q.attn_out = _ptr(k), _ptr(vt), _ptr(out)
+        q.attn_skv, q.attn_pitch, q.attn_bdiv = k.shape[2], vt.shape[3], bdiv
+        q._flag = C.c_int32(0)
+        q.attn_fused = C.pointer(q._flag)
+        q._keepalive += (k, vt, out)
     return q
 
 

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FOLEY_ABI_VERSION 7   /* 7: FOLEY_DT_F16 as a compute dtype (foley_config.compute_dtype, op descriptors); 6: foley_rowbcast.Ls (mode 2: nearest-exact up-sampled operand); 5: reference-keyed loading (foley_weights_*, foley_load_tensor, foley_bcast_weights); 4: fp8 weight storage (dtype codes 3/4, foley_gemm_desc.ldw/.wfmt); 3: foley_profile_forward; 2: foley_gemm_desc gained partials / qkv / rstride; foley_op_ln_mod_pending, foley_dac_encode */
+#define FOLEY_ABI_VERSION 8   /* 8: foley_qkv_split_desc.attn_* (cross attention in the epilogue of its q projection); 7: FOLEY_DT_F16 as a compute dtype (foley_config.compute_dtype, op descriptors); 6: foley_rowbcast.Ls (mode 2: nearest-exact up-sampled operand); 5: reference-keyed loading (foley_weights_*, foley_load_tensor, foley_bcast_weights); 4: fp8 weight storage (dtype codes 3/4, foley_gemm_desc.ldw/.wfmt); 3: foley_profile_forward; 2: foley_gemm_desc gained partials / qkv / rstride; foley_op_ln_mod_pending, foley_dac_encode */
 
 enum foley_dtype {
   FOLEY_DT_F32 = 0, FOLEY_DT_BF16 = 1, FOLEY_DT_I32 = 2,
@@ -196,6 +196,16 @@ typedef struct foley_qkv_split_desc {
   int32_t S_tot, tok_off;
   float eps;
   const float* cos_tab; const float* sin_tab;   /* [P, 64] */
+  /* Optional (nK = 1, 16-bit operands): attention of the projected q rows against <= 96 cached keys in the same epilogue
+   * (TwoStreamCABlock cross attention to the text, hifi_foley.py:271-319): attn_out [M, H*128] receives
+   * softmax(q k^T / sqrt(128)) v per head, rows ordered like the GEMM's.  Keys attn_k [sets, H, attn_skv, 128], values
+   * TRANSPOSED attn_vt [sets, H, 128, attn_pitch] (attn_pitch >= 96, finite beyond attn_skv), both in the operand dtype;
+   * the set of row r is (r / L) / attn_bdiv.  The library takes the fused form on small grids only (its 64-row head-split
+   * tile) and says so in *attn_fused (may be null): 1 = attn_out written, dst[0] untouched; 0 = plain head split into
+   * dst[0], the caller runs foley_op_attention itself. */
+  const void* attn_k; const void* attn_vt; void* attn_out;
+  int32_t attn_skv, attn_pitch, attn_bdiv;
+  int32_t* attn_fused;
 } foley_qkv_split_desc;
 
 typedef struct foley_gemm_desc {

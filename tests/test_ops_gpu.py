@@ -644,6 +644,49 @@ def test_gemm_fused_head_split(dev, dtype, B, L, H, Lv, tile):
         assert rel_err(dv[:, :, Lv:], v.transpose(1, 2)) < tol
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("clips,L,H,Skv,tile", [(1, 250, 12, 77, 0), (1, 40, 12, 77, 0), (2, 50, 2, 77, 27), (3, 8, 2, 33, 27), (1, 250, 2, 96, 27),
+                                                 (8, 250, 12, 77, 0)])
+def test_gemm_cross_q_with_attention_epilogue(dev, dtype, clips, L, H, Skv, tile):
+    """Cross-attention q projection with the attention against the cached text keys in its epilogue (hifi_foley.py:271-319;
+    QkvSplitArgs::attn_*): rows [cfg = 2][clip][l], two text sets (one per CFG half) - tiles that straddle the halves run
+    both.  Against the oracle math, and bit-identical to the unfused pair (head-split GEMM, then foley_op_attention) is
+    not required (the unfused q is rounded once more on its way through memory - the same values here).  Large grids
+    (last case) must report the plain head split and leave q in dst[0]."""
+    K, D = 256, H * 128
+    Bc, M = 2 * clips, 2 * clips * L
+    pitch = 96
+    x, w, b = _rand((M, K), 100), _rand((D, K), 101, 1 / math.sqrt(K)), _rand((D,), 102, 0.1)
+    gq = 1 + 0.1 * _rand((128,), 103)
+    pos = torch.arange(L).to(torch.int32)
+    cos, sin = tables.rope_table(L + 1)
+    kk, vv = _rand((2, H, Skv, 128), 104), _rand((2, H, Skv, 128), 105)
+    q = F.linear(_q(x, dtype), _q(w, dtype), b).view(Bc, L, H, 128)
+    c2, s2 = cos[pos.long()].repeat_interleave(2, 1), sin[pos.long()].repeat_interleave(2, 1)
+    rq = _q(O.apply_rope(O.rms_norm(q, gq, 1e-6), c2, s2).transpose(1, 2), dtype)          # [Bc, H, L, 128], rounded like the kernel's
+    sets = torch.arange(Bc) // clips
+    ref = O.sdpa(rq, _q(kk, dtype)[sets], _q(vv, dtype)[sets]).transpose(1, 2).reshape(M, D)
+    kd = kk.to(dev, dtype)
+    vt = torch.zeros(2, H, 128, pitch, device=dev, dtype=dtype)
+    vt[..., :Skv] = vv.transpose(2, 3).to(dev, dtype)
+    dq = torch.zeros(Bc, H, L, 128, device=dev, dtype=dtype)
+    out = torch.full((M, D), float("nan"), device=dev, dtype=dtype)
+    desc = rt.qkv_split_desc(L, H, [gq.to(dev)], [pos.to(dev)], [dq], L, 0, 1e-6, cos.to(dev), sin.to(dev),
+                             attn=(kd, vt, out, clips))
+    rt.op_gemm(x.to(dev, dtype), w.to(dev, dtype), b.to(dev), epilogue=rt.EPI_QKV_SPLIT, qkv=desc, tile=tile)
+    tol = {torch.bfloat16: 6e-3, torch.float16: 1e-3}[dtype]
+    b128 = (M + 127) // 128 * H                 # the launcher's grid measure: the 64-row head-split tile serves 24 .. 100
+    big = b128 > 100
+    assert desc.fused() == (tile == 27 or 24 <= b128 <= 100)
+    if desc.fused():
+        assert float(dq.float().abs().max()) == 0.0                    # q never left the chip
+        assert rel_err(out.float(), ref) < tol
+    else:
+        assert rel_err(dq.float(), rq) < tol and bool(torch.isnan(out.float()).all())
+        rt.op_attention(dq, kd, vt, out, out, 0, kv_bdiv=clips)
+        assert rel_err(out.float(), ref) < tol
+
+
 def test_latent_rows(dev):
     x = _rand((3, 128, 50), 60)
     out = torch.empty(2 * 3 * 50, 128, device=dev, dtype=torch.bfloat16)
