@@ -636,8 +636,10 @@ int launch_ln_mod_pair(const LnArgs& a0, const LnArgs& a1, int D, float eps, int
       else FOLEY_LAUNCH((ln_mod_kernel<bf16_t, V, false>), grid, block, 0, st, pr, D, eps);          \
     }                                                                                                      \
   }
-  // rows that split evenly over 2 / 3 waves (D = 1536: 3 waves x 2 float4 per lane; 1408 / 256: one wave)
-  static const int wide = []() { const char* e = getenv("FOLEY_LN_WIDE"); return e ? atoi(e) : 3; }();   // A/B switch (0 = one wave per row)
+  // rows that split evenly over 2 / 3 waves (D = 1536: 2 waves x 3 float4 per lane, or 3 x 2; 1408 / 256: one wave).  Two waves
+  // per row since the slabs are 16-bit (round 3, one box: bs=1 loop 347.4 -> 345.8 ms, bs=8 1525.7 -> 1520.2, 30 s 1488.7 -> 1478.6);
+  // three were better with fp32 slabs (round 2)
+  static const int wide = []() { const char* e = getenv("FOLEY_LN_WIDE"); return e ? atoi(e) : 2; }();   // A/B switch (0 = one wave per row, 3)
   const int total_rows = a0.M + a1.M;
   if (wide && total_rows <= 4096 && D % (4 * 64 * 3) == 0 && D / (4 * 64 * 3) <= 4 && wide == 3) {
 #define FOLEY_LNW(V, W)                                                                                               \
