@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -175,6 +176,7 @@ struct foley_ctx {
   // timing
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
+  std::atomic<int> abort_req{0};   // foley_abort(): checked by foley_sample between iterations
   // DAC workspace (grown on demand)
   DevBuf dacP, dacQ, dacR, dacZ;
   // reference-keyed weight store (weights.hip): ctx-owned packed arena
@@ -1083,6 +1085,7 @@ extern "C" int foley_sample(foley_ctx* c, float* latents, int use_graph, foley_p
     if (e != hipSuccess) return FAIL(FOLEY_ERR_HIP, hipGetErrorString(e));
     c->graph_guidance = pl.guidance;
   }
+  c->abort_req.store(0, std::memory_order_relaxed);   // a request left over from before this loop is not for it
   HIPTRY(hipEventRecord(c->ev0, st));
   HIPTRY(hipMemcpyAsync(c->x_cur, latents, xbytes, hipMemcpyDeviceToDevice, st));
   HIPTRY(hipMemsetAsync(c->step_ctr, 0, sizeof(int), st));
@@ -1095,10 +1098,23 @@ extern "C" int foley_sample(foley_ctx* c, float* latents, int use_graph, foley_p
       HIPTRY(hipStreamSynchronize(st));
       cb(it + 1, pl.n_iter, user);
     }
+    if (c->abort_req.exchange(0, std::memory_order_acq_rel)) {   // latents hold the state after iteration it + 1
+      if (!cb) {
+        HIPTRY(hipMemcpyAsync(latents, c->x_cur, xbytes, hipMemcpyDeviceToDevice, st));
+        HIPTRY(hipStreamSynchronize(st));
+      }
+      return FAIL(FOLEY_ERR_ABORTED, "sampling loop aborted by foley_abort()");
+    }
   }
   HIPTRY(hipMemcpyAsync(latents, c->x_cur, xbytes, hipMemcpyDeviceToDevice, st));
   HIPTRY(hipEventRecord(c->ev1, st));
   c->timed = true;
+  return 0;
+}
+
+extern "C" int foley_abort(foley_ctx* c) {
+  if (!c) return FAIL(FOLEY_ERR_INVALID, "null context");
+  c->abort_req.store(1, std::memory_order_release);
   return 0;
 }
 

@@ -108,6 +108,7 @@ _SIGNATURES = {
     "foley_prepare": (C.c_int, [C.c_void_p, C.POINTER(FoleyPlanC), C.c_void_p]),
     "foley_dit_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "foley_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, PROGRESS_CB, C.c_void_p, C.c_void_p]),
+    "foley_abort": (C.c_int, [C.c_void_p]),
     "foley_dac_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "foley_dac_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int,
                                    C.c_void_p, C.c_void_p]),
@@ -299,12 +300,30 @@ class FoleyContext:
         return out
 
     def sample(self, latents: torch.Tensor, use_graph: bool = False, progress=None) -> torch.Tensor:
-        """In-place denoising of `latents` [clips, C, La] fp32."""
-        cb = PROGRESS_CB(lambda i, n, _u: progress(i, n)) if progress else PROGRESS_CB()
+        """In-place denoising of `latents` [clips, C, La] fp32.  An exception raised by `progress` (ComfyUI's interrupt:
+        comfy.utils.ProgressBar.update raises inside the reference's loop, utils.py:247) stops the loop after the current
+        iteration and propagates to the caller, like it does there."""
+        raised = []
+
+        def _cb(i, n, _u):
+            try:
+                progress(i, n)
+            except BaseException as e:          # noqa: BLE001 - re-raised below, outside the C frame
+                if not raised:
+                    raised.append(e)
+                self.lib.foley_abort(self._h)
+
+        cb = PROGRESS_CB(_cb) if progress else PROGRESS_CB()
         with torch.cuda.device(self.device):
-            _check(self.lib, self.lib.foley_sample(self._h, _ptr(latents), int(use_graph), cb, None, _stream()),
-                   "foley_sample")
+            rc = self.lib.foley_sample(self._h, _ptr(latents), int(use_graph), cb, None, _stream())
+        if raised:
+            raise raised[0]
+        _check(self.lib, rc, "foley_sample")
         return latents
+
+    def abort(self) -> None:
+        """Ask a foley_sample running on another thread to stop after its current iteration (it raises FoleyRuntimeError)."""
+        _check(self.lib, self.lib.foley_abort(self._h), "foley_abort")
 
     def dac_decode(self, latents: torch.Tensor) -> torch.Tensor:
         clips, _c, T = latents.shape

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FOLEY_ABI_VERSION 8   /* 8: foley_qkv_split_desc.attn_* (cross attention in the epilogue of its q projection); 7: FOLEY_DT_F16 as a compute dtype (foley_config.compute_dtype, op descriptors); 6: foley_rowbcast.Ls (mode 2: nearest-exact up-sampled operand); 5: reference-keyed loading (foley_weights_*, foley_load_tensor, foley_bcast_weights); 4: fp8 weight storage (dtype codes 3/4, foley_gemm_desc.ldw/.wfmt); 3: foley_profile_forward; 2: foley_gemm_desc gained partials / qkv / rstride; foley_op_ln_mod_pending, foley_dac_encode */
+#define FOLEY_ABI_VERSION 8   /* 8: foley_qkv_split_desc.attn_* (cross attention in the epilogue of its q projection), foley_abort / FOLEY_ERR_ABORTED; 7: FOLEY_DT_F16 as a compute dtype (foley_config.compute_dtype, op descriptors); 6: foley_rowbcast.Ls (mode 2: nearest-exact up-sampled operand); 5: reference-keyed loading (foley_weights_*, foley_load_tensor, foley_bcast_weights); 4: fp8 weight storage (dtype codes 3/4, foley_gemm_desc.ldw/.wfmt); 3: foley_profile_forward; 2: foley_gemm_desc gained partials / qkv / rstride; foley_op_ln_mod_pending, foley_dac_encode */
 
 enum foley_dtype {
   FOLEY_DT_F32 = 0, FOLEY_DT_BF16 = 1, FOLEY_DT_I32 = 2,
@@ -50,7 +50,8 @@ enum foley_status {
   FOLEY_ERR_INVALID = -1,   /* bad argument / shape / dtype            */
   FOLEY_ERR_MISSING = -2,   /* a required tensor was never registered  */
   FOLEY_ERR_HIP = -3,       /* HIP runtime failure                      */
-  FOLEY_ERR_STATE = -4      /* call order violated (e.g. no prepare)    */
+  FOLEY_ERR_STATE = -4,     /* call order violated (e.g. no prepare)    */
+  FOLEY_ERR_ABORTED = -5    /* foley_abort() ended the sampling loop    */
 };
 
 typedef struct foley_ctx foley_ctx;
@@ -138,6 +139,11 @@ int foley_dit_forward(foley_ctx* ctx, const float* latents, int iter, float* out
  * latents on return.  With a progress callback the stream is synchronised once per iteration.
  * use_graph != 0 replays one captured hipGraph per iteration. */
 int foley_sample(foley_ctx* ctx, float* latents, int use_graph, foley_progress_cb cb, void* user, void* stream);
+/* Cancel a running foley_sample (the ComfyUI "interrupt": comfy.utils.ProgressBar.update raises inside the reference's loop,
+ * utils.py:201,247).  Callable from the progress callback or from another thread; the loop stops after the current iteration
+ * and foley_sample returns FOLEY_ERR_ABORTED with `latents` holding the state reached.  The request is consumed by the loop it
+ * stops; one that arrives while no loop runs is dropped by the next foley_sample on entry. */
+int foley_abort(foley_ctx* ctx);
 
 /* DAC-VAE decoder: latents [clips, latent_dim, T] fp32 -> waveform [clips, 1, T*hop] fp32. */
 int foley_dac_decode(foley_ctx* ctx, const float* latents, int clips, int T, float* wave, void* stream);

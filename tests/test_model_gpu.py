@@ -539,6 +539,40 @@ def test_progress_callback_path(tiny):
     assert torch.equal(l1, l2) and torch.equal(a1, a2)
 
 
+def test_interrupt_from_the_progress_callback(tiny):
+    """ComfyUI's interrupt: comfy.utils.ProgressBar.update raises inside the sampling loop (reference utils.py:247) and the
+    exception ends the run.  Here the callback's exception crosses the C frame by way of foley_abort: the loop stops after that
+    iteration, the SAME exception reaches the caller, and the context samples normally afterwards."""
+    sd, dsd, model, dac = tiny
+    cond = synth.synth_conditioning(C.TINY, 1.0, t2a=False)
+    visual = {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]}
+    text = {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]}
+
+    class Interrupted(Exception):
+        pass
+
+    for graph in (False, True):
+        seen = []
+
+        def tick(i, n):
+            seen.append(i)
+            if i == 3:
+                raise Interrupted("stop")
+
+        with pytest.raises(Interrupted):
+            sampler.denoise_process_with_generator(visual, text, 1.0, model, dac, 4.5, 12, 2, "euler",
+                                                   generator=torch.Generator("cpu").manual_seed(7), use_graph=graph, progress=tick)
+        assert seen == [1, 2, 3]
+    # a request that arrives while no loop runs is dropped; the context is intact
+    model.ctx.abort()
+    outs = []
+    for kw in (dict(use_graph=False, progress=lambda i, n: None), dict(use_graph=True)):
+        a, _sr, lat = sampler.denoise_process_with_generator(visual, text, 1.0, model, dac, 4.5, 12, 2, "euler",
+                                                            generator=torch.Generator("cpu").manual_seed(7), return_latents=True, **kw)
+        outs.append(lat)
+    assert torch.equal(outs[0], outs[1]) and bool(torch.isfinite(outs[0]).all())
+
+
 def test_zero_depth_single_joins_side_stream(dev):
     """depth_single == 0: the side stream forked by the forward must still be joined (graph capture
     would fail otherwise, eager mode would race) - ADVICE r1."""
