@@ -163,16 +163,21 @@ __global__ __launch_bounds__(128) void ln_mod_kernel(const LnPair pr, int D, flo
 // SEL (which row set of the pair) is a template parameter: argument fields are then loaded at constant
 // kernel-argument offsets, in a few wide scalar loads at entry, instead of one dependent dword at a time
 // in front of the first global load of this latency-bound kernel (same reason as gemm_ws_body).
+#ifndef FOLEY_LN_RPB
+#define FOLEY_LN_RPB 1   // rows per workgroup of the multi-wave LayerNorm (A/B builds with -DFOLEY_LN_RPB=2 / 4 through FOLEY_HIP_LIB: 1 row
+                         // -0.3 % on the bs=1 loop against 2, 4 rows +0.5 %)
+#endif
 template <typename OutT, int MAXV, bool PEND, int WPR, int SEL, bool SLAB16>
 __device__ __forceinline__ void ln_mod_wide_body(const LnPair& pr, int D, float eps) {
   using ST = typename std::conditional<SLAB16, OutT, float>::type;   // slab element type
-  __shared__ float red[2][2][WPR];   // [row of the block][statistic][wave of the row]
+  constexpr int RPB = FOLEY_LN_RPB;
+  __shared__ float red[RPB][2][WPR];   // [row of the block][statistic][wave of the row]
   constexpr int sel = SEL;
   const LnArgs& A = pr.a[SEL];
   const int M = A.M;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int rb = wave / WPR, part = wave % WPR;               // row of the block (0/1), column part
-  const int row_u = ((int)blockIdx.x - (sel ? pr.blocks0 : 0)) * 2 + rb;
+  const int row_u = ((int)blockIdx.x - (sel ? pr.blocks0 : 0)) * RPB + rb;
   const bool live = row_u < M;
   const int row = live ? row_u : M - 1;                       // dead waves shadow the last row (no stores)
   const int c0 = part * (MAXV * 64) + lane;                   // first float4 of this lane; stride 64
@@ -278,7 +283,7 @@ __device__ __forceinline__ void ln_mod_wide_body(const LnPair& pr, int D, float 
 }
 
 template <typename OutT, int MAXV, bool PEND, int WPR, bool SLAB16 = false>
-__global__ __launch_bounds__(128 * WPR) void ln_mod_wide_kernel(const LnPair pr, int D, float eps) {
+__global__ __launch_bounds__(64 * FOLEY_LN_RPB * WPR) void ln_mod_wide_kernel(const LnPair pr, int D, float eps) {
   if ((int)blockIdx.x >= pr.blocks0) ln_mod_wide_body<OutT, MAXV, PEND, WPR, 1, SLAB16>(pr, D, eps);   // workgroup-uniform
   else ln_mod_wide_body<OutT, MAXV, PEND, WPR, 0, SLAB16>(pr, D, eps);
 }
@@ -641,20 +646,23 @@ int launch_ln_mod_pair(const LnArgs& a0, const LnArgs& a1, int D, float eps, int
   // three were better with fp32 slabs (round 2)
   static const int wide = []() { const char* e = getenv("FOLEY_LN_WIDE"); return e ? atoi(e) : 2; }();   // A/B switch (0 = one wave per row, 3)
   const int total_rows = a0.M + a1.M;
+  LnPair prw = pr;   // the multi-wave kernels take FOLEY_LN_RPB rows per workgroup
+  prw.blocks0 = (a0.M + FOLEY_LN_RPB - 1) / FOLEY_LN_RPB;
+  const dim3 gridw(prw.blocks0 + (a1.M + FOLEY_LN_RPB - 1) / FOLEY_LN_RPB);
   if (wide && total_rows <= 4096 && D % (4 * 64 * 3) == 0 && D / (4 * 64 * 3) <= 4 && wide == 3) {
 #define FOLEY_LNW(V, W)                                                                                               \
     {                                                                                                                  \
-      dim3 blk(128 * W);                                                                                               \
+      dim3 blk(64 * FOLEY_LN_RPB * W);                                                                                               \
       if (pend) {                                                                                                      \
-        if (f32o) FOLEY_LAUNCH((ln_mod_wide_kernel<float, V, true, W>), grid, blk, 0, st, pr, D, eps);                \
-        else if (f16o && s16) FOLEY_LAUNCH((ln_mod_wide_kernel<f16_t, V, true, W, true>), grid, blk, 0, st, pr, D, eps);  \
-        else if (f16o) FOLEY_LAUNCH((ln_mod_wide_kernel<f16_t, V, true, W>), grid, blk, 0, st, pr, D, eps);           \
-        else if (s16) FOLEY_LAUNCH((ln_mod_wide_kernel<bf16_t, V, true, W, true>), grid, blk, 0, st, pr, D, eps);     \
-        else FOLEY_LAUNCH((ln_mod_wide_kernel<bf16_t, V, true, W>), grid, blk, 0, st, pr, D, eps);                    \
+        if (f32o) FOLEY_LAUNCH((ln_mod_wide_kernel<float, V, true, W>), gridw, blk, 0, st, prw, D, eps);                \
+        else if (f16o && s16) FOLEY_LAUNCH((ln_mod_wide_kernel<f16_t, V, true, W, true>), gridw, blk, 0, st, prw, D, eps);  \
+        else if (f16o) FOLEY_LAUNCH((ln_mod_wide_kernel<f16_t, V, true, W>), gridw, blk, 0, st, prw, D, eps);           \
+        else if (s16) FOLEY_LAUNCH((ln_mod_wide_kernel<bf16_t, V, true, W, true>), gridw, blk, 0, st, prw, D, eps);     \
+        else FOLEY_LAUNCH((ln_mod_wide_kernel<bf16_t, V, true, W>), gridw, blk, 0, st, prw, D, eps);                    \
       } else {                                                                                                         \
-        if (f32o) FOLEY_LAUNCH((ln_mod_wide_kernel<float, V, false, W>), grid, blk, 0, st, pr, D, eps);               \
-        else if (f16o) FOLEY_LAUNCH((ln_mod_wide_kernel<f16_t, V, false, W>), grid, blk, 0, st, pr, D, eps);          \
-        else FOLEY_LAUNCH((ln_mod_wide_kernel<bf16_t, V, false, W>), grid, blk, 0, st, pr, D, eps);                   \
+        if (f32o) FOLEY_LAUNCH((ln_mod_wide_kernel<float, V, false, W>), gridw, blk, 0, st, prw, D, eps);               \
+        else if (f16o) FOLEY_LAUNCH((ln_mod_wide_kernel<f16_t, V, false, W>), gridw, blk, 0, st, prw, D, eps);          \
+        else FOLEY_LAUNCH((ln_mod_wide_kernel<bf16_t, V, false, W>), gridw, blk, 0, st, prw, D, eps);                   \
       }                                                                                                                \
     }
     const int v3 = D / (4 * 64 * 3);
