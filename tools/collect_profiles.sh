@@ -32,6 +32,8 @@ rocprofv3 --kernel-trace --stats -d /tmp/kt1 -o kt -- python $R/bench.py --steps
 python $R/tools/prof_summary.py $(find /tmp/kt1 -name "*.db" | head -1) > $OUT/${TAG}_bench_bs1_kernel_stats.md
 rocprofv3 --kernel-trace --stats -d /tmp/kt8 -o kt -- python $R/bench.py --steps 1 --warmup 0 --bs 8 --no-cpu-baseline --no-extra > /tmp/kt8.log 2>&1
 python $R/tools/prof_summary.py $(find /tmp/kt8 -name "*.db" | head -1) > $OUT/${TAG}_bench_bs8_kernel_stats.md
+rocprofv3 --kernel-trace --stats -d /tmp/kt3 -o kt -- python $R/bench.py --config c3 --with-encoders --steps 1 --warmup 0 --no-cpu-baseline --no-extra > /tmp/kt3.log 2>&1
+python $R/tools/prof_summary.py $(find /tmp/kt3 -name "*.db" | head -1) > $OUT/${TAG}_bench_c3_kernel_stats.md
 rocprofv3 --kernel-trace --stats -d /tmp/kt5 -o kt -- python $R/bench.py --config c5 --steps 1 --warmup 0 --no-cpu-baseline --no-extra > /tmp/kt5.log 2>&1
 python $R/tools/prof_summary.py $(find /tmp/kt5 -name "*.db" | head -1) > $OUT/${TAG}_bench_c5_kernel_stats.md
 
