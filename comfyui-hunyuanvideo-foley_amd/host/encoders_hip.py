@@ -182,7 +182,7 @@ def synchformer_segments_hip(sd: SD, x: Tensor, dtype: torch.dtype = torch.float
     return y.view(G, L, D)[:, 0].reshape(S, frames, D).clone()       # temp_attn_agg is Identity
 
 
-def encode_video_with_sync_hip(sd: SD, frames: Tensor, dtype: torch.dtype = torch.float16, batch_size: int = 8) -> Tensor:
+def encode_video_with_sync_hip(sd: SD, frames: Tensor, dtype: torch.dtype = torch.float16, batch_size: int = 32) -> Tensor:
     """frames [T, 3, 224, 224] fp32 (25 fps, pre-processed, on the GPU) -> [1, num_segments*8, 768] fp32
     (feature_utils.py:80-108: 16-frame segments with stride 8)."""
     from .encoders import SYNC_SEGMENT, SYNC_STRIDE
@@ -216,7 +216,7 @@ def _engine_for(sd: SD, device, dtype) -> _Engine:
 
 # ----------------------------------------------------------------------------- SigLIP2 vision tower
 def siglip_image_features_hip(sd: SD, pixels: Tensor, dtype: torch.dtype = torch.bfloat16, prefix: str = "vision_model.",
-                              heads: int = HEADS, eps: float = 1e-6, batch_size: int = 8) -> Tensor:
+                              heads: int = HEADS, eps: float = 1e-6, batch_size: int = 64) -> Tensor:
     """`SiglipModel.get_image_features` (the pooled output of transformers' SiglipVisionTransformer) on the HIP engine,
     over the model's state dict: patch embedding (conv k = stride = patch -> GEMM over unfolded patches) + learned
     position table, pre-norm encoder layers (LayerNorm -> q/k/v -> attention -> out_proj -> +x; LayerNorm -> fc1 ->
