@@ -39,4 +39,7 @@ python $R/tools/prof_summary.py $(find /tmp/kt5 -name "*.db" | head -1) > $OUT/$
 
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-include-regex "$FILTER" -d /tmp/pmc_sq -o p -- python $R/tools/profile_run.py --iters 2 --no-dac > /tmp/pmc_sq.log 2>&1
 python $R/tools/pmc_summary.py $(find /tmp/pmc_sq -name "*.db") > $OUT/${TAG}_pmc_sq.md
+# the same SQ counters at 8 clips per GPU (the bs=8 half of the metric): matrix-pipe utilisation of the large-grid kernels
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-include-regex "$FILTER" -d /tmp/pmc_sq8 -o p -- python $R/tools/profile_run.py --iters 2 --no-dac --bs 8 > /tmp/pmc_sq8.log 2>&1
+python $R/tools/pmc_summary.py $(find /tmp/pmc_sq8 -name "*.db") > $OUT/${TAG}_pmc_sq_bs8.md
 ls -la $OUT | tail -14

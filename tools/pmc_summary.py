@@ -34,15 +34,20 @@ for path in a.dbs:
             seen.add((path, disp))
             cnt[(k, cname)] += 1
 counters = sorted({c for v in agg.values() for c in v})
-print("| kernel | launches | " + " | ".join(counters) + " |")
-print("|---|---|" + "---|" * len(counters))
+# derived: matrix-pipe utilisation = MFMA-busy cycles per SIMD / cycles the kernel was resident.  SQ_VALU_MFMA_BUSY_CYCLES sums
+# the 1024 SIMDs, SQ_BUSY_CYCLES the 32 shader engines (8 XCDs x 4): busy / (32 x SQ_BUSY) - checked against the in-kernel
+# timeline (tools/gemm_timeline.py: w1/w3 at M = 500 keeps the pipe busy 22 of 38 us; the counters say 0.53 - 0.57)
+util = "SQ_VALU_MFMA_BUSY_CYCLES" in counters and "SQ_BUSY_CYCLES" in counters
+print("| kernel | launches | " + " | ".join(counters) + (" | MFMA busy |" if util else " |"))
+print("|---|---|" + "---|" * (len(counters) + (1 if util else 0)))
 tot = defaultdict(float)
+u = lambda v: (f" {v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (32.0 * v['SQ_BUSY_CYCLES']):.3f} |" if v.get("SQ_BUSY_CYCLES") else " |") if util else ""
 for k in sorted(agg, key=lambda k: -sum(agg[k].values())):
     n = max([cnt[(k, c)] for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_WAVE_CYCLES")] + [0])
-    print(f"| `{k[:70]}` | {n} | " + " | ".join(f"{agg[k].get(c, 0):.4g}" for c in counters) + " |")
+    print(f"| `{k[:70]}` | {n} | " + " | ".join(f"{agg[k].get(c, 0):.4g}" for c in counters) + " |" + u(agg[k]))
     for c in counters:
         tot[c] += agg[k].get(c, 0)
-print("| **total** | | " + " | ".join(f"{tot[c]:.4g}" for c in counters) + " |")
+print("| **total** | | " + " | ".join(f"{tot[c]:.4g}" for c in counters) + " |" + u(tot))
 
 if a.traffic_json:
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
