@@ -494,13 +494,23 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
                 traffic_src = {"file": os.path.relpath(tf_path, ROOT), "kernel_src_sha": tj["kernel_src_sha"],
                                "unit": "bytes per loop iteration (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes on these kernel sources)"}
                 break
+        mfma_busy = None
+        for mf_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma.json")), reverse=True):
+            try:
+                mj = json.load(open(mf_path))
+            except Exception:
+                continue
+            if mj.get("kernel_src_sha") == kernel_src_sha() and mj.get("workload") == f"{a.config}/bs{bs_main}/{a.precision}/{a.model}":
+                mfma_busy = {"value": mj["mfma_busy"], "kernel": mj["kernel"], "file": os.path.relpath(mf_path, ROOT),
+                             "definition": mj["definition"]}
+                break
         dom = next((k for k in kernels if k["gflop_per_launch"] > 0), None)   # largest time per iteration among the MFMA kernels
         roof = {"bound": "mfma", "peak": peak, "unit": "TFLOP/s",
                 "achieved": dom["tflops"] if dom else loop_tf, "frac": dom["frac"] if dom else loop_tf / peak,
                 "kernel": dom["name"] if dom else "whole sampler loop",
                 "launch": ("dominant kernel of the loop (largest time per iteration): algorithmic FLOPs of one launch / the dispatch's own "
                            "start->stop HIP events on the launch stream (hipExtLaunchKernelGGL), eager forward at iteration 25, after the timed region"),
-                "traffic": traffic, "traffic_source": traffic_src,
+                "traffic": traffic, "traffic_source": traffic_src, "mfma_busy": mfma_busy,
                 "loop_frac": loop_tf / peak, "loop_achieved": loop_tf, "loop_ms": loop_ms, "dac_decode_ms": dac_ms, "prepare_ms": prepare_ms,
                 "algorithmic_tflop_per_clip": f_clip / 1e12, "event_bracket_us": bracket_us, "kernels": kernels}
         out = {

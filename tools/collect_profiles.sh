@@ -20,6 +20,10 @@ python $R/tools/pmc_summary.py --traffic-json $OUT/${TAG}_pmc_traffic.json --ite
   $(find /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE -name "*.db") > $OUT/${TAG}_pmc_mem.md
 cp $OUT/${TAG}_pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json   # bench.py reports roofline.traffic from the file whose source hash matches
 
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-include-regex "$FILTER" -d /tmp/pmc_sq -o p -- python $R/tools/profile_run.py --iters 2 --no-dac > /tmp/pmc_sq.log 2>&1
+python $R/tools/pmc_summary.py --mfma-json $OUT/${TAG}_pmc_mfma.json --workload c2/bs1/bf16/xxl $(find /tmp/pmc_sq -name "*.db") > $OUT/${TAG}_pmc_sq.md
+cp $OUT/${TAG}_pmc_mfma.json $R/profiles/${TAG}_pmc_mfma.json
+
 python $R/bench.py --steps 5 --warmup 2 > $OUT/${TAG}_bench_c2.json 2> $OUT/${TAG}_bench_c2.err
 tail -c 400 $OUT/${TAG}_bench_c2.json
 python $R/bench.py --config c3 --with-encoders --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $OUT/${TAG}_bench_c3.json 2> $OUT/${TAG}_bench_c3.err
@@ -37,8 +41,6 @@ python $R/tools/prof_summary.py $(find /tmp/kt3 -name "*.db" | head -1) > $OUT/$
 rocprofv3 --kernel-trace --stats -d /tmp/kt5 -o kt -- python $R/bench.py --config c5 --steps 1 --warmup 0 --no-cpu-baseline --no-extra > /tmp/kt5.log 2>&1
 python $R/tools/prof_summary.py $(find /tmp/kt5 -name "*.db" | head -1) > $OUT/${TAG}_bench_c5_kernel_stats.md
 
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-include-regex "$FILTER" -d /tmp/pmc_sq -o p -- python $R/tools/profile_run.py --iters 2 --no-dac > /tmp/pmc_sq.log 2>&1
-python $R/tools/pmc_summary.py $(find /tmp/pmc_sq -name "*.db") > $OUT/${TAG}_pmc_sq.md
 # the same SQ counters at 8 clips per GPU (the bs=8 half of the metric): matrix-pipe utilisation of the large-grid kernels
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-include-regex "$FILTER" -d /tmp/pmc_sq8 -o p -- python $R/tools/profile_run.py --iters 2 --no-dac --bs 8 > /tmp/pmc_sq8.log 2>&1
 python $R/tools/pmc_summary.py $(find /tmp/pmc_sq8 -name "*.db") > $OUT/${TAG}_pmc_sq_bs8.md

@@ -17,6 +17,7 @@ from collections import defaultdict
 ap = argparse.ArgumentParser()
 ap.add_argument("dbs", nargs="+")
 ap.add_argument("--traffic-json")
+ap.add_argument("--mfma-json", help="SQ pass: write the matrix-pipe utilisation of the kernel with the most MFMA cycles (bench.py: roofline.mfma_busy)")
 ap.add_argument("--iters", type=int, default=2)
 ap.add_argument("--workload", default="c2/bs1/bf16/xxl")
 a = ap.parse_args()
@@ -48,6 +49,16 @@ for k in sorted(agg, key=lambda k: -sum(agg[k].values())):
     for c in counters:
         tot[c] += agg[k].get(c, 0)
 print("| **total** | | " + " | ".join(f"{tot[c]:.4g}" for c in counters) + " |" + u(tot))
+
+if a.mfma_json and util:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    busy = {k: v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (32.0 * v["SQ_BUSY_CYCLES"]) for k, v in agg.items() if v.get("SQ_BUSY_CYCLES")}
+    top = max(agg, key=lambda k: agg[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0))
+    json.dump({"kernel_src_sha": bench.kernel_src_sha(), "workload": a.workload, "kernel": top, "mfma_busy": busy[top],
+               "definition": "SQ_VALU_MFMA_BUSY_CYCLES / (32 x SQ_BUSY_CYCLES): matrix-pipe busy cycles per SIMD over the cycles the "
+                             "kernel was resident, of the kernel with the most MFMA cycles in the loop (rocprofv3 --pmc pass)",
+               "all": {k: round(v, 4) for k, v in busy.items() if v > 0}}, open(a.mfma_json, "w"))
 
 if a.traffic_json:
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
