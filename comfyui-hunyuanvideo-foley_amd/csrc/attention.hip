@@ -733,6 +733,155 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16, LONG sequences on small grids (the 30 s clip: S = 1500 .. 1740, 2 x 12 heads -> 336 workgroups of 128 queries = 1.3
+// waves per SIMD): with so few waves the kernel's time is ONE wave's dependent chain per key tile - QK^T -> two lane-half
+// exchanges -> exponentials -> PV -> staging write -> barrier, 1 880 cycles for 512 cycles of MFMA in the kernel above - times
+// the number of tiles.  This form walks the keys 64 at a time: the chain's fixed latencies (MFMA drain, the cross-half
+// exchanges, the rescale test, the staging write and the barrier) are paid once per 64 keys, the two 32-key score tiles
+// are independent MFMA chains, and the lane-half exchanges are v_permlane32_swap (one VALU instruction each; __shfl_xor
+// compiles to ds_bpermute, a round trip through the LDS crossbar).  Same operand layout, staging (register-staged double
+// buffer, padded pitches) and output mapping as attn_bf16_wide_kernel; 70 KiB of LDS, two workgroups per CU.
+__device__ __forceinline__ float xhalf_max(float v) {   // max over the lane pair (l, l ^ 32)
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+template <typename T, typename OutT>
+__global__ __launch_bounds__(256, 2) void attn_bf16_long_kernel(const AttnArgs a) {   // two waves per SIMD (<= 256 registers): left alone the compiler takes 194 + 96 AGPRs = one workgroup per CU
+  constexpr int HD = 128, KT = 64;
+  constexpr int KP = 2 * HD + 16, VP = 2 * KT + 16;      // LDS row pitches in bytes (K rows: 272, V^T rows: 144)
+  constexpr int STG = KT * KP + HD * VP;                 // one stage: K tile + V^T tile = 35 840 B
+  constexpr int NS = HD / 16, ND = HD / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int j = lane & 31, kh = lane >> 5;
+  int qt, h, b;
+  attn_block_coords(a, 128, qt, h, b);
+  const int q0 = qt * 128 + w * 32;
+  const int bk = b / a.kv_bdiv;
+  const T* __restrict__ Q = (const T*)a.q + ((long)(b * a.H + h) * a.Sq) * HD;
+  const T* __restrict__ K = (const T*)a.k + ((long)(bk * a.H + h) * a.Skv) * HD;
+  const T* __restrict__ VT = (const T*)a.v + ((long)(bk * a.H + h) * HD) * a.vt_pitch;
+  const float scale2 = 0.08838834764831845f * 1.4426950408889634f;   // log2(e) / sqrt(128)
+
+  bf16x8 qf[NS];
+  {
+    const T* p = Q + (long)min(q0 + j, a.Sq - 1) * HD + 8 * kh;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) qf[s] = *(const bf16x8*)(p + 16 * s);
+  }
+  f32x16 o[ND];
+#pragma unroll
+  for (int d = 0; d < ND; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  // staging: K tile 64 rows x 16 chunks, V^T tile 128 rows x 8 chunks = 1024 + 1024 pieces of 16 B, 4 + 4 per thread
+  const int k_row0 = tid >> 4, k_col = tid & 15;       // 16 rows per pass
+  const int v_row0 = tid >> 3, v_col = tid & 7;        // 32 rows per pass
+  const int vmax = a.vt_pitch - 8;                     // last 16-byte chunk of a V^T row (the pitch covers Skv rounded up to 32, not to 64)
+  u32x4 rk[4], rv[4];
+  auto gload = [&](int t) {
+    const int kt = t * KT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      rk[i] = *(const u32x4*)(K + (long)min(kt + k_row0 + i * 16, a.Skv - 1) * HD + k_col * 8);
+      rv[i] = *(const u32x4*)(VT + (long)(v_row0 + i * 32) * a.vt_pitch + min(kt + v_col * 8, vmax));   // clamped chunks carry masked (p = 0) keys
+    }
+  };
+  auto lstore = [&](int stage) {
+    unsigned char* base = lds + stage * STG;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *(u32x4*)(base + (k_row0 + i * 16) * KP + k_col * 16) = rk[i];
+      *(u32x4*)(base + KT * KP + (v_row0 + i * 32) * VP + v_col * 16) = rv[i];
+    }
+  };
+  const int nt = (a.Skv + KT - 1) / KT;
+  const int pi = 16 * ((j >> 2) & 1) + (j & 3) + 4 * (j >> 3);  // A-row j of a 32-key score tile carries key pi
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int kt = t * KT;
+    if (t + 1 < nt) gload(t + 1);                 // next tile's global loads fly during this tile's math
+    const unsigned char* Ks = lds + (t & 1) * STG;
+    const unsigned char* Vs = Ks + KT * KP;
+    f32x16 s0, s1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s0[e] = s1[e] = 0.f;
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {             // two independent score tiles: keys kt .. kt+31 and kt+32 .. kt+63
+      s0 = mfma16<T>(*(const bf16x8*)(Ks + pi * KP + (16 * st + 8 * kh) * 2), qf[st], s0);
+      s1 = mfma16<T>(*(const bf16x8*)(Ks + (32 + pi) * KP + (16 * st + 8 * kh) * 2), qf[st], s1);
+    }
+    // s0[e] / s1[e] = raw score(key kt + {0, 32} + 16*kh + e, query q0 + j); log2 domain through scale2 (> 0: commutes with max)
+    if (kt + KT > a.Skv) {                        // only a tile that sticks out of the sequence masks (wave-uniform test)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        s0[e] = (kt + 16 * kh + e < a.Skv) ? s0[e] : -INFINITY;
+        s1[e] = (kt + 32 + 16 * kh + e < a.Skv) ? s1[e] : -INFINITY;
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mx = fmaxf(mx, fmaxf(s0[e], s1[e]));
+    mx = xhalf_max(mx);
+    const float m_new = fmaxf(m_run, mx * scale2);
+    float ps = 0.f;
+    bf16x8 pb[4];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[e], scale2, -m_new));
+      const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[e], scale2, -m_new));
+      ps += p0 + p1;
+      pb[e >> 3][e & 7] = to_carrier<T>(p0);
+      pb[2 + (e >> 3)][e & 7] = to_carrier<T>(p1);
+    }
+    ps = xhalf_sum(ps);
+    if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {   // the 64 accumulator rescales only when some query's maximum moved
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // exp2(-inf) = 0 on the first tile
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+    }
+    l_run += ps;
+    m_run = m_new;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)                   // k-step u: keys kt + 32*(u>>1) + 16*kh + 8*(u&1) + 0..7
+#pragma unroll
+      for (int d = 0; d < ND; ++d)
+        o[d] = mfma16<T>(*(const bf16x8*)(Vs + (d * 32 + j) * VP + (32 * (u >> 1) + 16 * kh + 8 * (u & 1)) * 2), pb[u], o[d]);
+    if (t + 1 < nt) {
+      lstore((t + 1) & 1);        // stage (t+1)&1 was last read in iteration t-1: every wave passed the barrier below since
+      __syncthreads();
+    }
+  }
+
+  const int tok = q0 + j;
+  if (tok >= a.Sq) return;
+  const float inv = 1.0f / l_run;
+  OutT* dst;
+  if (tok < a.split) dst = (OutT*)a.outA + ((long)b * a.split + tok) * (a.H * HD);
+  else dst = (OutT*)a.outB + ((long)b * (a.Sq - a.split) + (tok - a.split)) * (a.H * HD);
+  dst += h * HD;
+#pragma unroll
+  for (int d = 0; d < ND; ++d)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const f32x4 v = {o[d][g4 * 4 + 0] * inv, o[d][g4 * 4 + 1] * inv, o[d][g4 * 4 + 2] * inv, o[d][g4 * 4 + 3] * inv};
+      Pack4Out<OutT>::store(dst + d * 32 + 8 * g4 + 4 * kh, v);
+    }
+}
+
 }  // namespace
 
 static long long* g_attn_dbg = nullptr;
@@ -758,6 +907,10 @@ int launch_attention(const AttnArgs& a_in, int out_dtype, hipStream_t st) {
     // (the conditioning encoders) exists in the wide form only
     const dim3 gw(((a.Sq + 127) / 128) * a.H * a.Bq);
     const bool wide = (long)gw.x >= 256 || hd == 64, h16 = a.in_dtype == FOLEY_F16, o32 = out_dtype == FOLEY_F32;
+    // long key sequences on grids of at most ~2 waves per SIMD: 64 keys per iteration of each wave's dependent chain (attn_bf16_long_kernel;
+    // FOLEY_ATTN_LONG=0 keeps the 32-key form)
+    static const bool long_on = []() { const char* e = getenv("FOLEY_ATTN_LONG"); return !(e && e[0] == '0'); }();
+    const bool longk = long_on && wide && hd == 128 && a.Skv >= 512 && (long)gw.x * 4 <= 2048;
     // small grids whose operands fit the LDS: the DMA-staged form (FOLEY_ATTN_LDS=0 keeps the register-loaded kernel)
     static const bool lds_on = []() { const char* e = getenv("FOLEY_ATTN_LDS"); return !(e && e[0] == '0'); }();
     const int nt = (a.Skv + 31) >> 5;
@@ -773,6 +926,12 @@ int launch_attention(const AttnArgs& a_in, int out_dtype, hipStream_t st) {
         hipError_t e_ = foley_raise_lds((const void*)attn_lds_kernel<T, O>, 160 * 1024, raised);     \
         if (e_ != hipSuccess) return foley_set_err(hipGetErrorString(e_), __FILE__, __LINE__);       \
         FOLEY_LAUNCH((attn_lds_kernel<T, O>), grid1, dim3(256), lds16, st, a, merge_off);            \
+      } else                                                                                         \
+      if (longk) {                                                                                   \
+        static std::atomic<unsigned long long> raised{0};                                            \
+        hipError_t e_ = foley_raise_lds((const void*)attn_bf16_long_kernel<T, O>, 2 * 35840, raised); \
+        if (e_ != hipSuccess) return foley_set_err(hipGetErrorString(e_), __FILE__, __LINE__);       \
+        FOLEY_LAUNCH((attn_bf16_long_kernel<T, O>), gw, dim3(256), 2 * 35840, st, a);                \
       } else                                                                                         \
       if (wide && hd == 64) FOLEY_LAUNCH((attn_bf16_wide_kernel<T, O, 64>), gw, dim3(256), 0, st, a);  \
       else if (wide) FOLEY_LAUNCH((attn_bf16_wide_kernel<T, O, 128>), gw, dim3(256), 0, st, a);        \

@@ -192,7 +192,7 @@ template <typename T> struct EpiOutT<T, EPI_DAC> { using type = float; };
 // done) that hold no accumulators but take their share of the LDS -> global passes.
 template <typename T, int EPI, int BM, int BN, int WM, int WN, int XW = 0>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&acc)[BM / WM / 32][BN / WN / 32],
-                                                  unsigned char* lds_raw, int m0, int n0, int ks) {
+                                                  unsigned char* lds_raw, int m0, int n0, int ks, int vtid = -1) {
   constexpr int NT = (WM * WN + XW) * 64, TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
   using OutT = typename EpiOutT<T, EPI>::type;
   constexpr int CP = VecStore<OutT>::CP;                    // output elements per lane and pass
@@ -200,7 +200,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
   constexpr int TPR = OBN / CP, RP = NT / TPR, PASSES = BM / RP;
   static_assert(NT % TPR == 0 && BM % RP == 0 && PASSES >= 1, "tile / epilogue mismatch");
   float* tile = (float*)lds_raw;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // vtid: the thread's id inside a VIRTUAL tile (gemm_wide_impl.h runs a 256x256 tile's epilogue as two 256x128 passes whose
+  // writer waves are renumbered 0 .. WM*WN-1 and whose other waves help as XW waves); -1: the hardware thread id
+  const int tid = vtid >= 0 ? vtid : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN, fi = lane & 31, kh = lane >> 5;
   const bool estamp = g.dbg && (g.dbg_mode & 0xff) == 4 && tid == 0;   // tools/gemm_timeline.py --epilogue
   if (estamp) g.dbg[(long)blockIdx.x * 4 + 0] = wall_clock64();
@@ -417,7 +419,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
 // attention launch and the boundary in front of it are gone (QkvSplitArgs::attn_*).
 template <typename T, int BM, int BN, int WM, int WN, int XW = 0, bool EARLY = true, bool ATTN = false>
 __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&acc)[BM / WM / 32][BN / WN / 32],
-                                                  unsigned char* lds_raw, int m0, int n0) {
+                                                  unsigned char* lds_raw, int m0, int n0, int vtid = -1) {
   static_assert(BN == 128, "one head per tile");
   constexpr int NT = (WM * WN + XW) * 64, TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
   constexpr int CP = VecStore<T>::CP, TPR = 128 / CP, RP = NT / TPR, PASSES = BM / RP;
@@ -432,7 +434,7 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&ac
   static_assert(TPR == 16 || TPR == 32, "head-split epilogue: 16 or 32 lanes per row");
   const QkvSplitArgs& q = g.qs;
   float* tile = (float*)lds_raw;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = vtid >= 0 ? vtid : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;   // vtid: see gemm_epilogue_lds
   const int wm = wave / WN, wn = wave % WN, fi = lane & 31, kh = lane >> 5;
   const bool estamp = g.dbg && (g.dbg_mode & 0xff) == 4 && tid == 0;   // tools/gemm_timeline.py --epilogue
   if (estamp) g.dbg[(long)blockIdx.x * 4 + 0] = wall_clock64();

@@ -624,7 +624,43 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
       tile = 22;
   }
   if (tile_auto && ws_conv3_ok && (tile == 19 || tile == 29 || tile == 9)) tile = 23;   // large grids: the 256x128 tap-fused form (w1/w3 at M = 4000: 329 -> 285 us)
-  if (g.wfmt && tile != 15 && tile != 19 && tile != 21 && tile != 23) {   // fp8 weights exist only in the wave-specialised mainloops
+  // 256x256 tiles on the BK = 32 mainloop (gemm_wide_impl.h, tiles 31 / 32) for the large grids, wherever their workgroups
+  // fill the last round of 256 CUs about as well as the 256x128 tiles' do (tools/wide_bench.py at M = 4000: w1/w3 298 -> 249 us,
+  // w2 158 -> 134, linear2 66 -> 59, fc2 92 -> 79; fc1 - 1.5 rounds of 256x256 against exactly 3 of 256x128 - stays).
+  // FOLEY_WIDE=0 keeps the 256x128 tiles.
+  // Mid-size grids (M = 3000: the 30 s clip) whose N = 1536 gated-residual GEMMs landed on 128x128 tiles with two K ranges
+  // (288 tiles, 1.1 rounds) take the same route: 72 tiles of 256x256 x three K ranges (w2 149 -> 97 us, fc2 99 -> 59 us).
+  const bool mid_split = (tile == 21 || tile == 15 || tile == 25) && g.M >= 2048 && epi == EPI_GATE_RES && deferred;
+  if (tile_auto && sizeof(T) == 2 && !g1 && (tile == 23 || tile == 19 || tile == 29 || mid_split)) {
+    static const bool wide_on = []() { const char* e = getenv("FOLEY_WIDE"); return !(e && e[0] == '0'); }();
+    const bool conv = tile == 23 || tile == 21;
+    const bool epi_ok = epi == EPI_STORE_F32 || epi == EPI_GATE_RES || epi == EPI_SILUGATE_T || (!conv && epi == EPI_GELU_T);
+    const bool addr_ok = conv || (g.taps == 1 && g.segV >= g.M && g.rstride <= 1 && g.tap0 == 0);
+    if (wide_on && epi_ok && addr_ok && g.tapC % 32 == 0) {
+      const long mt = (g.M + 255) / 256, tw = mt * ((g.N + 255) / 256), tb = mt * ((g.N + 127) / 128);
+      const int nk64 = (conv ? g.tapC : g.K) / 64;
+      auto ksp = [&](long blocks) -> long {   // the K split the deferred rule below will choose for `blocks` tiles
+        if (epi != EPI_GATE_RES) return 1;
+        if (g.ksplit > 0) return g.ksplit;
+        if (!deferred) return 1;
+        long w = 256 / blocks;
+        if (w > nk64 / 4) w = nk64 / 4;
+        if (w > g.partial_cap) w = g.partial_cap;
+        return w < 1 ? 1 : (w > 16 ? 16 : w);
+      };
+      auto eff = [](long wg) { return (double)wg / (double)(((wg + 255) / 256) * 256); };
+      const long kw = ksp(tw);
+      const double ew = eff(tw * kw), eb = eff(tb * ksp(tb));
+      GemmArgs gt = g;
+      gt.ksplit = (int)kw;
+      // a K split on top of it pays only where the 256x128 tiles leave the chip half empty (M = 3000, N = 1536: 144 workgroups
+      // - w2 143 -> 97 us, fc2 99 -> 59 us with three K ranges); at M = 4000 the two slabs cost the next LayerNorm 12 us per launch
+      // (pending form 21.6 vs 9.6 us) for 7 us won in the GEMM
+      const bool split_ok = kw == 1 || eb < 0.6 || mid_split;
+      if (ew >= 0.74 && ew >= eb - 0.13 && split_ok && gemm_vec_out_ok<T>(gt, epi)) tile = conv ? 31 : 32;
+    }
+  }
+  if (g.wfmt && tile != 15 && tile != 19 && tile != 21 && tile != 23 && tile != 31 && tile != 32) {   // fp8 weights exist only in the wave-specialised mainloops
     if (!tile_auto) return foley_set_err("GEMM: fp8 weights need tile 15, 19 or 21", __FILE__, __LINE__);
     tile = 15;
   }
@@ -682,14 +718,14 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     g.ksplit = 1;   // fp32 (parity) mode keeps a fixed summation order
   } else if (g.ksplit == 0) {
     // fill ~3 workgroups per CU, keep >= 12 K-slices per range
-    static const int bm[30] = {0, 128, 64, 64, 128, 128, 64, 128, 64, 256, 0, 128, 0, 64, 0, 128, 0, 0, 0, 256, 0, 128, 256, 256, 0, 128, 0, 0, 0, 256};
-    static const int bn[30] = {0, 128, 128, 64, 64, 128, 64, 128, 128, 128, 0, 128, 0, 64, 0, 128, 0, 0, 0, 128, 0, 128, 64, 128, 0, 128, 0, 0, 0, 128};
-    if (tile < 0 || tile >= 30 || bm[tile] == 0) return foley_set_err("GEMM: unknown tile", __FILE__, __LINE__);
+    static const int bm[33] = {0, 128, 64, 64, 128, 128, 64, 128, 64, 256, 0, 128, 0, 64, 0, 128, 0, 0, 0, 256, 0, 128, 256, 256, 0, 128, 0, 0, 0, 256, 0, 256, 256};
+    static const int bn[33] = {0, 128, 128, 64, 64, 128, 64, 128, 128, 128, 0, 128, 0, 64, 0, 128, 0, 0, 0, 128, 0, 128, 64, 128, 0, 128, 0, 0, 0, 128, 0, 256, 256};
+    if (tile < 0 || tile >= 33 || bm[tile] == 0) return foley_set_err("GEMM: unknown tile", __FILE__, __LINE__);
     const long blocks = (long)((g.M + bm[tile] - 1) / bm[tile]) * ((g.N + bn[tile] - 1) / bn[tile]);
-    const int nk = (tile == 11 || tile == 13 || tile == 21 || tile == 22 || tile == 23) ? 3 * (g.tapC / BK) / 3 : g.K / BK;   // conv3 splits over channel chunks
+    const int nk = (tile == 11 || tile == 13 || tile == 21 || tile == 22 || tile == 23 || tile == 31) ? 3 * (g.tapC / BK) / 3 : g.K / BK;   // conv3 splits over channel chunks
     // small tiles want ~3 workgroups per CU; the large, efficient tiles only split when they
     // cannot even cover the chip once (the fp32 atomics are not free)
-    const long target = (tile == 1 || tile == 5 || tile == 7 || tile == 9 || tile == 11 || tile == 15 || tile == 19 || tile == 21 || tile == 22 || tile == 23 || tile == 25 || tile == 29) ? 192 : (tile == 13 ? 512 : 768);
+    const long target = (tile == 1 || tile == 5 || tile == 7 || tile == 9 || tile == 11 || tile == 15 || tile == 19 || tile == 21 || tile == 22 || tile == 23 || tile == 25 || tile == 29 || tile >= 31) ? 192 : (tile == 13 ? 512 : 768);
     long want = (target + blocks - 1) / blocks;
     if (want > nk / 12) want = nk / 12;
     if (deferred) {   // one resident round of workgroups: as many K ranges as fit on 256 CUs (>= 4 slices each)
@@ -734,8 +770,14 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
   // single-block modulation GEMM once it was gone).  Problems that need the scalar epilogue take the twins.
   if ((tile == 25 || tile == 29) && epi != EPI_QKV_SPLIT && !(g.vec_out && (!g1 || g1s.vec_out))) tile = tile == 25 ? 15 : 19;
   if ((tile == 27 || tile == 26 || tile == 28) && (epi != EPI_QKV_SPLIT || g.wfmt)) return foley_set_err("GEMM: tile 27 (64x128) serves the fused head split with bf16 weights only", __FILE__, __LINE__);
-  if ((g.ldw != g.K || (g1 && g1s.ldw != g1s.K)) && !(tile == 15 || tile == 19 || tile == 21 || tile == 22 || tile == 23 || tile == 25 || tile == 26 || tile == 27 || tile == 28 || tile == 29))
+  if ((g.ldw != g.K || (g1 && g1s.ldw != g1s.K)) && tile != 31 && tile != 32 && !(tile == 15 || tile == 19 || tile == 21 || tile == 22 || tile == 23 || tile == 25 || tile == 26 || tile == 27 || tile == 28 || tile == 29))
     return foley_set_err("GEMM: padded weight rows (ldw != K) need a wave-specialised tile", __FILE__, __LINE__);
+  if (tile == 31 || tile == 32) {   // 256x256 tiles on the BK = 32 mainloop (gemm_wide_impl.h)
+    if (g1) return foley_set_err("GEMM: the 256x256 tiles have no two-problem form", __FILE__, __LINE__);
+    if constexpr (__is_same(T, bf16_t)) return launch_gemm_wide_bf16(g, epi, tile, st);
+    else if constexpr (__is_same(T, f16_t)) return launch_gemm_wide_f16(g, epi, tile, st);
+    else return foley_set_err("GEMM: the 256x256 tiles serve 16-bit operands", __FILE__, __LINE__);
+  }
   if (tile == 11 || tile == 13) {
     if (g1) return foley_set_err("conv3 kernel has no two-problem form", __FILE__, __LINE__);
     return launch_gemm_conv3(g, DtCode<T>::v, epi, tile == 11 ? 1 : 3, st);

@@ -36,6 +36,14 @@ __device__ __forceinline__ void buf_lds16(const void* base, unsigned bytes, unsi
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
 
+// s_barrier the compiler may not move MFMAs across: they touch no memory, so nothing else orders them against the builtin (left
+// alone hipcc sank a whole MFMA block below the second barrier of the strict-alternation loops, see gemm_wide_impl.h)
+__device__ __forceinline__ void hard_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // L2 prefetch: one dword per lane into a pinned scratch register (see the consumer loop); out-of-range
 // lanes touch nothing.
 __device__ __forceinline__ void buf_prefetch4(const void* base, unsigned bytes, int voff, int soff, int& sink) {
@@ -92,6 +100,10 @@ __device__ __forceinline__ void gemm_ws_body(const GemmPair& pr) {
   constexpr int BROW = 64 * WSZ;                     // bytes of one W row per K-slice in LDS
   constexpr int AI = BM / 8 / LW, BI = BN * BROW / 1024 / LW;  // 1 KiB pieces per loader wave and K-slice
   constexpr int STAGE = BM * 128 + BN * BROW;
+  // Large grids (256-row tiles, eight consumer waves): a SECOND barrier per slice makes the two consumer waves of a SIMD
+  // alternate strictly between the matrix pipe and the LDS - never matrix || matrix (w2 at M = 4000: 160 -> 152 us; the
+  // M = 500 tiles lose 7 - 13 % to it: their loops wait for memory, not for the pipe).  See gemm_wide_impl.h.
+  constexpr bool TWOB = BM == 256 && WM * WN == 8;
   static_assert(BM % (8 * LW) == 0 && (BN * BROW) % (1024 * LW) == 0 && BI >= 1, "bad tile");
   static_assert((NS - 1) * (AI + BI) < 64, "vmcnt is a 6-bit counter");
   static_assert(EPI != EPI_SILUGATE_T || (FN % 2 == 0), "gated epilogue needs fragment pairs");
@@ -211,6 +223,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmPair& pr) {
         if (kt > 0) { t_mem += tb - ta; t_bar += tc - tb; }   // the ring fill (kt == 0) is the prologue, stamped separately
       }
       if (kt + NS - 1 < nk) issue(stage == 0 ? NS - 1 : stage - 1);
+      if constexpr (TWOB) __builtin_amdgcn_s_barrier();   // B: the consumer halves swap pipes (below)
       stage = stage + 1 == NS ? 0 : stage + 1;
     }
     if (acct && lane == 0) {
@@ -394,15 +407,20 @@ __device__ __forceinline__ void gemm_ws_body(const GemmPair& pr) {
   int stage = 0;
   for (int kt = 0; kt < nk; ++kt) {
     if (late) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if constexpr (TWOB) hard_barrier();
+    else __builtin_amdgcn_s_barrier();
     if (kt == 0) tl_stamp(g, 1);
     prefetch();
     if (late && kt > 0) {
       cvtb();
       mma();
     }
+    if constexpr (TWOB) {   // strict alternation: the late half is done multiplying - barrier B, then it reads
+      if (late) hard_barrier();
+    }
     const unsigned char* As = lds + stage * STAGE;
     const unsigned char* Bs = As + BM * 128;
+    auto reads = [&]() {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -415,7 +433,13 @@ __device__ __forceinline__ void gemm_ws_body(const GemmPair& pr) {
         for (int j = 0; j < FN; ++j) rawb[s >> 1][j] = *(const u32x4*)(Bs + b_row[j] + (((s + kh) ^ b_sw[j]) << 4));
       }
     }
+    };
+    reads();
     if (!late) {
+      if constexpr (TWOB) {   // ... the early half has read its fragments - barrier B, then it multiplies
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        hard_barrier();
+      }
       cvtb();
       mma();
     }
@@ -481,6 +505,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_conv3_kernel(cons
   constexpr int BI = BN * BROW / 1024 / LW;             // weight pieces per loader wave and tap slice
   constexpr int BSL = BN * BROW;                        // bytes per weight slice
   constexpr int ZOFF = NAB * ABUF + NSB * BSL;          // 128 zero bytes
+  constexpr bool TWOB = BM == 256 && BN == 128;         // large-grid form: second barrier per slice (see gemm_ws_body; w1/w3 at M = 4000: 271 -> 262 us)
   static_assert(NW == 8 && (BN * BROW) % (1024 * LW) == 0 && BI >= 1, "bad tile");
   static_assert(3 * NAB >= NSB + 2, "an activation buffer would be refilled while its chunk is still being consumed");
   static_assert(conv3_inflight(NSB, 0, AI, BI) < 64 && conv3_inflight(NSB, 1, AI, BI) < 64 && conv3_inflight(NSB, 2, AI, BI) < 64,
@@ -572,6 +597,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_conv3_kernel(cons
         }
         __builtin_amdgcn_s_barrier();
         if (kt + NSB - 1 < nk) issue(kt + NSB - 1);
+        if constexpr (TWOB) __builtin_amdgcn_s_barrier();   // B: the consumer halves swap pipes (below)
       }
     }
     return;
@@ -636,13 +662,18 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_conv3_kernel(cons
     for (int tap = 0; tap < 3; ++tap) {
       const int kt = kt0 + tap;
       if (late) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      if constexpr (TWOB) hard_barrier();
+      else __builtin_amdgcn_s_barrier();
       if (kt == 0) tl_stamp(g, 1);
       if (late && kt > 0) {
         cvtb();
         mma();
       }
+      if constexpr (TWOB) {   // strict alternation: the late half is done multiplying - barrier B, then it reads
+        if (late) hard_barrier();
+      }
       const unsigned char* Bs = lds + NAB * ABUF + (kt % NSB) * BSL;
+      auto reads = [&]() {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -658,7 +689,13 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_conv3_kernel(cons
           for (int j = 0; j < FN; ++j) rawb[s >> 1][j] = *(const u32x4*)(Bs + b_row[j] + (((s + kh) ^ b_sw[j]) << 4));
         }
       }
+      };
+      reads();
       if (!late) {
+        if constexpr (TWOB) {   // ... the early half has read its fragments - barrier B, then it multiplies
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          hard_barrier();
+        }
         cvtb();
         mma();
       }

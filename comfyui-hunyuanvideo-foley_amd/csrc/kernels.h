@@ -111,6 +111,10 @@ int launch_gemm_conv3(const GemmArgs& g, int dtype, int epi, int tile, hipStream
 // wave-specialised mainloop (gemm_ws_impl.h; one entry per 16-bit operand type): tile 15 = 128x128, 19 = 256x128; g / g1 resolved by launch_gemm
 int launch_gemm_ws_bf16(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hipStream_t st);
 int launch_gemm_ws_f16(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hipStream_t st);
+// 256x256 tiles on the BK = 32 mainloop (gemm_wide_impl.h): tile 31 = tap-fused conv k=3, 32 = plain linear layer (eight waves of
+// 128x64); single problem, vector epilogue, any weight storage
+int launch_gemm_wide_bf16(const GemmArgs& g, int epi, int tile, hipStream_t st);
+int launch_gemm_wide_f16(const GemmArgs& g, int epi, int tile, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // Attention: O = softmax(Q K^T / sqrt(hd)) V, no mask, hd = 128 (or 64: AttnArgs::head_dim).  Q [Bq, H, Sq, hd], K/V [Bkv, H, Skv, hd]

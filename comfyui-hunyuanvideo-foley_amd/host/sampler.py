@@ -236,6 +236,7 @@ def replicate(model: FoleyModel, dac: Optional[FoleyDAC], devices: Sequence) -> 
                                   buffer=model.arena.buffer.to(d, copy=True))
             m = FoleyModel.from_arena(model.cfg, arena, model.dtype, d, dac_cfg=model.dac_cfg,
                                       quantization=model.quantization)
+            m._text_len_fixed = model._text_len_fixed      # the sticky text bucket is per MODEL in the reference (utils.py:166-188)
             dd = None
             if dac is not None:
                 da = packers.Arena(dac.arena.buffer.numel(), dac.arena.table, d, buffer=dac.arena.buffer.to(d, copy=True))
@@ -265,6 +266,15 @@ def denoise_process_multi(visual_feats, text_feats, audio_len_in_s, replicas: Se
     shards = [shard_range(batch_size, r, len(replicas)) for r in range(len(replicas))]
     results: List = [None] * len(replicas)
     errors: List = []
+    # The conditioning tensors may still be in flight on the CALLER's streams (the CLAP / SigLIP2 / Synchformer kernels of
+    # the node run on the default stream of their device): every worker runs on a fresh non-blocking stream, which orders
+    # nothing against them by itself - one event per producing device, recorded here on the calling thread, and waited for
+    # by each worker's stream before it touches a feature.
+    ready = []
+    for dv in {t.device for t in list(visual_feats.values()) + list(text_feats.values()) if torch.is_tensor(t) and t.is_cuda}:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dv))
+        ready.append(ev)
 
     def work(r):
         lo, hi = shards[r]
@@ -272,7 +282,10 @@ def denoise_process_multi(visual_feats, text_feats, audio_len_in_s, replicas: Se
             return
         model, dac = replicas[r]
         try:
-            with torch.cuda.device(model.device), torch.cuda.stream(torch.cuda.Stream(model.device)):
+            stream = torch.cuda.Stream(model.device)
+            with torch.cuda.device(model.device), torch.cuda.stream(stream):
+                for ev in ready:
+                    stream.wait_event(ev)
                 results[r] = denoise_process_with_generator(
                     visual_feats, text_feats, audio_len_in_s, model, dac, guidance_scale, num_inference_steps, hi - lo,
                     sampler, use_graph=use_graph, noise=noise[lo:hi], return_latents=True,
@@ -280,6 +293,12 @@ def denoise_process_multi(visual_feats, text_feats, audio_len_in_s, replicas: Se
                 torch.cuda.current_stream().synchronize()
         except Exception as e:          # surfaced on the calling thread
             errors.append(e)
+            for m, _ in replicas:       # an interrupt (or any failure) on one replica stops the others at their next iteration
+                if m is not model:
+                    try:
+                        m.ctx.abort()
+                    except Exception:   # noqa: BLE001 - best effort; the first error is the one reported
+                        pass
 
     threads = [threading.Thread(target=work, args=(r,), name=f"foley-dp-{r}") for r in range(len(replicas))]
     for t in threads:

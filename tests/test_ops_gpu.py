@@ -48,9 +48,12 @@ def _q(t, dtype):   # round a CPU reference operand through the compute dtype
     (257, 129, 128, 19),
     # four consumer waves (64x64 / 128x64 wave tiles) + loader waves helping in the epilogue
     (500, 1536, 1536, 25), (500, 1536, 1536, 29), (37, 200, 64, 25), (700, 640, 4608, 29), (1000, 136, 320, 25), (257, 129, 128, 29),
+    # 256x256 tiles on the BK = 32 mainloop (gemm_wide_impl.h, tile 32): ragged M / N edges, half-empty column passes (N = 136),
+    # K = one 64-wide slice pair .. many
+    (500, 1536, 1536, 32), (37, 200, 64, 32), (700, 640, 4608, 32), (1000, 136, 320, 32), (257, 136, 128, 32), (4000, 512, 192, 32),
 ])
 def test_gemm_linear(dev, dtype, M, N, K, tile):
-    if tile in (15, 19, 25, 29) and dtype == torch.float32:
+    if tile in (15, 19, 25, 29, 32) and dtype == torch.float32:
         pytest.skip("wave-specialised tiles are bf16 only")
     A, W, b = _rand((M, K), 1), _rand((N, K), 2, 1 / math.sqrt(K)), _rand((N,), 3, 0.1)
     ref = F.linear(_q(A, dtype), _q(W, dtype), b)
@@ -92,11 +95,13 @@ def test_gemm_transpose_detecting(dev, dtype, tile):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("tile", [0, 15, 19, 25, 29])
+@pytest.mark.parametrize("tile", [0, 15, 19, 25, 29, 32])
 @pytest.mark.parametrize("epi", ["store_t", "silu", "gelu", "silugate", "gate_res_vec", "gate_res_tok", "addend"])
 def test_gemm_epilogues(dev, dtype, epi, tile):
     if tile and dtype == torch.float32:
         pytest.skip("wave-specialised tiles are bf16 only")
+    if tile == 32 and epi in ("store_t", "silu"):
+        pytest.skip("the 256x256 tiles carry the epilogues of the large-grid GEMMs only")
     M, N, K = 300, 512, 256
     clips, L = 3, 50                     # rows ordered [cfg=2][clip=3][l=50]
     A, W, b = _rand((M, K), 4), _rand((N, K), 5, 1 / math.sqrt(K)), _rand((N,), 6, 0.1)
@@ -136,7 +141,7 @@ def test_gemm_epilogues(dev, dtype, epi, tile):
 
 
 @pytest.mark.parametrize("fmt", [torch.float8_e4m3fn, torch.float8_e5m2])
-@pytest.mark.parametrize("tile", [15, 19, 21, 23])
+@pytest.mark.parametrize("tile", [15, 19, 21, 23, 31, 32])
 @pytest.mark.parametrize("case", ["linear", "ragged", "conv3", "gelu", "silugate", "gate_res_split", "qkv_split"])
 @pytest.mark.parametrize("act", [torch.bfloat16, torch.float16])
 def test_gemm_fp8_weight_storage(dev, fmt, tile, case, act):
@@ -145,8 +150,10 @@ def test_gemm_fp8_weight_storage(dev, fmt, tile, case, act):
     registers.  Widening is exact and both kernels use the same K order, so the result must be BIT-IDENTICAL
     to the same GEMM on the weights widened to bf16 at load time - and therefore as close to the fp32
     statement on fp8-rounded weights as the bf16 path is."""
-    if tile in (21, 23) and case not in ("conv3", "gate_res_split"):
-        pytest.skip("tiles 21 / 23 are the tap-fused conv k=3 kernels")
+    if tile in (21, 23, 31) and case not in ("conv3", "gate_res_split"):
+        pytest.skip("tiles 21 / 23 / 31 are the tap-fused conv k=3 kernels")
+    if tile == 32 and case in ("conv3", "gate_res_split", "qkv_split"):
+        pytest.skip("tile 32 is the plain 256x256 tile (32-byte fp8 weight rows): linear layers without the head split")
     M, N, K = {"linear": (500, 1536, 1536), "ragged": (257, 1408, 320), "conv3": (500, 512, 3 * 256), "gelu": (300, 512, 256),
                "silugate": (300, 512, 256), "gate_res_split": (500, 1536, 3 * 512), "qkv_split": (500, 3 * 2 * 128, 256)}[case]
     conv = (250, K // 3, 3, 1) if case in ("conv3", "gate_res_split") else None
@@ -229,7 +236,7 @@ def test_gemm_split_k(dev, ksplit, conv):
 
 
 @pytest.mark.parametrize("ksplit", [0, 2, 3, 7])
-@pytest.mark.parametrize("conv", [False, True, 11, 13, 15, 19, 21, 22, 23])
+@pytest.mark.parametrize("conv", [False, True, 11, 13, 15, 19, 21, 22, 23, 31, -32])
 @pytest.mark.parametrize("tok_gate", [False, True])
 @pytest.mark.parametrize("slab_dt", [torch.float32, torch.bfloat16, torch.float16])
 def test_gemm_deferred_split_k(dev, ksplit, conv, tok_gate, slab_dt):
@@ -251,14 +258,14 @@ def test_gemm_deferred_split_k(dev, ksplit, conv, tok_gate, slab_dt):
         gate = _rand((N,), 28)
         g_full = gate
         rb = rt.rowbcast(gate.to(dev), 0)
-    if conv:
+    if conv and conv > 0:
         y = O.conv1d_cl(_q(x, dt), _q(w, dt), b, 1).reshape(B * L, N)
         Wp, kw = packers.conv_to_gemm(w), dict(conv=(L, C, 3, 1))
-        if conv in (11, 13, 15, 19, 21, 22, 23):
+        if conv in (11, 13, 15, 19, 21, 22, 23, 31):
             kw["tile"] = conv    # tap-fused / wave-specialised conv addressing
     else:
         y = F.linear(_q(x, dt).reshape(B * L, C), _q(w[:, :, 0], dt), b)
-        Wp, kw = w[:, :, 0].contiguous(), {}
+        Wp, kw = w[:, :, 0].contiguous(), ({"tile": -conv} if conv else {})     # negative: a plain linear layer on that tile
     xres = res0.to(dev).clone()
     slabs = torch.full((8, B * L, N), float("nan"), device=dev, dtype=slab_dt)
     used = rt.op_gemm(x.reshape(B * L, C).to(dev, dt), Wp.to(dev, dt), b.to(dev), out0=xres, epilogue=rt.EPI_GATE_RES,
@@ -281,11 +288,11 @@ def test_gemm_deferred_split_k(dev, ksplit, conv, tok_gate, slab_dt):
 
 # ----------------------------------------------------------------------------- GEMM: conv addressing
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("tile", [0, 3, 5, 6, 11, 13, 15, 19, 21, 22, 23])
+@pytest.mark.parametrize("tile", [0, 3, 5, 6, 11, 13, 15, 19, 21, 22, 23, 31])
 @pytest.mark.parametrize("B,L,Cin,Cout", [(2, 50, 256, 384), (3, 7, 128, 64), (1, 250, 1536, 256), (5, 33, 128, 200), (2, 250, 64, 128),
-                                          (4, 129, 192, 320)])
+                                          (4, 129, 192, 320), (16, 250, 128, 256)])
 def test_conv3_channels_last(dev, dtype, tile, B, L, Cin, Cout):
-    if tile in (15, 19, 21, 22, 23) and dtype == torch.float32:
+    if tile in (15, 19, 21, 22, 23, 31) and dtype == torch.float32:
         pytest.skip("wave-specialised tiles are bf16 only")
     """ChannelLastConv1d k=3 pad=1 (mlp_layers.py:104-110) as a GEMM over overlapping rows
     (register-staged and direct-to-LDS mainloops)."""
@@ -298,7 +305,7 @@ def test_conv3_channels_last(dev, dtype, tile, B, L, Cin, Cout):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("tile", [0, 21, 22, 23])
+@pytest.mark.parametrize("tile", [0, 21, 22, 23, 31])
 @pytest.mark.parametrize("B,L,Cin,Cout", [(2, 250, 1536, 512), (3, 70, 128, 256), (4, 129, 192, 384)])
 def test_conv3_silu_gate(dev, dtype, tile, B, L, Cin, Cout):
     """ConvMLP w1 / w3 (mlp_layers.py:113-149): silu(conv3(x, w1)) * conv3(x, w3) in one launch over the
@@ -394,7 +401,10 @@ def test_attention(dev, out_dtype, B, H, Sq, Skv, split, kv_bdiv):
     (16, 12, 290, 290, 40, 1), (16, 12, 290, 77, 40, 8), (32, 4, 257, 95, 3, 1), (64, 2, 129, 33, 0, 2),
     # config C5 (30 s, CFG pair): the wide kernel at its real key-tile counts - 55 / 47 tiles of online-softmax
     # rescaling with a ragged last tile (1740 = 54*32 + 12, 1500 = 46*32 + 28), and the 77 cached text keys
-    (2, 12, 1740, 1740, 240, 1), (2, 12, 1500, 1500, 0, 1), (2, 12, 1740, 77, 240, 1)])
+    (2, 12, 1740, 1740, 240, 1), (2, 12, 1500, 1500, 0, 1), (2, 12, 1740, 77, 240, 1),
+    # the 64-keys-per-iteration form of long sequences on small grids (attn_bf16_long_kernel: the two C5 self-attention shapes above
+    # and these): last tile with 33 / 24 / 64 valid keys, odd tile counts, a shared K / V batch
+    (3, 12, 1100, 545, 0, 1), (2, 12, 1400, 600, 100, 1), (4, 6, 1300, 1024, 0, 2)])
 @pytest.mark.parametrize("half", [torch.bfloat16, torch.float16])
 def test_attention_bf16(dev, B, H, Sq, Skv, split, kv_bdiv, half):
     """Throughput kernels: bf16 Q/K, transposed bf16 V with a padded pitch; 4-wave key split for
@@ -467,6 +477,24 @@ def test_attention_bf16_spiky(dev):
     ob = torch.empty(1, 64, 128, device=dev, dtype=torch.bfloat16)
     rt.op_attention(qb.to(dev), kb.to(dev), vt.to(dev), ob, ob, 0)
     assert rel_err(ob.float(), ref) < 1e-2
+
+
+def test_attention_long_kernel_rescales(dev):
+    """attn_bf16_long_kernel (64 keys per iteration): spikes placed in different 64-key tiles - and in both 32-key halves of one - force
+    the running maximum of chosen queries to jump late in the key walk (the rare accumulator-rescale branch; guide rule 26)."""
+    B, H, Sq, Skv = 2, 12, 1400, 640
+    q, k, v = _rand((B, H, Sq, 128), 36), _rand((B, H, Skv, 128), 37), _rand((B, H, Skv, 128), 38)
+    for (b, h, key, qi, amp) in ((0, 0, 70, 5, 4.0), (0, 0, 300, 5, 6.0), (0, 0, 610, 5, 9.0), (1, 7, 100, 1399, 5.0), (1, 7, 130, 1399, 8.0),
+                                 (1, 3, 639, 700, 7.0)):
+        k[b, h, key] = q[b, h, qi] * amp
+    qb, kb, vb = (t.to(torch.bfloat16) for t in (q, k, v))
+    ref = O.sdpa(qb.float(), kb.float(), vb.float()).transpose(1, 2).reshape(B, Sq, H * 128)
+    vt = vb.transpose(2, 3).contiguous()
+    ob = torch.full((B, Sq, H * 128), float("nan"), device=dev, dtype=torch.bfloat16)
+    rt.op_attention(qb.to(dev), kb.to(dev), vt.to(dev), ob, ob, 0)
+    assert rel_err(ob.float(), ref) < 1e-2
+    for (b, h, qi) in ((0, 0, 5), (1, 7, 1399), (1, 3, 700)):      # the spiked rows themselves
+        assert rel_err(ob[b, qi, h * 128:(h + 1) * 128].float(), ref[b, qi, h * 128:(h + 1) * 128]) < 2e-2
 
 
 def test_attention_spiky_scores(dev):
