@@ -742,6 +742,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // are independent MFMA chains, and the lane-half exchanges are v_permlane32_swap (one VALU instruction each; __shfl_xor
 // compiles to ds_bpermute, a round trip through the LDS crossbar).  Same operand layout, staging (register-staged double
 // buffer, padded pitches) and output mapping as attn_bf16_wide_kernel; 70 KiB of LDS, two workgroups per CU.
+// Measured (tools/attn_bench.py): S = 1740 75.6 -> 71.8 us, S = 1500 64.0 -> 61.1 us - the chain is not latency- but
+// instruction-bound: rocprofv3 SQ counters give, per wave, VALU 28 % (278 VALU instructions per 64 keys: exponentials,
+// maxima, packing, staging addresses), matrix pipe 26 %, parked at a wait 39 %, issue stalls 24 %, at 1.3 waves per SIMD.
+// A split-KV form on top of it (two workgroups per query tile, each half of the keys, partial softmax states merged by the
+// second arriver through a workspace record with an agent-scope release / acquire hand-off) was built, correct, and SLOWER
+// (91 vs 72 us): at 208 registers and 70 KiB only two workgroups fit a CU, so its 672 workgroups run in 1.3 rounds.
 __device__ __forceinline__ float xhalf_max(float v) {   // max over the lane pair (l, l ^ 32)
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));

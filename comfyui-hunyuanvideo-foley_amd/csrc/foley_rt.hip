@@ -654,13 +654,31 @@ extern "C" int foley_prepare(foley_ctx* c, const foley_plan* pl, void* stream_v)
     const size_t tab_bytes = (size_t)NI * ncfg * P * ncol * 4;
     // ... and only where the weight stream is what the per-iteration GEMM costs (a few distinct rows: the 8-periodic empty sync
     // features).  With the 224 dense rows of a video clip the batched GEMM costs what the 50 small ones do (18.3 vs 19 ms).
-    const bool hoist = f.depth_single > 0 && ncfg * P <= 64 && (double)tab_bytes <= cap_gb * 1073741824.0;
+    bool hoist = f.depth_single > 0 && ncfg * P <= 64 && (double)tab_bytes <= cap_gb * 1073741824.0;
+    const size_t svec_bytes = (size_t)NI * ncfg * Ls * D * es;
+    if (hoist) {
+      // ... and only while the tables (they scale with n_iter: 1.06 GB at 50 steps, 4.2 GB at 200) take at most half of what the
+      // device has free, counting what this context already holds - every data-parallel replica keeps its own
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { hipGetLastError(); free_b = 0; }
+      const size_t held = c->smod_tab.bytes + c->svec_tab.bytes;
+      if (tab_bytes + svec_bytes > held && (tab_bytes + svec_bytes - held) > free_b / 2) hoist = false;
+    }
+    const void* old_tab = c->smod_tab.p;
+    if (hoist && (grow(c->smod_tab, tab_bytes) != 0 || grow(c->svec_tab, svec_bytes) != 0)) {
+      hipGetLastError();     // allocation failed: not an error - the per-iteration GEMM of run_forward is still there
+      hoist = false;
+    }
+    if (!hoist && (c->smod_tab.p || c->svec_tab.p)) {   // a plan that does not hoist gives the tables back
+      HIPTRY(hipStreamSynchronize(st));
+      if (c->smod_tab.p) hipFree(c->smod_tab.p);
+      if (c->svec_tab.p) hipFree(c->svec_tab.p);
+      c->smod_tab = DevBuf{};
+      c->svec_tab = DevBuf{};
+    }
     if (c->graph_exec && hoist != c->smod_hoisted) ctx_drop_graph(c);
     c->smod_hoisted = false;
     if (hoist) {
-      const void* old_tab = c->smod_tab.p;
-      TRY(grow(c->smod_tab, tab_bytes));
-      TRY(grow(c->svec_tab, (size_t)NI * ncfg * Ls * D * es));
       if (c->graph_exec && old_tab != c->smod_tab.p) ctx_drop_graph(c);   // captured kernels hold the table's address
       for (int it = 0; it < NI; ++it)
         TRY(launch_rows_add_act(c->sync_tok, rb_vec(c->vec_table + (size_t)it * D, 0, nullptr), ncfg * Ls, D, 1,

@@ -20,6 +20,7 @@
 
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <set>
 #include <string>
 #include <vector>
@@ -711,4 +712,79 @@ extern "C" int foley_bcast_weights(foley_ctx* c, void* nccl_comm, int root, void
   const int rc = fn(w->arena, w->arena, w->bytes, /*ncclUint8*/ 1, root, nccl_comm, (hipStream_t)stream);
   if (rc != 0) return W_FAIL(FOLEY_ERR_HIP, "ncclBroadcast failed");
   return foley_weights_mark_received(c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Single-process data parallelism (one host process that sees all GPUs of the node - the ComfyUI case, host/sampler.py
+// replicate()): every buffer of the root device reaches the other devices in ONE grouped RCCL launch - ncclCommInitAll over
+// the device list, then ncclGroupStart / one ncclBroadcast per (device, buffer) / ncclGroupEnd - instead of N-1 serial peer
+// copies.  Communicators are cached per device list.  RCCL is resolved from the process like in foley_bcast_weights.
+namespace {
+struct Rccl {
+  typedef int (*init_all_fn)(void**, int, const int*);
+  typedef int (*group_fn)();
+  typedef int (*bcast_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+  init_all_fn init_all = nullptr;
+  group_fn gstart = nullptr, gend = nullptr;
+  bcast_fn bcast = nullptr;
+  bool ok = false;
+};
+Rccl& rccl() {
+  static Rccl r = []() {
+    Rccl q;
+    void* h = nullptr;
+    auto sym = [&](const char* name) -> void* {
+      void* p = dlsym(RTLD_DEFAULT, name);
+      if (!p && h) p = dlsym(h, name);
+      return p;
+    };
+    if (!dlsym(RTLD_DEFAULT, "ncclCommInitAll"))
+      for (const char* lib : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+        h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+        if (!h) h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+      }
+    q.init_all = (Rccl::init_all_fn)sym("ncclCommInitAll");
+    q.gstart = (Rccl::group_fn)sym("ncclGroupStart");
+    q.gend = (Rccl::group_fn)sym("ncclGroupEnd");
+    q.bcast = (Rccl::bcast_fn)sym("ncclBroadcast");
+    q.ok = q.init_all && q.gstart && q.gend && q.bcast;
+    return q;
+  }();
+  return r;
+}
+std::mutex g_local_mu;
+std::map<std::vector<int>, std::vector<void*>> g_local_comms;
+}  // namespace
+
+extern "C" int foley_bcast_local(int ndev, const int* devices, int nbuf, void* const* bufs, const uint64_t* bytes) {
+  if (ndev < 1 || !devices || nbuf < 1 || !bufs || !bytes) return W_FAIL(FOLEY_ERR_INVALID, "bad argument");
+  Rccl& r = rccl();
+  if (!r.ok) return W_FAIL(FOLEY_ERR_STATE, "RCCL (ncclCommInitAll / ncclGroupStart / ncclBroadcast) not found in the process");
+  std::lock_guard<std::mutex> lk(g_local_mu);
+  int prev = 0;
+  hipGetDevice(&prev);
+  const std::vector<int> key(devices, devices + ndev);
+  auto it = g_local_comms.find(key);
+  if (it == g_local_comms.end()) {
+    std::vector<void*> comms((size_t)ndev, nullptr);
+    if (r.init_all(comms.data(), ndev, devices) != 0) {
+      hipSetDevice(prev);
+      return W_FAIL(FOLEY_ERR_HIP, "ncclCommInitAll failed (duplicate or unreachable devices?)");
+    }
+    it = g_local_comms.emplace(key, comms).first;
+  }
+  int rc = r.gstart();
+  for (int d = 0; d < ndev && rc == 0; ++d) {
+    if (hipSetDevice(devices[d]) != hipSuccess) { rc = -1; break; }
+    for (int i = 0; i < nbuf && rc == 0; ++i)
+      rc = r.bcast(bufs[(size_t)d * nbuf + i], bufs[(size_t)d * nbuf + i], (size_t)bytes[i], /*ncclUint8*/ 1, /*root rank*/ 0,
+                   it->second[(size_t)d], (hipStream_t)0);   // in place on every rank (the send buffer only counts on the root)
+  }
+  const int rc2 = r.gend();
+  for (int d = 0; d < ndev; ++d)
+    if (hipSetDevice(devices[d]) == hipSuccess) hipDeviceSynchronize();
+  hipSetDevice(prev);
+  if (rc != 0 || rc2 != 0) return W_FAIL(FOLEY_ERR_HIP, "grouped ncclBroadcast failed");
+  return 0;
 }

@@ -91,7 +91,7 @@ class ProfEntryC(C.Structure):
 
 
 PROGRESS_CB = C.CFUNCTYPE(None, C.c_int32, C.c_int32, C.c_void_p)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _SIGNATURES = {
     "foley_abi_version": (C.c_uint32, []),
@@ -105,6 +105,7 @@ _SIGNATURES = {
     "foley_weights_arena": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "foley_weights_mark_received": (C.c_int, [C.c_void_p]),
     "foley_bcast_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "foley_bcast_local": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "foley_prepare": (C.c_int, [C.c_void_p, C.POINTER(FoleyPlanC), C.c_void_p]),
     "foley_dit_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "foley_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, PROGRESS_CB, C.c_void_p, C.c_void_p]),
@@ -379,6 +380,32 @@ class FoleyContext:
 
 
 # ----------------------------------------------------------------------------- op-level wrappers (tests, microbench)
+def bcast_local(buffers_per_device: Sequence[Sequence[torch.Tensor]]) -> float:
+    """foley_bcast_local: `buffers_per_device[d][i]` is buffer i (uint8, same size on every device) on the d-th device; the
+    root's (d = 0) contents reach every other device in ONE grouped RCCL launch.  Returns the wall time in seconds.  RCCL is
+    the copy PyTorch ships (loaded into the process here if torch.distributed has not done so yet)."""
+    import time
+    lib = load_library()
+    ndev, nbuf = len(buffers_per_device), len(buffers_per_device[0])
+    devs = [b[0].device.index for b in buffers_per_device]
+    if len(set(devs)) != ndev:
+        raise FoleyRuntimeError("bcast_local: one entry per distinct device")
+    for b in buffers_per_device:
+        if len(b) != nbuf or any(t.device != b[0].device or not t.is_contiguous() for t in b):
+            raise FoleyRuntimeError("bcast_local: every device carries the same buffers")
+    rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    if os.path.exists(rccl):
+        C.CDLL(rccl, mode=C.RTLD_GLOBAL)
+    dev_arr = (C.c_int * ndev)(*devs)
+    ptrs = (C.c_void_p * (ndev * nbuf))(*[t.data_ptr() for b in buffers_per_device for t in b])
+    sizes = (C.c_uint64 * nbuf)(*[t.numel() * t.element_size() for t in buffers_per_device[0]])
+    for d in devs:
+        torch.cuda.synchronize(d)
+    t0 = time.perf_counter()
+    _check(lib, lib.foley_bcast_local(ndev, dev_arr, nbuf, ptrs, sizes), "foley_bcast_local")
+    return time.perf_counter() - t0
+
+
 def rowbcast(t: Optional[torch.Tensor], mode: int = 0, rows_per_cfg: int = 1, L: int = 1,
              ld: Optional[int] = None, Ls: int = 0, period: int = 0) -> RowBcastC:
     """mode 2: `t` holds Ls rows per cfg; token l of a clip reads row nearest_exact(l) (tables.nearest_exact_index)."""

@@ -214,36 +214,62 @@ def denoise_process_with_generator(visual_feats, text_feats, audio_len_in_s, mod
 def replicate(model: FoleyModel, dac: Optional[FoleyDAC], devices: Sequence) -> List:
     """One (FoleyModel, FoleyDAC) pair per device of `devices` for clip-level data parallelism inside ONE
     process (the ComfyUI case: a single prompt-worker process that sees all GPUs of the node).  The pair of the
-    device the model already lives on is reused; every other device receives ONE device-to-device copy of the
-    packed DiT arena and one of the DAC arena (peer copies over xGMI) - the in-process counterpart of the
-    single broadcast of host/distributed.py.  Replicas are cached on the model."""
+    device the model already lives on is reused; all other devices receive the packed DiT arena and the DAC arena in
+    ONE grouped RCCL broadcast over xGMI (`runtime.bcast_local` -> foley_bcast_local: ncclCommInitAll over the device
+    list, one ncclBroadcast per (device, arena) inside ncclGroupStart / End) - the in-process counterpart of the single
+    broadcast of host/distributed.py; `model.last_broadcast_s` keeps its wall time.  A second context on a device that
+    already holds one (the 1-GPU test set-up: RCCL communicators want distinct devices) takes a device-local copy.
+    Replicas are cached on the model."""
+    from . import runtime as _rt
     if model.arena is None:
         raise FoleyRuntimeError("replicate() needs a model packed by the host packers (an arena it can copy)")
     cache = model.__dict__.setdefault("_replicas", {})
-    out = []
+    slots, pending = [], []                         # per requested device: ("own", ) | ("cached", key) ; new replicas to fill
     for d in devices:
         d = torch.device(d)
         if d.type != "cuda":
             raise FoleyRuntimeError("replicas live on HIP devices")
         if d.index is None:
             d = torch.device("cuda", torch.cuda.current_device())
-        if d == model.device and not any(m is model for m, _ in out):
-            out.append((model, dac))
+        if d == model.device and not any(sl[0] == "own" for sl in slots):
+            slots.append(("own", None))
             continue
-        key = (str(d), sum(1 for m, _ in out if m.device == d))        # the same device twice = two contexts on it
-        if key not in cache:
-            arena = packers.Arena(model.arena.buffer.numel(), model.arena.table, d,
-                                  buffer=model.arena.buffer.to(d, copy=True))
-            m = FoleyModel.from_arena(model.cfg, arena, model.dtype, d, dac_cfg=model.dac_cfg,
-                                      quantization=model.quantization)
+        key = (str(d), sum(1 for sl in slots if sl[1] is not None and sl[1][0] == str(d)) + 0)   # the same device twice = two contexts on it
+        slots.append(("cached", key))
+        if key not in cache and key not in [p[0] for p in pending]:
+            pending.append((key, d))
+    if pending:
+        bufs = {}
+        for key, d in pending:
+            bufs[key] = (torch.empty_like(model.arena.buffer, device=d),
+                         torch.empty_like(dac.arena.buffer, device=d) if dac is not None else None)
+        # one grouped broadcast to the first new replica of every device that does not hold the model yet
+        first = {}
+        for key, d in pending:
+            if d != model.device and d not in first:
+                first[d] = key
+        model.last_broadcast_s = 0.0
+        if first:
+            per_dev = [[model.arena.buffer.view(torch.uint8).reshape(-1)] + ([dac.arena.buffer.view(torch.uint8).reshape(-1)] if dac is not None else [])]
+            for d, key in first.items():
+                per_dev.append([bufs[key][0].view(torch.uint8).reshape(-1)] + ([bufs[key][1].view(torch.uint8).reshape(-1)] if dac is not None else []))
+            model.last_broadcast_s = _rt.bcast_local(per_dev)
+        for key, d in pending:                      # further contexts on a device: device-local copies of what is there already
+            if first.get(d) == key:
+                continue
+            src = (model.arena.buffer, dac.arena.buffer if dac is not None else None) if d == model.device else bufs[first[d]]
+            bufs[key][0].copy_(src[0])
+            if dac is not None:
+                bufs[key][1].copy_(src[1])
+        for key, d in pending:
+            arena = packers.Arena(model.arena.buffer.numel(), model.arena.table, d, buffer=bufs[key][0])
+            m = FoleyModel.from_arena(model.cfg, arena, model.dtype, d, dac_cfg=model.dac_cfg, quantization=model.quantization)
             m._text_len_fixed = model._text_len_fixed      # the sticky text bucket is per MODEL in the reference (utils.py:166-188)
             dd = None
             if dac is not None:
-                da = packers.Arena(dac.arena.buffer.numel(), dac.arena.table, d, buffer=dac.arena.buffer.to(d, copy=True))
-                dd = FoleyDAC.from_arena(da, d, dac.cfg)
+                dd = FoleyDAC.from_arena(packers.Arena(dac.arena.buffer.numel(), dac.arena.table, d, buffer=bufs[key][1]), d, dac.cfg)
             cache[key] = (m, dd)
-        out.append(cache[key])
-    return out
+    return [(model, dac) if kind == "own" else cache[key] for kind, key in slots]
 
 
 def denoise_process_multi(visual_feats, text_feats, audio_len_in_s, replicas: Sequence, guidance_scale: float,

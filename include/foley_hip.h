@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FOLEY_ABI_VERSION 8   /* 8: foley_qkv_split_desc.attn_* (cross attention in the epilogue of its q projection), foley_abort / FOLEY_ERR_ABORTED; 7: FOLEY_DT_F16 as a compute dtype (foley_config.compute_dtype, op descriptors); 6: foley_rowbcast.Ls (mode 2: nearest-exact up-sampled operand); 5: reference-keyed loading (foley_weights_*, foley_load_tensor, foley_bcast_weights); 4: fp8 weight storage (dtype codes 3/4, foley_gemm_desc.ldw/.wfmt); 3: foley_profile_forward; 2: foley_gemm_desc gained partials / qkv / rstride; foley_op_ln_mod_pending, foley_dac_encode */
+#define FOLEY_ABI_VERSION 9   /* 9: foley_bcast_local (single-process grouped broadcast of the arenas); 8: foley_qkv_split_desc.attn_* (cross attention in the epilogue of its q projection), foley_abort / FOLEY_ERR_ABORTED; 7: FOLEY_DT_F16 as a compute dtype (foley_config.compute_dtype, op descriptors); 6: foley_rowbcast.Ls (mode 2: nearest-exact up-sampled operand); 5: reference-keyed loading (foley_weights_*, foley_load_tensor, foley_bcast_weights); 4: fp8 weight storage (dtype codes 3/4, foley_gemm_desc.ldw/.wfmt); 3: foley_profile_forward; 2: foley_gemm_desc gained partials / qkv / rstride; foley_op_ln_mod_pending, foley_dac_encode */
 
 enum foley_dtype {
   FOLEY_DT_F32 = 0, FOLEY_DT_BF16 = 1, FOLEY_DT_I32 = 2,
@@ -127,6 +127,11 @@ int foley_weights_end(foley_ctx* ctx, void* stream);
 int foley_weights_arena(foley_ctx* ctx, void** dev_ptr, uint64_t* bytes);
 int foley_weights_mark_received(foley_ctx* ctx);
 int foley_bcast_weights(foley_ctx* ctx, void* nccl_comm, int root, void* stream);
+/* Single-process form of the same step (one host process that drives all GPUs of the node, e.g. a ComfyUI prompt worker; the
+ * reference has no counterpart - its only batching is utils.py:159-162 on one device): buffer i of devices[0] (`bytes[i]` bytes at
+ * bufs[0 * nbuf + i]) is broadcast to bufs[d * nbuf + i] on every other device in ONE grouped RCCL launch (ncclCommInitAll over
+ * `devices`, cached; ncclGroupStart / ncclBroadcast per (device, buffer) / ncclGroupEnd), then every device is synchronised. */
+int foley_bcast_local(int ndev, const int* devices, int nbuf, void* const* bufs, const uint64_t* bytes);
 
 /* Step-invariant precompute for one run; allocates/reuses the context workspace. */
 int foley_prepare(foley_ctx* ctx, const foley_plan* plan, void* stream);

@@ -112,6 +112,25 @@ def test_bench_spawns_its_own_ranks(config, bs):
     assert abs(sum(x["noise_sum"] for x in out["ranks"]) - out["noise_total"]) < 1e-9
 
 
+def test_bench_eight_ranks_c4_dry_run():
+    """The 8-GPU job of BASELINE configs[3] (bs = 64: eight ranks x eight clips) through bench.py's own spawner, on CPU
+    tensors over gloo: eight ranks rendezvous on 127.0.0.1, rank 0 packs, ONE broadcast ships the bundle (video features
+    included), rank r owns clips [8r, 8r + 8), every rank verifies what it received against a local re-synthesis, and
+    stdout is one JSON line.  (The largest world the GPU side can be tried at before the driver's 8-GPU run is 2.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--dry-run",
+                        "--config", "c4", "--model", "tiny", "--duration", "1"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len([ln for ln in r.stdout.splitlines() if ln.strip()]) == 1, r.stdout[:500]
+    out = json.loads(r.stdout.strip())
+    assert out["n_gpus"] == 8 and out["collectives"] == 1 and out["backend"] == "gloo"
+    assert [x["rank"] for x in out["ranks"]] == list(range(8))
+    assert [x["shard"] for x in out["ranks"]] == [[8 * i, 8 * i + 8] for i in range(8)] and all(x["ok"] for x in out["ranks"])
+    assert abs(sum(x["noise_sum"] for x in out["ranks"]) - out["noise_total"]) < 1e-9
+
+
 def test_bench_rejects_inconsistent_launch():
     """A mismatch between --gpus and the launcher's WORLD_SIZE is a clean error (exit code 2), not an assert."""
     env = dict(os.environ, RANK="0", WORLD_SIZE="4", LOCAL_RANK="0")

@@ -791,7 +791,8 @@ def test_denoise_process_multi_shards_the_batch(tiny, dev):
     clips of a batch are sharded over replicas, one host thread and one context each, with no collective.  On a
     1-GPU box the two replicas are two contexts on the same device (the threading, the per-thread stream capture
     and the process-wide set-up lock are what is exercised); with two GPUs the second replica lives on cuda:1
-    after ONE peer copy of the arena.  The sharded run must equal the single-context run of the full batch."""
+    after ONE grouped RCCL broadcast of the two arenas (runtime.bcast_local).  The sharded run must equal the single-context
+    run of the full batch."""
     sd, dsd, model, dac = tiny
     cond = synth.synth_conditioning(C.TINY, 1.0, t2a=False)
     vis = {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]}
@@ -812,6 +813,25 @@ def test_denoise_process_multi_shards_the_batch(tiny, dev):
     one, _sr = sampler.denoise_process_multi(vis, txt, 1.0, reps, 4.5, 10, 1, "euler",
                                              generator=torch.Generator("cpu").manual_seed(7))
     assert rel_err(one, full[:1]) < 1e-5
+
+
+def test_bcast_local_grouped_rccl_launch(dev):
+    """foley_bcast_local (the in-process form of the single weight broadcast, used by sampler.replicate): ncclCommInitAll over
+    every visible device + ONE grouped launch carrying two buffers per device.  On the 1-GPU boxes the communicator has one
+    rank (RCCL resolution, communicator cache, group semantics and the in-place root call are what runs); with more devices
+    every replica must hold the root's bytes afterwards."""
+    from foley_amd.host import runtime as rt
+    n = torch.cuda.device_count()
+    g = torch.Generator().manual_seed(3)
+    a0 = torch.randint(0, 255, (3_000_001,), dtype=torch.uint8, generator=g).to(dev)
+    b0 = torch.randint(0, 255, (4097,), dtype=torch.uint8, generator=g).to(dev)
+    per_dev = [[a0, b0]] + [[torch.zeros_like(a0, device=f"cuda:{i}"), torch.zeros_like(b0, device=f"cuda:{i}")] for i in range(1, n)]
+    want_a, want_b = a0.cpu(), b0.cpu()
+    for _ in range(2):                                    # the second call takes the cached communicators
+        secs = rt.bcast_local(per_dev)
+        assert secs >= 0.0
+        for bufs in per_dev:
+            assert torch.equal(bufs[0].cpu(), want_a) and torch.equal(bufs[1].cpu(), want_b)
 
 
 def test_bench_two_ranks_over_rccl(dev):
