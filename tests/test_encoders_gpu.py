@@ -67,6 +67,48 @@ def test_siglip_vision_tower_on_the_engine(dev):
     assert f32.shape == ref.shape and e32 < 2e-5 and e16 < 5e-3 and eb < 4e-2
 
 
+def test_siglip_full_depth_benchmarked_tower(dev):
+    """The tower bench.py times (google/siglip2-base-patch16-512's architecture: 12 layers, 512 px, 1024 tokens per frame)
+    at FULL depth and resolution, one frame, against transformers' module on the CPU in fp32 - the benchmarked encoder is
+    parity-checked, not only finite; a second frame checks batch independence at this size."""
+    m = _small_siglip(layers=12, image=512, patch=16)
+    sd = {k: v.detach().to(dev) for k, v in m.state_dict().items()}
+    px = torch.randn(2, 3, 512, 512, generator=torch.Generator().manual_seed(6))
+    with torch.inference_mode():
+        ref = m(pixel_values=px[:1]).pooler_output
+    f32 = EH.siglip_image_features_hip(sd, px.to(dev), torch.float32)
+    b16 = EH.siglip_image_features_hip(sd, px.to(dev), torch.bfloat16)
+    e32, eb = rel_err(f32[:1], ref), rel_err(b16[:1], ref)
+    print("SigLIP2 ViT-B/16-512, 12 layers, on the HIP engine vs transformers (CPU fp32): fp32 %.2e, bf16 %.2e" % (e32, eb))
+    assert f32.shape == (2, 768) and e32 < 2e-5 and eb < 6e-2
+    one = EH.siglip_image_features_hip(sd, px[1:].to(dev).contiguous(), torch.float32)
+    assert rel_err(one, f32[1:]) < 1e-5
+
+
+def test_clap_full_depth_benchmarked_encoder(dev):
+    """The CLAP text encoder bench.py times (ClapTextConfig defaults = laion/larger_clap_general's RoBERTa-base: 12 layers,
+    MLP 3072, vocabulary 50265) at full depth, one prompt of 12 tokens + <s> </s>, against transformers on the CPU in fp32."""
+    from transformers import ClapTextConfig, ClapTextModelWithProjection
+    torch.manual_seed(5)
+    m = ClapTextModelWithProjection(ClapTextConfig()).eval()
+    with torch.no_grad():
+        gen = torch.Generator().manual_seed(6)
+        for n, p_ in m.named_parameters():
+            if p_.dim() == 1:
+                p_.copy_((1.0 if "LayerNorm.weight" in n else 0.0) + 0.05 * torch.randn(p_.shape, generator=gen))
+    g = torch.Generator().manual_seed(7)
+    ids = torch.cat([torch.tensor([0]), torch.randint(3, 50000, (12,), generator=g), torch.tensor([2])])[None]
+    mask = torch.ones_like(ids)
+    with torch.inference_mode():
+        ref = m(input_ids=ids, attention_mask=mask, return_dict=True).last_hidden_state
+    sd = {k: v.detach().to(dev) for k, v in m.state_dict().items() if k.startswith("text_model.") and v.is_floating_point()}
+    f32 = EH.clap_text_hidden_hip(sd, ids.to(dev), mask.to(dev), torch.float32)
+    b16 = EH.clap_text_hidden_hip(sd, ids.to(dev), mask.to(dev), torch.bfloat16)
+    e32, eb = rel_err(f32, ref), rel_err(b16, ref)
+    print("CLAP RoBERTa-base, 12 layers, on the HIP engine vs transformers (CPU fp32): fp32 %.2e, bf16 %.2e" % (e32, eb))
+    assert f32.shape == ref.shape and e32 < 2e-5 and eb < 6e-2
+
+
 def test_clap_text_encoder_on_the_engine(dev):
     """`last_hidden_state` of transformers' ClapTextModelWithProjection (the text tokens of feature_utils.py:133-138) as restated
     on the engine - RoBERTa embeddings with pad-aware positions, post-norm layers, exact GELU, LayerNorm eps 1e-12 - for two

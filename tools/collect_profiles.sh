@@ -2,9 +2,9 @@
 # Runs on the GPU box (via gpurun): bench lines, rocprofv3 kernel-trace stats of the bench command and
 # the PMC passes (separate runs, kernel filter - rocprofv3 segfaults in PyTorch's own kernels
 # otherwise), summarised into gpurun_out/ (the raw databases stay in /tmp: too large to ship back).
-#   gpurun --timeout 1800 -- 'bash tools/collect_profiles.sh r03 [tag-suffix]'
+#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r04 [tag-suffix]'
 set -u
-TAG=${1:-r03}${2:+_$2}
+TAG=${1:-r04}${2:+_$2}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out
 mkdir -p $OUT
@@ -44,4 +44,12 @@ python $R/tools/prof_summary.py $(find /tmp/kt5 -name "*.db" | head -1) > $OUT/$
 # the same SQ counters at 8 clips per GPU (the bs=8 half of the metric): matrix-pipe utilisation of the large-grid kernels
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-include-regex "$FILTER" -d /tmp/pmc_sq8 -o p -- python $R/tools/profile_run.py --iters 2 --no-dac --bs 8 > /tmp/pmc_sq8.log 2>&1
 python $R/tools/pmc_summary.py $(find /tmp/pmc_sq8 -name "*.db") > $OUT/${TAG}_pmc_sq_bs8.md
-ls -la $OUT | tail -14
+# per-launch timeline of one DAC decode against the per-launch roofline bound (fp32 matrix peak / HBM), bs = 1 and 8
+for b in 1 8; do
+  rocprofv3 --kernel-trace -d /tmp/dt$b -o dt -- python $R/tools/dac_trace.py --bs $b > /tmp/dt$b.log 2>&1
+  python $R/tools/dac_trace.py --bs $b --summarise /tmp/dt$b > $OUT/${TAG}_dac_trace_bs$b.md 2>&1
+done
+python $R/tools/attn_bench.py > $OUT/${TAG}_attn_bench.txt 2>&1
+python $R/tools/wide_bench.py --m 4000 --cases w13,w2,lin2,fc1,fc2,proj --tiles 0,23,31 --rounds 12 > $OUT/${TAG}_wide_bench.txt 2>&1
+python $R/tools/wide_bench.py --m 3000 --cases w13,w2,lin2,fc1,fc2,proj --tiles 0,23,31 --rounds 12 --fp8 >> $OUT/${TAG}_wide_bench.txt 2>&1
+ls -la $OUT | tail -18

@@ -3,7 +3,8 @@ gated residual through deferred split-K slabs, GELU) - tools/gemm_bench.py times
 M = 4000 x N = 8192 moves more bytes than the operands.  Weights rotate through enough copies to defeat the Infinity
 Cache; variants are interleaved round by round inside ONE process (median and min per variant).
 
-    python tools/wide_bench.py --m 4000 --cases w13,w2,lin2,fc1,fc2,proj --tiles 0,31,33 [--rounds 12]
+    python tools/wide_bench.py --m 4000 --cases w13,w2,lin2,fc1,fc2,proj --tiles 0,23,31 [--rounds 12]
+(position bias: the first tile of a round runs 3 - 10 % slower than the same kernel later in the round - compare columns, not boxes)
 """
 import argparse
 import os
@@ -25,21 +26,15 @@ CASES = {"w13": (8192, 4608, True, "silugate"), "w2": (1536, 12288, True, "gate"
 ap = argparse.ArgumentParser()
 ap.add_argument("--m", type=int, default=4000)
 ap.add_argument("--cases", default="w13,w2,lin2,fc1,fc2")
-ap.add_argument("--tiles", default="0,31,33")
+ap.add_argument("--tiles", default="0,23,31")
 ap.add_argument("--rounds", type=int, default=12)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--fp8", action="store_true", help="weights stored as fp8 e4m3fn")
-ap.add_argument("--mode", type=int, default=0, help="experiment switches of the mainloops (GemmArgs::dbg_mode >> 8)")
 a = ap.parse_args()
-import ctypes as _C
-_lib = rt.load_library()
-_lib.foley_debug_gemm_timeline.argtypes = [_C.c_void_p, _C.c_int]
-_lib.foley_debug_gemm_timeline.restype = None
-_lib.foley_debug_gemm_timeline(None, a.mode << 8)
 dev = torch.device("cuda:0")
 dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
 tiles = [int(t) for t in a.tiles.split(",")]
-print(f"M={a.m} dtype={a.dtype} fp8={a.fp8} mode={a.mode}")
+print(f"M={a.m} dtype={a.dtype} fp8={a.fp8}")
 for name in a.cases.split(","):
     N, K, conv, epi = CASES[name]
     esz = 1 if a.fp8 else 2
@@ -60,12 +55,10 @@ for name in a.cases.split(","):
     def run(tile, i):
         W = Ws[i % ncopy]
         tconv = tile
-        if tile >= 35 and not conv:
-            tconv = 32
-        if tile in (31, 33) and not conv:
-            tconv = tile + 1            # 31 / 33 are the conv forms, 32 / 34 the plain ones
-        if tile in (32, 34) and conv:
-            tconv = tile - 1
+        if tile == 31 and not conv:
+            tconv = 32                  # 31 is the tap-fused conv form of the 256x256 tile, 32 the plain one
+        if tile == 32 and conv:
+            tconv = 31
         if epi == "silugate":
             return rt.op_gemm(A, W, None, out0=out16, epilogue=rt.EPI_SILUGATE_T, tile=tconv, **ckw)
         if epi == "gelu":
