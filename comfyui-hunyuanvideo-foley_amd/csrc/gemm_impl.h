@@ -630,14 +630,20 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
   // FOLEY_WIDE=0 keeps the 256x128 tiles.
   // Mid-size grids (M = 3000: the 30 s clip) whose N = 1536 gated-residual GEMMs landed on 128x128 tiles with two K ranges
   // (288 tiles, 1.1 rounds) take the same route: 72 tiles of 256x256 x three K ranges (w2 149 -> 97 us, fc2 99 -> 59 us).
-  const bool mid_split = (tile == 21 || tile == 15 || tile == 25) && g.M >= 2048 && epi == EPI_GATE_RES && deferred;
+  // (plain layers arrive here on tile 3 / 5 when their 288 tiles of 128x128 fit no rule above - fp8 weights turn that into tile 15 below)
+  // (bf16 convs on tile 22, the 256x64 tap-fused form); measured down to M = 2000 (w2 89 -> 70 us, fc2 65 -> 46 with five K ranges)
+  const bool mid_split = (tile == 21 || tile == 22 || tile == 15 || tile == 25 || tile == 5 || tile == 3) && g.M >= 1536 && g.N >= 256 &&
+                         epi == EPI_GATE_RES && deferred;
   if (tile_auto && sizeof(T) == 2 && !g1 && (tile == 23 || tile == 19 || tile == 29 || mid_split)) {
     static const bool wide_on = []() { const char* e = getenv("FOLEY_WIDE"); return !(e && e[0] == '0'); }();
-    const bool conv = tile == 23 || tile == 21;
+    const bool conv = tile == 23 || tile == 21 || (mid_split && ws_conv3_ok);
     const bool epi_ok = epi == EPI_STORE_F32 || epi == EPI_GATE_RES || epi == EPI_SILUGATE_T || (!conv && epi == EPI_GELU_T);
     // plain layers: long K only - a 256x256 tile pays its two-pass epilogue and 6-slice ring fill once per 24 slices at K = 768
     // (the ViT-B encoders' fc1 at M = 22 000: 223 us on this tile against ~140 on 256x128)
-    const bool addr_ok = conv || (g.taps == 1 && g.segV >= g.M && g.rstride <= 1 && g.tap0 == 0 && (g.K >= 2048 || mid_split));
+    const bool addr_ok = conv || (g.taps == 1 && g.segV >= g.M && g.rstride <= 1 && g.tap0 == 0 &&
+                                  // ... or a weight-streaming panel (the single-block modulation GEMM of a video clip: M = 224 rows against
+                                  // N = 331 776 columns - a 256-column tile re-reads the activations half as often: 60.6 -> 51.9 us per eighth)
+                                  (g.K >= 2048 || mid_split || (epi == EPI_STORE_F32 && g.N >= 16384 && g.M >= 128)));
     if (wide_on && epi_ok && addr_ok && g.tapC % 32 == 0) {
       const long mt = (g.M + 255) / 256, tw = mt * ((g.N + 255) / 256), tb = mt * ((g.N + 127) / 128);
       const int nk64 = (conv ? g.tapC : g.K) / 64;

@@ -51,6 +51,15 @@ class _Engine:
             t = self.vecs[k] = (t - 1.0 if minus_one else t).contiguous()
         return t
 
+    def fused(self, sd: SD, key: str, wkeys, bkeys) -> SD:
+        """Row-concatenation of several linear layers that read the same input (q / k / v projections kept as separate modules
+        by the HF encoders) staged once as ONE matrix / bias under `key`: one GEMM launch and one read of the activations
+        instead of three.  Returns the small dict `linear` looks the staged tensors up in."""
+        if key + ".w" not in self.mats:
+            self.mats[key + ".w"] = torch.cat([sd[k].detach().reshape(sd[k].shape[0], -1) for k in wkeys]).to(self.dev, self.dtype).contiguous()
+            self.vecs[key + ".b"] = torch.cat([sd[k].detach().reshape(-1) for k in bkeys]).to(self.dev, torch.float32).contiguous()
+        return {key + ".w": self.mats[key + ".w"], key + ".b": self.vecs[key + ".b"]}
+
     def one(self, n: int) -> Tensor:
         t = self.ones.get(n)
         if t is None:
@@ -243,10 +252,8 @@ def siglip_image_features_hip(sd: SD, pixels: Tensor, dtype: torch.dtype = torch
     for i in range(depth):
         l = f"{p}encoder.layers.{i}"
         h = E.ln(x, sd, l + ".layer_norm1", eps)
-        sh = lambda t: t.view(B, N, heads, hd).permute(0, 2, 1, 3)
-        q = sh(E.linear(h, sd, l + ".self_attn.q_proj.weight", l + ".self_attn.q_proj.bias"))
-        k = sh(E.linear(h, sd, l + ".self_attn.k_proj.weight", l + ".self_attn.k_proj.bias"))
-        v = sh(E.linear(h, sd, l + ".self_attn.v_proj.weight", l + ".self_attn.v_proj.bias"))
+        fq = E.fused(sd, l + ".self_attn.qkv#", [l + f".self_attn.{n}_proj.weight" for n in "qkv"], [l + f".self_attn.{n}_proj.bias" for n in "qkv"])
+        q, k, v = _split_heads(E.linear(h, fq, l + ".self_attn.qkv#.w", l + ".self_attn.qkv#.b"), B, N)      # one [B*N, 3*D] projection
         att = E.attention(q, k, v).reshape(B * N, D)
         E.linear_residual(x, att, sd, l + ".self_attn.out_proj.weight", l + ".self_attn.out_proj.bias")
         hid = E.linear(E.ln(x, sd, l + ".layer_norm2", eps), sd, l + ".mlp.fc1.weight", l + ".mlp.fc1.bias", act="gelu_tanh")
@@ -297,10 +304,9 @@ def clap_text_hidden_hip(sd: SD, input_ids: Tensor, attention_mask: Tensor, dtyp
     for i in range(depth):
         l = f"{p}encoder.layer.{i}"
         xT = x.to(E.dtype)
-        sh = lambda t: t.view(B, T, heads, hd).permute(0, 2, 1, 3)
-        q = sh(E.linear(xT, sd, l + ".attention.self.query.weight", l + ".attention.self.query.bias"))
-        k = sh(E.linear(xT, sd, l + ".attention.self.key.weight", l + ".attention.self.key.bias"))
-        v = sh(E.linear(xT, sd, l + ".attention.self.value.weight", l + ".attention.self.value.bias"))
+        a_ = l + ".attention.self."
+        fq = E.fused(sd, a_ + "qkv#", [a_ + n + ".weight" for n in ("query", "key", "value")], [a_ + n + ".bias" for n in ("query", "key", "value")])
+        q, k, v = _split_heads(E.linear(xT, fq, a_ + "qkv#.w", a_ + "qkv#.b"), B, T)
         att = torch.cat([E.attention(q[b:b + 1], k[b:b + 1, :, :lens_h[b]], v[b:b + 1, :, :lens_h[b]]) for b in range(B)])
         E.linear_residual(x, att.reshape(B * T, D), sd, l + ".attention.output.dense.weight", l + ".attention.output.dense.bias")
         y = E.ln(x, sd, l + ".attention.output.LayerNorm", eps, out_dtype=torch.float32)
