@@ -15,7 +15,7 @@ Configurations (BASELINE.json `configs`):
 
 The default line (c2, bs=1/GPU at every N, so that the driver's per-N values are one scaling curve) also carries, as
 `extra`: bs8 (the bs=8/GPU half of the metric), c4 (V2A features, bs=8/GPU - at N=8 the C4 workload), progress (the
-per-iteration host callback path ComfyUI's progress bar takes) and, at N=1, c3 and c5 - two timed passes each.
+per-iteration host callback path ComfyUI's progress bar takes) and, at N=1, c3 and c5 - three timed passes each (four for the bs=8 lines).
 
 Multi-GPU: `python bench.py --gpus N` SPAWNS its own N ranks (one process per GPU, RCCL) when it
 is not already running under a launcher; under `torch.distributed.run` (RANK / WORLD_SIZE set) it
@@ -446,7 +446,7 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
     # ---- the bs=8-per-GPU half of the BASELINE metric, same JSON line
     extra = {}
     if not a.no_extra and a.bs is None and a.config == "c2" and not a.progress:
-        def extra_line(bs, dur, workload, passes=2, **kw):
+        def extra_line(bs, dur, workload, passes=3, **kw):
             """`passes` timed passes (1 warm-up) of another configuration of the same path; clips sharded like the main line."""
             la_x = int(dur * cfg.frame_rate)
             gx = torch.Generator("cpu").manual_seed(1234)
