@@ -37,6 +37,7 @@ SD = Dict[str, Tensor]
 
 SYNC_SEGMENT, SYNC_STRIDE = 16, 8          # feature_utils.py:91-93
 FPS_SIGLIP, FPS_SYNC = 8, 25
+_CHUNK_BYTES = 256 << 20                   # select_frames: float32 frames converted per contiguous slab of at most this size
 
 
 # ----------------------------------------------------------------------------- frame selection
@@ -54,11 +55,29 @@ def select_frames(image: Tensor, duration: float, frame_rate: float, device=None
     i8 = torch.linspace(0, n - 1, int(duration * FPS_SIGLIP)).long().clamp_(max=total - 1)
     i25 = torch.linspace(0, n - 1, int(duration * FPS_SYNC)).long().clamp_(max=total - 1)
     lo, hi = int(min(i8.min(), i25.min())), int(max(i8.max(), i25.max()))
-    block = image[lo:hi + 1]                       # a view: ONE contiguous host-to-device copy, no gather on the CPU
-    if device is not None:
-        block = block.to(device)
-    frames = (block * 255.0).byte().permute(0, 3, 1, 2)
-    return frames.index_select(0, (i8 - lo).to(frames.device)), frames.index_select(0, (i25 - lo).to(frames.device))
+    # float32 frames are 12 bytes per pixel (25 MB at 1080p): the span is converted in bounded chunks - a contiguous slab of at
+    # most ~256 MB goes to the device, is multiplied and cast there, and only the uint8 frames somebody selected are kept, so a
+    # 30 s / 1080p clip needs megabytes next to the model instead of 20 GB.  `.to(torch.int32).to(torch.uint8)` wraps out-of-range
+    # values like the reference's CPU `.byte()` does (a direct float -> uint8 cast saturates on the GPU).
+    want = torch.unique(torch.cat((i8, i25)))
+    per_frame = max(1, image[0].numel() * image.element_size())
+    chunk = max(1, _CHUNK_BYTES // per_frame)
+    kept, pos = [], {}
+    for c0 in range(lo, hi + 1, chunk):
+        c1 = min(hi + 1, c0 + chunk)
+        sel = want[(want >= c0) & (want < c1)]
+        if sel.numel() == 0:
+            continue
+        block = image[c0:c1]                       # a view: one contiguous host-to-device copy per chunk, no gather on the CPU
+        if device is not None:
+            block = block.to(device)
+        u8 = (block * 255.0).to(torch.int32).to(torch.uint8) if block.is_cuda else (block * 255.0).byte()
+        for j in sel.tolist():
+            pos[j] = len(pos)
+        kept.append(u8.index_select(0, (sel - c0).to(u8.device)))
+    frames = torch.cat(kept).permute(0, 3, 1, 2)
+    pick = lambda idx: frames.index_select(0, torch.tensor([pos[int(j)] for j in idx.tolist()], device=frames.device))
+    return pick(i8), pick(i25)
 
 
 # ----------------------------------------------------------------------------- pre-processing
@@ -279,10 +298,7 @@ def encode_text_feat(tokenizer, model, prompts, device) -> Tensor:
     inputs = tokenizer(prompts, padding=True, return_tensors="pt").to(device)
     if torch.device(device).type == "cuda":
         from . import encoders_hip as EH
-        cur = getattr(model, "_foley_text_sd", None)
-        if cur is None or next(iter(cur.values())).device != torch.device(device):
-            model._foley_text_sd = cur = {k: v.detach().to(device) for k, v in model.state_dict().items()
-                                          if k.startswith("text_model.") and v.is_floating_point()}
+        cur = _cached_state(model, "_foley_text_sd", device, lambda k, v: k.startswith("text_model.") and v.is_floating_point())
         cfgm = model.config
         out = EH.clap_text_hidden_hip(cur, inputs["input_ids"], inputs["attention_mask"], next(model.parameters()).dtype,
                                       heads=cfgm.num_attention_heads, eps=cfgm.layer_norm_eps, pad_id=cfgm.pad_token_id)
@@ -338,9 +354,35 @@ def video_features(frames_8fps: Tensor, frames_25fps: Tensor, siglip2_model, syn
 def _siglip_state(model, device) -> SD:
     """State dict of the HF SigLIP model's vision tower on `device`, cached on the module (the engine stages its own
     compute-dtype copies of the matrices once per state dict object)."""
-    cur = getattr(model, "_foley_vision_sd", None)
-    if cur is None or next(iter(cur.values())).device != torch.device(device):
-        sd = {k: v.detach().to(device) for k, v in model.state_dict().items()
-              if k.startswith("vision_model.") or k.startswith(("embeddings.", "encoder.", "post_layernorm.", "head."))}
-        model._foley_vision_sd = cur = sd
-    return cur
+    return _cached_state(model, "_foley_vision_sd", device,
+                         lambda k, v: k.startswith("vision_model.") or k.startswith(("embeddings.", "encoder.", "post_layernorm.", "head.")))
+
+
+def _weights_signature(model):
+    """Cheap identity of a module's current weights: storage address and in-place version counter of every parameter - changes
+    when the weights are reloaded, moved (ComfyUI off-loading) or modified in place."""
+    return tuple((p.data_ptr(), p._version, str(p.device)) for p in model.parameters())
+
+
+def _cached_state(model, attr: str, device, keep) -> SD:
+    """Device copy of the part of an HF module's state dict an engine encoder reads, cached ON the module together with the
+    signature of the weights it was taken from: reloaded / moved / edited weights invalidate it (and, through the new dict
+    object, the engine's staged matrices - host/encoders_hip.py keys them on the dict).  `release_encoder_caches` drops it."""
+    cur = getattr(model, attr, None)
+    sig = _weights_signature(model)
+    if cur is None or cur[0] != sig or cur[1] != torch.device(device):
+        sd = {k: v.detach().to(device) for k, v in model.state_dict().items() if keep(k, v)}
+        cur = (sig, torch.device(device), sd)
+        setattr(model, attr, cur)
+    return cur[2]
+
+
+def release_encoder_caches(*models) -> None:
+    """Drop the device copies of the encoders' state dicts cached on `models` (all of them: pass the HF modules the loader
+    holds) and every matrix the HIP engine staged from them - call it when the dependencies are unloaded."""
+    from . import encoders_hip as EH
+    for m in models:
+        for attr in ("_foley_text_sd", "_foley_vision_sd"):
+            if hasattr(m, attr):
+                delattr(m, attr)
+    EH._ENGINES.clear()

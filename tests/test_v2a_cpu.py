@@ -79,6 +79,15 @@ def test_frame_selection_equals_whole_clip_conversion():
         r25 = frames.index_select(0, torch.linspace(0, n - 1, int(dur * 25)).long())
         f8, f25 = E.select_frames(img, dur, fps)
         assert torch.equal(f8, r8) and torch.equal(f25, r25), (total, dur, fps)
+        # the span is converted in bounded slabs (float32 frames are 12 bytes per pixel): any slab size gives the same frames
+        saved = E._CHUNK_BYTES
+        try:
+            for cb in (1, 3 * img[0].numel() * 4, 7 * img[0].numel() * 4):
+                E._CHUNK_BYTES = cb
+                c8, c25 = E.select_frames(img, dur, fps)
+                assert torch.equal(c8, r8) and torch.equal(c25, r25), (total, dur, fps, cb)
+        finally:
+            E._CHUNK_BYTES = saved
 
 
 def test_preprocess_pipelines():
@@ -142,3 +151,22 @@ def test_video_features_shapes_and_text(monkeypatch):
     assert torch.equal(text["text_feat"], res[1:]) and torch.equal(text["uncond_text_feat"], res[:1])
     # feature lengths for the 5 s headline clip follow the same rule: [1,40,768] / [1,112,768]
     assert C.lengths(5.0)[1:] == (40, 8 * ((125 - E.SYNC_SEGMENT) // E.SYNC_STRIDE + 1)) == (40, 112)
+
+
+def test_encoder_state_cache_follows_the_weights():
+    """The device copy of an HF encoder's state dict (what the HIP engine stages its matrices from) is cached on the module
+    with a signature of the weights it was taken from: same weights -> same dict object (the engine keeps its staged
+    matrices), weights edited in place or replaced -> a fresh copy, `release_encoder_caches` drops it."""
+    m = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.LayerNorm(3))
+    keep = lambda k, v: v.is_floating_point()
+    a = E._cached_state(m, "_foley_text_sd", "cpu", keep)
+    assert E._cached_state(m, "_foley_text_sd", "cpu", keep) is a and torch.equal(a["0.weight"], m[0].weight)
+    with torch.no_grad():
+        m[0].weight.add_(1.0)                                  # in-place edit: version counter moves
+    b = E._cached_state(m, "_foley_text_sd", "cpu", keep)
+    assert b is not a and torch.equal(b["0.weight"], m[0].weight)
+    m[0].weight = torch.nn.Parameter(torch.zeros(3, 4))        # reloaded weights: new storage
+    c = E._cached_state(m, "_foley_text_sd", "cpu", keep)
+    assert c is not b and float(c["0.weight"].abs().sum()) == 0.0
+    E.release_encoder_caches(m)
+    assert not hasattr(m, "_foley_text_sd")
