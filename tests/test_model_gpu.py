@@ -499,6 +499,45 @@ def test_c5_full_size_against_reference_fixture(dev, depth):
     assert 1e-2 < d0 < 1e-1 and e8 < 1.5 * d0 and e32 < 1.5 * d0
 
 
+@pytest.mark.parametrize("name,hidden,heads", [("xxl-1-1", 1536, 12), ("xl-1-1", 1408, 11)])
+@pytest.mark.parametrize("dtype,fmt", [(torch.bfloat16, "none"), (torch.float16, "none"), (torch.bfloat16, "fp8_e4m3fn"), (torch.float16, "fp8_e5m2")])
+def test_large_grid_tiles_against_the_oracle(dev, name, hidden, heads, dtype, fmt):
+    """The large-grid GEMM tiles INSIDE the model (256x256 BK = 32 tiles for w1/w3, the 256-row tiles with the second barrier,
+    256x256 split-K tiles at mid-size grids) in every operand / storage combination, at both model widths (D = 1408: a ragged
+    last column tile and 44 chunks of 32 channels): one depth-1+1 forward of a CFG pair x 8 clips at 5 s (M = 4000) and of a CFG
+    pair at 30 s (M = 3000), each against the fp32 oracle on the same (storage-rounded) weights."""
+    from foley_amd import nodes
+    c = C.DiTConfig(name=name, depth_triple=1, depth_single=1, hidden=hidden, heads=heads)
+    sd = synth.synth_dit_state_dict(c)
+    prec = "bf16" if dtype == torch.bfloat16 else "fp16"
+    model = nodes.HunyuanModelLoader.pack_state_dict(sd, prec, fmt, device=dev, cfg=c)
+    sdq = nodes.fp8_round_state_dict(nodes.round_params(sd, dtype), fmt, autocast=True, param_dtype=dtype) if fmt != "none" else nodes.round_params(sd, dtype)
+    sdq = {k: v.float() for k, v in sdq.items()}
+    tol = (5e-3 if dtype == torch.bfloat16 else 8e-4) if fmt == "none" else 8e-3      # measured 1.8e-3 / 2.2e-4 / 2.2 - 2.8e-3
+    for dur, clips in ((5.0, 8), (30.0, 1)):
+        La, Lv, Ls = C.lengths(dur, c)
+        cond = synth.synth_conditioning(c, dur, t2a=False, sd=sd)
+        x = torch.randn(clips, 128, La, generator=torch.Generator().manual_seed(41)).to(dtype).float()
+        steps, it = 10, 4
+        vis = {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]}
+        txt = {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]}
+        model.ctx.prepare(sampler.build_plan(model, vis, txt, La, 4.5, steps, clips, "euler"))
+        rows = model.ctx.dit_forward(x.to(dev).contiguous(), it).float().cpu()          # [(cfg, clip, l), 128]
+        t_it = tables.model_timesteps(tables.sigma_grid(steps))[it]
+        text77, unc77 = O.pad_or_trim_text(cond["text"]), O.pad_or_trim_text(cond["uncond_text"])
+        e_clip = sd["empty_clip_feat"].view(1, 1, -1).expand(1, Lv, -1)
+        e_sync = sd["empty_sync_feat"].view(1, 1, -1).expand(1, Ls, -1)
+        sel = [0, clips - 1] if clips > 1 else [0]                                       # first and last clip of the batch
+        with torch.inference_mode():
+            for b in sel:
+                ref = O.dit_forward(sdq, c.heads, torch.cat([x[b:b + 1], x[b:b + 1]]), t_it.expand(2), torch.cat([unc77, text77]),
+                                    torch.cat([e_clip, cond["clip"]]), torch.cat([e_sync, cond["sync"]]))
+                got = torch.stack([rows.view(2, clips, La, 128)[0, b], rows.view(2, clips, La, 128)[1, b]]).transpose(1, 2)
+                e = rel_err(got, ref)
+                print("%s %s/%s %gs clip %d: %.2e" % (name, prec, fmt, dur, b, e))
+                assert e < tol, (name, prec, fmt, dur, b, e)
+
+
 def test_xl_dimensions_forward(dev):
     """The xl model family (D=1408, 11 heads: N/K not multiples of 128/256) at depth 1+1 against the
     oracle - exercises the N-edge masking of every GEMM tile and the 11-head split."""
