@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64) void attn_kernel(const AttnArgs a) {
       s[e] = (key < a.Skv) ? s[e] * scale : -INFINITY;
       mx = fmaxf(mx, s[e]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = xhalf_max(mx);
     const float m_new = fmaxf(m_run, mx);     // finite: every tile holds at least one valid key
     const float alpha = expf(m_run - m_new);  // exp(-inf) = 0 on the first tile
     float ps = 0.f;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64) void attn_kernel(const AttnArgs a) {
       s[e] = expf(s[e] - m_new);
       ps += s[e];
     }
-    ps += __shfl_xor(ps, 32, 64);
+    ps = xhalf_sum(ps);
     l_run = l_run * alpha + ps;
     m_run = m_new;
 #pragma unroll
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
       s[e] = (kt + 16 * kh + e < a.Skv) ? s[e] * scale2 : -INFINITY;
       mx = fmaxf(mx, s[e]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = xhalf_max(mx);
     const float m_new = fmaxf(m_run, mx);
     float ps = 0.f;
     bf16x8 pb[2];
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnArgs a) {
       ps += pv;
       pb[e >> 3][e & 7] = to_carrier<T>(pv);
     }
-    ps += __shfl_xor(ps, 32, 64);
+    ps = xhalf_sum(ps);
     // the 64 accumulator rescales only when some query's running maximum moved (rare after the first tiles)
     if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // exp2(-inf) = 0 on the first tile
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void attn_lds_kernel(const AttnArgs a, const i
       s[e] = (kt + 16 * kh + e < a.Skv) ? s[e] * scale2 : -INFINITY;
       mx = fmaxf(mx, s[e]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = xhalf_max(mx);
     const float m_new = fmaxf(m_run, mx);
     float ps = 0.f;
     bf16x8 pb[2];
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256) void attn_lds_kernel(const AttnArgs a, const i
       ps += pv;
       pb[e >> 3][e & 7] = to_carrier<T>(pv);
     }
-    ps += __shfl_xor(ps, 32, 64);
+    ps = xhalf_sum(ps);
     // the 64 accumulator rescales only when some query's running maximum moved (rare after the first tiles)
     if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // exp2(-inf) = 0 on the first tile
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[e]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = xhalf_max(mx);
     const float m_new = fmaxf(m_run, mx * scale2);
     float ps = 0.f;
     bf16x8 pb[2];
@@ -681,7 +681,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       ps += pv;
       pb[e >> 3][e & 7] = to_carrier<T>(pv);
     }
-    ps += __shfl_xor(ps, 32, 64);
+    ps = xhalf_sum(ps);
     // the 64 accumulator rescales only when some query's running maximum moved (rare after the first tiles)
     if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // exp2(-inf) = 0 on the first tile
@@ -748,15 +748,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // A split-KV form on top of it (two workgroups per query tile, each half of the keys, partial softmax states merged by the
 // second arriver through a workspace record with an agent-scope release / acquire hand-off) was built, correct, and SLOWER
 // (91 vs 72 us): at 208 registers and 70 KiB only two workgroups fit a CU, so its 672 workgroups run in 1.3 rounds.
-__device__ __forceinline__ float xhalf_max(float v) {   // max over the lane pair (l, l ^ 32)
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float xhalf_sum(float v) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
 template <typename T, typename OutT>
 __global__ __launch_bounds__(256, 2) void attn_bf16_long_kernel(const AttnArgs a) {   // two waves per SIMD (<= 256 registers): left alone the compiler takes 194 + 96 AGPRs = one workgroup per CU
   constexpr int HD = 128, KT = 64;

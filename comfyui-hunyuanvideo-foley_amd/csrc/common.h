@@ -117,6 +117,18 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// Exchange between the lane pair (l, l ^ 32) - the two key halves of a 32x32 score tile's column - as ONE v_permlane32_swap
+// (VALU) instead of the ds_bpermute round trip through the LDS crossbar that __shfl_xor(v, 32) compiles to.  Bit-identical
+// to `op(v, __shfl_xor(v, 32))`: max and a two-operand add commute.
+__device__ __forceinline__ float xhalf_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // Sum over the 64 lanes, result in every lane: the four row sums meet through two DPP row broadcasts (lane 15 of a
 // row into the next row, lane 31 into the upper half) and one v_readlane - no ds_bpermute round trips through the LDS.
 __device__ __forceinline__ float wave_sum(float v) {

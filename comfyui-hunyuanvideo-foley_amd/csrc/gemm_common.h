@@ -666,7 +666,7 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&ac
                 sc[e] = (kt + 16 * kh + e < Skv) ? sc[e] * scale2 : -INFINITY;
                 mx = fmaxf(mx, sc[e]);
               }
-              mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+              mx = xhalf_max(mx);
               const float m_new = fmaxf(m_run, mx);
               float ps = 0.f;
               bf16x8 pb[2];
@@ -676,7 +676,7 @@ __device__ __forceinline__ void gemm_epilogue_qkv(const GemmArgs& g, f32x16 (&ac
                 ps += pv;
                 pb[e >> 3][e & 7] = to_carrier<T>(pv);
               }
-              ps += __shfl_xor(ps, 32, 64);
+              ps = xhalf_sum(ps);
               // the 64 accumulator rescales only when some query's running maximum moved (never on the first tile: o = 0)
               if (kt > 0 && __builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
