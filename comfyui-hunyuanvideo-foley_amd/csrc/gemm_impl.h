@@ -768,6 +768,7 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     if (g1) ok = extent(g1s) && ok;
     if (!ok && g.wfmt) return foley_set_err("GEMM: fp8-weight operands exceed the 2 GiB buffer-offset range", __FILE__, __LINE__);
     if (!ok && (tile == 21 || tile == 22 || tile == 23)) return foley_set_err("GEMM: conv3 operands exceed the 2 GiB buffer-offset range", __FILE__, __LINE__);
+    if (!ok && (tile == 31 || tile == 32)) return foley_set_err("GEMM: the 256x256 tiles range every load against 32-bit buffer extents: operands exceed the 2 GiB buffer-offset range", __FILE__, __LINE__);
     if (!ok && ((tile >= 5 && tile <= 9) || tile == 15 || tile == 19 || tile == 25 || tile == 26 || tile == 27 || tile == 28 || tile == 29)) tile = (tile == 6) ? 3 : ((tile == 8 || tile == 27) ? 2 : 1);   // register-staged twins
   }
   g.vec_out = gemm_vec_out_ok<T>(g, epi) ? 1 : 0;

@@ -114,9 +114,9 @@ class _Engine:
         return out
 
 
-def _split_heads(qkv: Tensor, B: int, N: int):
+def _split_heads(qkv: Tensor, B: int, N: int, heads: int = HEADS):
     """[B*N, 3*H*64] -> q, k, v views [B, H, N, 64] (the '(K H D)' packing of nn.Linear(dim, 3*dim) / in_proj_weight)."""
-    t = qkv.view(B, N, 3, HEADS, HD).permute(2, 0, 3, 1, 4)
+    t = qkv.view(B, N, 3, heads, HD).permute(2, 0, 3, 1, 4)
     return t[0], t[1], t[2]
 
 
@@ -253,7 +253,7 @@ def siglip_image_features_hip(sd: SD, pixels: Tensor, dtype: torch.dtype = torch
         l = f"{p}encoder.layers.{i}"
         h = E.ln(x, sd, l + ".layer_norm1", eps)
         fq = E.fused(sd, l + ".self_attn.qkv#", [l + f".self_attn.{n}_proj.weight" for n in "qkv"], [l + f".self_attn.{n}_proj.bias" for n in "qkv"])
-        q, k, v = _split_heads(E.linear(h, fq, l + ".self_attn.qkv#.w", l + ".self_attn.qkv#.b"), B, N)      # one [B*N, 3*D] projection
+        q, k, v = _split_heads(E.linear(h, fq, l + ".self_attn.qkv#.w", l + ".self_attn.qkv#.b"), B, N, heads)      # one [B*N, 3*D] projection
         att = E.attention(q, k, v).reshape(B * N, D)
         E.linear_residual(x, att, sd, l + ".self_attn.out_proj.weight", l + ".self_attn.out_proj.bias")
         hid = E.linear(E.ln(x, sd, l + ".layer_norm2", eps), sd, l + ".mlp.fc1.weight", l + ".mlp.fc1.bias", act="gelu_tanh")
@@ -306,7 +306,7 @@ def clap_text_hidden_hip(sd: SD, input_ids: Tensor, attention_mask: Tensor, dtyp
         xT = x.to(E.dtype)
         a_ = l + ".attention.self."
         fq = E.fused(sd, a_ + "qkv#", [a_ + n + ".weight" for n in ("query", "key", "value")], [a_ + n + ".bias" for n in ("query", "key", "value")])
-        q, k, v = _split_heads(E.linear(xT, fq, a_ + "qkv#.w", a_ + "qkv#.b"), B, T)
+        q, k, v = _split_heads(E.linear(xT, fq, a_ + "qkv#.w", a_ + "qkv#.b"), B, T, heads)
         att = torch.cat([E.attention(q[b:b + 1], k[b:b + 1, :, :lens_h[b]], v[b:b + 1, :, :lens_h[b]]) for b in range(B)])
         E.linear_residual(x, att.reshape(B * T, D), sd, l + ".attention.output.dense.weight", l + ".attention.output.dense.bias")
         y = E.ln(x, sd, l + ".attention.output.LayerNorm", eps, out_dtype=torch.float32)

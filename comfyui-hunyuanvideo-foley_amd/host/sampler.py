@@ -190,7 +190,8 @@ def denoise_process_with_generator(visual_feats, text_feats, audio_len_in_s, mod
                                    guidance_scale: float, num_inference_steps: int, batch_size: int, sampler: str,
                                    generator: Optional[torch.Generator] = None, use_graph: bool = True,
                                    progress: Optional[Callable[[int, int], None]] = None,
-                                   return_latents: bool = False, noise: Optional[torch.Tensor] = None):
+                                   return_latents: bool = False, noise: Optional[torch.Tensor] = None,
+                                   _abort_event: Optional[threading.Event] = None):
     """Same contract as the reference function of this name (utils.py:125-258):
     returns (audio [bs, 1, T] fp32 on the model's device, sample_rate)."""
     cfg = model.cfg
@@ -201,6 +202,8 @@ def denoise_process_with_generator(visual_feats, text_feats, audio_len_in_s, mod
     plan = build_plan(model, visual_feats, text_feats, La, guidance_scale, num_inference_steps, batch_size, sampler)
     model.attach_dac(dac)
     model.ctx.prepare(plan)
+    if _abort_event is not None and _abort_event.is_set():      # another replica of a data-parallel run failed meanwhile
+        raise FoleyRuntimeError("sampling aborted: another replica failed")
     model.ctx.sample(latents, use_graph=use_graph, progress=progress)
     audio = model.ctx.dac_decode(latents)
     # (the reference's "trim to exact length" slices the size-1 channel axis: a no-op)
@@ -253,7 +256,19 @@ def replicate(model: FoleyModel, dac: Optional[FoleyDAC], devices: Sequence) -> 
             per_dev = [[model.arena.buffer.view(torch.uint8).reshape(-1)] + ([dac.arena.buffer.view(torch.uint8).reshape(-1)] if dac is not None else [])]
             for d, key in first.items():
                 per_dev.append([bufs[key][0].view(torch.uint8).reshape(-1)] + ([bufs[key][1].view(torch.uint8).reshape(-1)] if dac is not None else []))
-            model.last_broadcast_s = _rt.bcast_local(per_dev)
+            try:
+                model.last_broadcast_s = _rt.bcast_local(per_dev)
+            except FoleyRuntimeError as e:          # no librccl in the process / ncclCommInitAll refused the device list
+                import logging
+                import time as _time
+                logging.getLogger("foley_amd").warning("grouped RCCL broadcast unavailable (%s): falling back to peer copies", e)
+                t0 = _time.perf_counter()
+                for dst in per_dev[1:]:
+                    for s_buf, d_buf in zip(per_dev[0], dst):
+                        d_buf.copy_(s_buf, non_blocking=True)
+                for d in first:
+                    torch.cuda.synchronize(d)
+                model.last_broadcast_s = _time.perf_counter() - t0
         for key, d in pending:                      # further contexts on a device: device-local copies of what is there already
             if first.get(d) == key:
                 continue
@@ -288,6 +303,12 @@ def denoise_process_multi(visual_feats, text_feats, audio_len_in_s, replicas: Se
     m0 = replicas[0][0]
     cfg = m0.cfg
     La = int(audio_len_in_s * cfg.frame_rate)
+    # The sticky text bucket is ONE value per model in the reference (utils.py:166-188): every replica pads this batch to the
+    # same length - the largest bucket any replica has seen so far or this prompt asks for - whichever shards it gets.
+    t_now = min(77 if text_feats["text_feat"].shape[1] <= 77 else 128, cfg.text_len)
+    sticky = max([t_now] + [m._text_len_fixed or 0 for m, _ in replicas])
+    for m, _ in replicas:
+        m._text_len_fixed = sticky
     noise = draw_noise(batch_size, cfg.latent_dim, La, m0.dtype, generator)
     shards = [shard_range(batch_size, r, len(replicas)) for r in range(len(replicas))]
     results: List = [None] * len(replicas)
@@ -302,6 +323,9 @@ def denoise_process_multi(visual_feats, text_feats, audio_len_in_s, replicas: Se
         ev.record(torch.cuda.current_stream(dv))
         ready.append(ev)
 
+    failed = threading.Event()              # set by the first failing worker; the others do not start (or stop at their next iteration)
+    running = [False] * len(replicas)
+
     def work(r):
         lo, hi = shards[r]
         if hi <= lo:
@@ -312,19 +336,30 @@ def denoise_process_multi(visual_feats, text_feats, audio_len_in_s, replicas: Se
             with torch.cuda.device(model.device), torch.cuda.stream(stream):
                 for ev in ready:
                     stream.wait_event(ev)
+                if failed.is_set():
+                    return
+                running[r] = True
                 results[r] = denoise_process_with_generator(
                     visual_feats, text_feats, audio_len_in_s, model, dac, guidance_scale, num_inference_steps, hi - lo,
                     sampler, use_graph=use_graph, noise=noise[lo:hi], return_latents=True,
-                    progress=progress if r == 0 else None)
+                    progress=progress if r == 0 else None, _abort_event=failed)
                 torch.cuda.current_stream().synchronize()
         except Exception as e:          # surfaced on the calling thread
             errors.append(e)
-            for m, _ in replicas:       # an interrupt (or any failure) on one replica stops the others at their next iteration
-                if m is not model:
+            failed.set()                # replicas still in prepare / warm-up see it before their loop starts (foley_sample
+            import time as _time        # clears a stale abort request at entry); the ones inside the loop stop at the next iteration:
+            while True:                 # keep asking until every other worker has left (closes the check-then-clear window)
+                busy = [i for i in range(len(replicas)) if i != r and running[i]]
+                for i in busy:
                     try:
-                        m.ctx.abort()
+                        replicas[i][0].ctx.abort()
                     except Exception:   # noqa: BLE001 - best effort; the first error is the one reported
                         pass
+                if not busy:
+                    break
+                _time.sleep(0.005)
+        finally:
+            running[r] = False
 
     threads = [threading.Thread(target=work, args=(r,), name=f"foley-dp-{r}") for r in range(len(replicas))]
     for t in threads:

@@ -461,8 +461,9 @@ def pad_or_trim_text(x: Tensor, t_fixed: int = 77) -> Tensor:
 def sample_latents(sd: SD, heads: int, noise: Tensor, text: Tensor, uncond_text: Tensor, clip: Tensor,
                    sync: Tensor, steps: int, guidance: float, solver: str = "euler",
                    shift: float = 1.0, text_len: int = 77, trace: Optional[list] = None,
-                   max_iters: Optional[int] = None) -> Tensor:
+                   max_iters: Optional[int] = None, start_iter: int = 0) -> Tensor:
     """The denoising loop of denoise_process_with_generator (utils.py:144-247).
+    `start_iter` > 0 (Euler only) resumes the loop from latents `noise` = the state after that many iterations.
 
     noise [bs,128,La] (already drawn, utils.py:151-156); text/uncond_text [1,T,768];
     clip [1,Lv,768]; sync [1,Ls,768].  CFG batch order is [uncond ; cond]
@@ -484,7 +485,11 @@ def sample_latents(sd: SD, heads: int, noise: Tensor, text: Tensor, uncond_text:
     else:
         clip_in, sync_in, text_in = clip_r, sync_r, text_r
     x = noise.float()
+    assert start_iter == 0 or solver == "euler"
+    st.idx = start_iter
     for i, t in enumerate(ts):
+        if i < start_iter:
+            continue
         if max_iters is not None and i >= max_iters:
             break
         xin = torch.cat([x, x]) if guidance > 1.0 else x

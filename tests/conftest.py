@@ -39,6 +39,23 @@ def rel_err(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
+def record_parity(name, **values):
+    """Append one measured-parity record (errors, the reference's own noise floor d0, their ratio) to
+    gpurun_out/parity_records.json (or $FOLEY_PARITY_JSON): the gates are inequalities, the records make movements INSIDE a
+    gate visible from round to round (copied to profiles/rNN_parity.json)."""
+    import json
+    path = os.environ.get("FOLEY_PARITY_JSON") or os.path.join(ROOT, "gpurun_out", "parity_records.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    try:
+        with open(path) as f:
+            recs = json.load(f)
+    except (OSError, ValueError):
+        recs = {}
+    recs[name] = {k: (float(v) if isinstance(v, (int, float)) else v) for k, v in values.items()}
+    with open(path, "w") as f:
+        json.dump(recs, f, indent=1, sort_keys=True)
+
+
 @pytest.fixture(scope="session")
 def dev():
     return torch.device("cuda:0")

@@ -18,6 +18,9 @@ Fixtures:
   g6_c1_xxl      config C1 at real xxl dims: 1 s, 10 Euler steps, CFG off, bs 1 (the 1e-3 gate)
   g7_sampler     tiny sampler: CFG 4.5 bs 2 Euler + the three multi-stage solvers
   g9_dac         full-width DAC decoder on [1,128,10]
+  g10 - g16      DAC encoder, V2A conditioning, bf16 / fp16 reference runs, full-size single forwards (see each function)
+  g17_c2_loop / g18_c2_bf16_loop   the HEADLINE run (xxl, 5 s, 50 Euler iterations, CFG 4.5) through the reference's own
+                 sampler loop + DAC decoder: fp32 (the 1e-3 waveform gate) and as the reference runs a bf16 model (~15 min)
 """
 from __future__ import annotations
 
@@ -695,7 +698,7 @@ def g14():
     The 16-bit runs draw their noise in the model dtype like the reference does; the fp32 runs take that
     noise.  Stored: y (every 2nd / 16th frame of both CFG halves; the 16-bit outputs as float32 images), the
     input noise is re-drawn by the tests from the same seed and verified against `x_sum`."""
-    if _FULL:
+    if "done" in _FULL:
         return
     _FULL["done"] = True
     it, steps, g = 25, 50, 4.5
@@ -760,7 +763,96 @@ def g14():
     save("g16_c5_full", **o16)
 
 
-ALL = {"g14": g14, "g15": g14, "g16": g14, "g13": g13, "g12": g12, "g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11}
+# ----------------------------------------------------------------------------- G17 / G18
+def _traced_ref_sampler(md, c, cond, dur, g, steps, gen, noise=None):
+    """The reference's denoise_process_with_generator (utils.py:125-258) with a spy on the scheduler step
+    (scheduling_flow_match_discrete.py:262-297) that keeps the latents after EVERY iteration, and a spy on
+    prepare_latents_with_generator (utils.py:111-121) that records (or overrides) the drawn noise."""
+    trace, drawn = [], {}
+    orig_step = NS.sched.FlowMatchDiscreteScheduler.step
+    orig_prep = NS.utils.prepare_latents_with_generator
+
+    def step_spy(self, *a, **k):
+        r = orig_step(self, *a, **k)
+        trace.append(r[0].float().clone())
+        if len(trace) % 10 == 0:
+            print(f"      iteration {len(trace)}", flush=True)
+        return r
+
+    def prep_spy(*a, **k):
+        drawn["noise"] = (noise.clone() if noise is not None else orig_prep(*a, **k))
+        return drawn["noise"].clone()
+    NS.sched.FlowMatchDiscreteScheduler.step = step_spy
+    NS.utils.prepare_latents_with_generator = prep_spy
+    if hasattr(md.foley_model, "_text_len_fixed"):
+        del md.foley_model._text_len_fixed
+    t0 = time.time()
+    try:
+        with torch.inference_mode():
+            audio, sr = NS.utils.denoise_process_with_generator(
+                {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]},
+                {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]},
+                dur, md, ref_cfg(c), g, steps, 1, "euler", generator=gen)
+    finally:
+        NS.sched.FlowMatchDiscreteScheduler.step = orig_step
+        NS.utils.prepare_latents_with_generator = orig_prep
+    assert sr == 48000 and len(trace) == steps
+    return audio.float(), torch.stack(trace), drawn["noise"], time.time() - t0
+
+
+G17_CHECKPOINTS = (1, 10, 25, 40, 50)
+
+
+def g17():
+    """G17 / G18 - north_star's gate AT THE HEADLINE CONFIGURATION (round-5 verdict item 1): the reference's own
+    sampler loop, full xxl model (18 + 36 blocks), C2 = text-to-audio 5 s, 50 Euler iterations, CFG 4.5, bs 1,
+    seed 1234, through its DAC decoder (utils.py:125-258, scheduling_flow_match_discrete.py:210-297,
+    dac_vae/model/dac.py:280-303).
+      g17  fp32 parameters: the drawn noise, the latents after iterations {1, 10, 25, 40, 50}, the norm of the
+           latents after every iteration, the 48 kHz waveform (every 5th sample).
+      g18  the loop as the reference runs a bf16 model (parameters .to(bfloat16), autocast, noise drawn in
+           bf16): final latents + waveform; next to it the fp32 model on THAT noise, so that
+           d0 = |bf16 run - fp32 run| / |fp32 run| is the reference's own 50-iteration bf16 drift."""
+    if "loop" in _FULL:          # "g17" and "g18" name the same generator
+        return
+    _FULL["loop"] = True
+    c = C.XXL
+    t0 = time.time()
+    sd = synth.synth_dit_state_dict(c)
+    dsd = synth.synth_dac_state_dict(C.DAC48K)
+    print(f"    synthesised xxl + DAC weights in {time.time() - t0:.0f}s")
+    dac = build_ref_dac(C.DAC48K, dsd)
+    cond = synth.synth_conditioning(c, 5.0, t2a=True, sd=sd)
+    m32 = build_ref_dit(c, sd)
+    md32 = ModelDict(foley_model=m32, dac_model=dac, device=torch.device("cpu"))
+    idx = [i - 1 for i in G17_CHECKPOINTS]
+    # ---- g17: fp32, noise drawn in fp32 from seed 1234
+    audio, trace, noise, secs = _traced_ref_sampler(md32, c, cond, 5.0, 4.5, 50, torch.Generator("cpu").manual_seed(1234))
+    print(f"    reference C2 fp32 loop ran in {secs:.0f}s -> {tuple(audio.shape)}")
+    chk = torch.randn((1, 128, 250), generator=torch.Generator("cpu").manual_seed(1234), dtype=torch.float32)
+    assert torch.equal(chk, noise)
+    save("g17_c2_loop", noise=noise, checkpoints=np.array(G17_CHECKPOINTS), latents=trace[idx],
+         latent_norms=trace.double().flatten(1).norm(dim=1).float(), wave_s5=audio[..., ::5],
+         wave_norm=np.float64(audio.double().norm()), ref_secs=np.float64(secs))
+    # ---- g18: the bf16 loop, then the fp32 model on the bf16-drawn noise
+    m16 = build_ref_dit(c, sd).to(torch.bfloat16)
+    md16 = ModelDict(foley_model=m16, dac_model=dac, device=torch.device("cpu"))
+    a16, tr16, noise16, secs16 = _traced_ref_sampler(md16, c, cond, 5.0, 4.5, 50, torch.Generator("cpu").manual_seed(1234))
+    assert noise16.dtype == torch.bfloat16
+    print(f"    reference C2 bf16 loop ran in {secs16:.0f}s")
+    del m16, md16
+    a32, tr32, _, secs32 = _traced_ref_sampler(md32, c, cond, 5.0, 4.5, 50, torch.Generator("cpu").manual_seed(1234),
+                                               noise=noise16.float())
+    d0_lat = [rel(tr16[i], tr32[i]) for i in idx]
+    d0_wave = rel(a16, a32)
+    print(f"    reference bf16 loop vs its own fp32 loop on the same noise: latents after {G17_CHECKPOINTS} rel "
+          f"{['%.3e' % d for d in d0_lat]}, waveform rel {d0_wave:.3e}")
+    save("g18_c2_bf16_loop", noise_b16=noise16.float(), checkpoints=np.array(G17_CHECKPOINTS),
+         latents_b16=tr16[idx], latents_f32=tr32[idx], wave_b16_s5=a16[..., ::5], wave_f32_s5=a32[..., ::5],
+         d0_latents=np.array(d0_lat), d0_wave=np.float64(d0_wave))
+
+
+ALL = {"g17": g17, "g18": g17, "g14": g14, "g15": g14, "g16": g14, "g13": g13, "g12": g12, "g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11}
 
 
 def main():

@@ -111,6 +111,24 @@ def test_g6_c1_xxl():
     assert rel_err(torch.stack(trace), g["latents"]) < 1e-5 and rel_err(wav, g["waveform"]) < 3e-5
 
 
+@pytest.mark.slow
+def test_g17_c2_loop_tail():
+    """The oracle against the reference's own HEADLINE run (g17: xxl, 5 s, 50 Euler iterations, CFG 4.5): resumed from the
+    reference's latents after iteration 40, the last ten iterations + the DAC decode must reproduce the reference's final
+    latents and waveform (~2 min on 8 cores)."""
+    g = golden("g17_c2_loop")
+    cps = [int(c) for c in g["checkpoints"]]
+    sd = synth.synth_dit_state_dict(C.XXL)
+    cond = synth.synth_conditioning(C.XXL, 5.0, t2a=True, sd=sd)
+    with torch.inference_mode():
+        lat = O.sample_latents(sd, C.XXL.heads, g["latents"][cps.index(40)], cond["text"], cond["uncond_text"], cond["clip"],
+                               cond["sync"], 50, 4.5, start_iter=40)
+        wav = O.dac_decode(synth.synth_dac_state_dict(C.DAC48K), lat)
+    e_lat, e_wav = rel_err(lat, g["latents"][cps.index(50)]), rel_err(wav[..., ::5], g["wave_s5"])
+    print("oracle vs reference, C2 iterations 41-50: latents %.2e, waveform %.2e" % (e_lat, e_wav))
+    assert e_lat < 1e-5 and e_wav < 3e-5
+
+
 def test_g8_fp8_weight_only_semantics():
     """Reference FP8WeightWrapper / _wrap_fp8_inplace (utils.py:316-485): the wrapped set, wrapped
     Linear / channels-last Conv1d forwards, and the TimestepEmbedder-under-autocast quirk."""
