@@ -87,22 +87,71 @@ def kernel_src_sha() -> str:
     return h.hexdigest()[:16]
 
 
-def cpu_baseline(sd_gpu, dsd_gpu, cfg, cond, noise, duration, threads=16):
-    """The CPU oracle (a port of the reference's fp32 CPU path) on this box's host cores, on a
-    bounded sample of the same workload: three DiT forwards of the conditional half (the loop does
-    2 x 50 of them per clip) + the DAC decode, extrapolated.  Thread count is capped: the torch
-    CPU kernels stop scaling (and thrash) far below this box's 256 hardware threads."""
+def physical_cores() -> int:
+    """Physical cores this process may run on (distinct (package, core) pairs of /proc/cpuinfo within the affinity mask)."""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except Exception:
+        allowed = set(range(os.cpu_count() or 1))
+    try:
+        cores, cpu, phys = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "processor":
+                cpu, phys = int(v), None
+            elif k == "physical id":
+                phys = int(v)
+            elif k == "core id" and cpu in allowed:
+                cores.add((phys, int(v)))
+        if cores:
+            return len(cores)
+    except Exception:
+        pass
+    return max(1, len(allowed))
+
+
+def cpu_baseline(sd_gpu, dsd_gpu, cfg, cond, noise, duration, threads=16, budget_s=75.0):
+    """The CPU oracle (a port of the reference's fp32 CPU path) on this box's host cores, per BASELINE.md section 4:
+      * BASELINE configs[0] (C1: text-to-audio 1 s, 10 Euler iterations, CFG off + DAC decode) run IN FULL, 3 repeats,
+        median - at `threads` (16: where the torch CPU kernels stop scaling on these hosts) and once at threads =
+        physical cores (repeats cut to what the time budget allows; both stated);
+      * the metric's own configuration (C2): three DiT forwards of the CFG pair's conditional half + the DAC decode of the
+        same clip, extrapolated to the 2 x 50 forwards of a clip - at the better of the two thread counts.
+    `value` is the C2 figure (the metric's configuration); a reported baseline only."""
     from oracle import foley_oracle as O
     try:
         avail = len(os.sched_getaffinity(0))
     except Exception:
         avail = os.cpu_count() or 1
-    cores = max(1, min(threads, avail))
-    torch.set_num_threads(cores)
+    phys = physical_cores()
+    t_begin = time.perf_counter()
     sd = {k: v.float().cpu() for k, v in sd_gpu.items()}
     dsd = {k: v.float().cpu() for k, v in dsd_gpu.items()}
     cc = {k: v.float().cpu() for k, v in cond.items()}
     x = noise[:1].float().cpu()
+    # C1: its own conditioning (1 s: Lv 8, Ls 16) and noise, like golden g6
+    c1 = synth.synth_conditioning(cfg, 1.0, t2a=True, sd=sd)
+    n1 = torch.randn((1, cfg.latent_dim, int(cfg.frame_rate)), generator=torch.Generator("cpu").manual_seed(1234))
+
+    def c1_pass():
+        t0 = time.perf_counter()
+        with torch.inference_mode():
+            lat = O.sample_latents(sd, cfg.heads, n1, c1["text"], c1["uncond_text"], c1["clip"], c1["sync"], 10, 1.0)
+            O.dac_decode(dsd, lat)
+        return time.perf_counter() - t0
+
+    c1_runs = {}
+    for nthreads in dict.fromkeys([max(1, min(threads, avail)), max(1, min(phys, avail))]):
+        torch.set_num_threads(nthreads)
+        times = [c1_pass()]
+        while len(times) < 3 and (time.perf_counter() - t_begin) + times[0] < budget_s * (0.45 if nthreads != phys else 0.8):
+            times.append(c1_pass())
+        times.sort()
+        c1_runs[nthreads] = {"threads": nthreads, "repeats": len(times), "median_s": round(times[len(times) // 2], 3),
+                             "audio_sec_per_sec": round(1.0 / times[len(times) // 2], 4)}
+    best = min(c1_runs.values(), key=lambda r: r["median_s"])["threads"]
+    torch.set_num_threads(best)
     n_fwd = STEPS_PER_CLIP * 2
     n_sample = 3
     with torch.inference_mode():
@@ -115,9 +164,13 @@ def cpu_baseline(sd_gpu, dsd_gpu, cfg, cond, noise, duration, threads=16):
         O.dac_decode(dsd, x - v)
         t_dec = time.perf_counter() - t0
     t_clip = n_fwd * t_fwd + t_dec
-    return {"value": duration / t_clip, "unit": "audio-sec/sec", "cores": cores, "kind": "port",
-            "sample": f"{n_sample} of {n_fwd} DiT forwards ({t_fwd:.2f}s each, fp32 torch-CPU oracle, {cores} threads of "
-                      f"{avail} available) + the DAC decode ({t_dec:.2f}s) of the same {duration:g} s clip, extrapolated"}
+    return {"value": duration / t_clip, "unit": "audio-sec/sec", "cores": best, "kind": "port",
+            "physical_cores": phys, "hardware_threads": avail,
+            "c1_full": {"workload": "BASELINE configs[0]: T2A 1 s, 10 Euler iterations, CFG off, fp32, bs 1, incl. DAC decode, run in full",
+                        "runs": list(c1_runs.values())},
+            "sample": f"{n_sample} of {n_fwd} DiT forwards ({t_fwd:.2f}s each, fp32 torch-CPU oracle, {best} threads; {phys} physical cores / "
+                      f"{avail} hardware threads available) + the DAC decode ({t_dec:.2f}s) of the same {duration:g} s clip, extrapolated "
+                      f"x{n_fwd}/{n_sample}; C1 in full: " + "; ".join(f"{r['median_s']}s median of {r['repeats']} at {r['threads']} threads" for r in c1_runs.values())}
 
 
 def encoder_pass(cfg, duration, dev, dtype, frame_rate=16.0, hw=(480, 640), repeats=2):
@@ -414,6 +467,7 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
         model.ctx.dac_decode(lat)
         torch.cuda.synchronize()
         dac_ms = model.ctx.last_elapsed_ms()
+        pieces["local"] = {"clips": bs * steps, "pass_ms": round(1e3 * dt / steps, 2), "loop_ms": round(loop_ms, 2)}
         if use_dist:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -422,8 +476,23 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
         assert not progress or len(ticks) == (steps + warmup) * STEPS_PER_CLIP
         return dt, loop_ms, dac_ms
 
+    def device_identity():
+        pr = torch.cuda.get_device_properties(dev)
+        return {"device": str(dev), "name": pr.name, "uuid": str(getattr(pr, "uuid", "")), "pci_bus_id": getattr(pr, "pci_bus_id", None)}
+
+    def gather_ranks(local_rec):
+        """Every rank's own record, all-gathered on the job's communicator: what each rank ran on and how long ITS passes took
+        (the line's `value` uses the slowest rank) - so that "did RCCL see N ranks, did each do its clips" reads off the line."""
+        rec = dict(rank=rank, **device_identity(), **local_rec)
+        if not use_dist:
+            return [rec]
+        recs = [None] * world
+        dist.all_gather_object(recs, rec)
+        return recs
+
     dt, loop_ms, dac_ms = measure(bs_main, noise_all[lo:hi], a.steps, a.warmup)
     prepare_ms = pieces.get("prepare_ms")
+    rank_records = gather_ranks(dict(pieces["local"], shard=[lo, hi]))
     f_clip = flops_clip(cfg, duration, STEPS_PER_CLIP, GUIDANCE)
     f_loop = f_clip - 2.30933e9 * la
     peak = PEAK_TFLOPS[a.precision]
@@ -452,11 +521,17 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
             gx = torch.Generator("cpu").manual_seed(1234)
             nx = sampler.draw_noise(world * bs, cfg.latent_dim, la_x, dtype, gx)
             lox, hix = D.shard_range(world * bs, rank, world)
+            pk = kw.pop("peak", peak)
             dtx, loopx, dacx = measure(bs, nx[lox:hix], passes, 1, duration=dur, **kw)
             fl = flops_clip(cfg, dur, STEPS_PER_CLIP, GUIDANCE) - 2.30933e9 * la_x
-            return {"value": world * bs * passes * dur / dtx, "unit": "audio-sec/sec", "workload": workload, "clips_per_gpu": bs,
+            line = {"value": world * bs * passes * dur / dtx, "unit": "audio-sec/sec", "workload": workload, "clips_per_gpu": bs,
                     "steps": passes, "warmup": 1, "ms_per_step": 1e3 * dtx / passes, "loop_ms": loopx, "dac_decode_ms": dacx,
-                    "loop_frac": bs * fl / (loopx * 1e-3) / 1e12 / peak}
+                    "loop_frac": bs * fl / (loopx * 1e-3) / 1e12 / pk}
+            if use_dist:                       # per-rank evidence: every rank's own pass time and clip count
+                rr = gather_ranks(dict(pieces["local"], shard=[lox, hix]))
+                line["ranks"] = {"n": len(rr), "clips_total": sum(r["clips"] for r in rr),
+                                 "pass_ms_min": min(r["pass_ms"] for r in rr), "pass_ms_max": max(r["pass_ms"] for r in rr)}
+            return line
 
         extra["bs8"] = extra_line(8, duration, "c2 at bs=8 per GPU (the bs=8 half of the BASELINE metric)", passes=4)
         # stand-in V2A features: a pure function of the seed, synthesised on every rank like the noise
@@ -477,6 +552,14 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
             extra["c5"] = extra_line(1, CONFIGS["c5"]["duration"], f"c5: {CONFIGS['c5']['desc']}", model=m5,
                                      visual={"siglip2_feat": c5c["clip"], "syncformer_feat": c5c["sync"]})
             del m5
+            # the PARITY mode (precision=fp32: fp32 operands on v_mfma_f32_32x32x2_f32, no split-K) - the mode that carries
+            # north_star's 1e-3 waveform gate (golden g17) gets a throughput line too, against the fp32 matrix peak
+            if a.precision != "fp32":
+                m32 = nodes.HunyuanModelLoader.pack_state_dict(sd, "fp32", "none", device=dev, cfg=cfg, dac_cfg=dac_cfg)
+                extra["fp32"] = extra_line(1, duration, "c2 bs=1 in the fp32 parity mode (fp32 operands / fp32 accumulate; the mode gated at 1e-3 "
+                                           "on the waveform against the reference's fp32 sampler, golden g17); loop_frac against the 157.3 TFLOP/s "
+                                           "fp32 matrix peak", passes=2, model=m32, peak=PEAK_TFLOPS["fp32"])
+                del m32
 
     if rank == 0:
         clips = world * bs_main * a.steps
@@ -505,11 +588,26 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
                              "definition": mj["definition"]}
                 break
         dom = next((k for k in kernels if k["gflop_per_launch"] > 0), None)   # largest time per iteration among the MFMA kernels
+        # the same kernel's average in the rocprofv3 --kernel-trace --stats run of this command (profiles/rNN_rocprof_dominant.json,
+        # written by tools/collect_profiles.sh; reported only for exactly these kernel sources): the dispatch-event average above
+        # and the traced one differ by ~3 %
+        rocprof = None
+        for rp_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprof_dominant.json")), reverse=True):
+            try:
+                rj = json.load(open(rp_path))
+            except Exception:
+                continue
+            if rj.get("kernel_src_sha") == kernel_src_sha() and rj.get("workload") == f"{a.config}/bs{bs_main}/{a.precision}/{a.model}" and dom:
+                tfr = dom["gflop_per_launch"] * 1e9 / (rj["avg_us"] * 1e-6) / 1e12
+                rocprof = {"kernel": rj["kernel"], "avg_us": rj["avg_us"], "calls": rj["calls"], "achieved": round(tfr, 1),
+                           "frac": round(tfr / peak, 4), "file": os.path.relpath(rp_path, ROOT)}
+                break
         roof = {"bound": "mfma", "peak": peak, "unit": "TFLOP/s",
                 "achieved": dom["tflops"] if dom else loop_tf, "frac": dom["frac"] if dom else loop_tf / peak,
                 "kernel": dom["name"] if dom else "whole sampler loop",
                 "launch": ("dominant kernel of the loop (largest time per iteration): algorithmic FLOPs of one launch / the dispatch's own "
                            "start->stop HIP events on the launch stream (hipExtLaunchKernelGGL), eager forward at iteration 25, after the timed region"),
+                "frac_rocprof": rocprof["frac"] if rocprof else None, "rocprof": rocprof,
                 "traffic": traffic, "traffic_source": traffic_src, "mfma_busy": mfma_busy,
                 "loop_frac": loop_tf / peak, "loop_achieved": loop_tf, "loop_ms": loop_ms, "dac_decode_ms": dac_ms, "prepare_ms": prepare_ms,
                 "algorithmic_tflop_per_clip": f_clip / 1e12, "event_bracket_us": bracket_us, "kernels": kernels}
@@ -523,7 +621,9 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
                                    f"DAC-VAE fp32 decode to 48 kHz, host-to-host (H2D noise + D2H waveform timed)",
                        "clips_per_gpu": bs_main, "parallelism": f"dp{world}", "hip_graph": graph,
                        "progress_callback": bool(a.progress),
-                       "collectives": 1 if use_dist else 0, "broadcast_s": bcast_s, "bundle_bytes": spec.total},
+                       "collectives": 1 if use_dist else 0, "broadcast_s": bcast_s, "bundle_bytes": spec.total,
+                       "rccl_nranks": dist.get_world_size() if use_dist else 1, "backend": a.backend if use_dist else None,
+                       "ranks": rank_records},
             "roofline": roof,
         }
         if encoders is not None:

@@ -932,6 +932,76 @@ def test_denoise_process_multi_shards_the_batch(tiny, dev):
     assert rel_err(one, full[:1]) < 1e-5
 
 
+def test_eight_contexts_on_one_device_full_size(dev):
+    """What an 8-GPU ComfyUI run asks of ONE host process (sampler.denoise_process_multi, FOLEY_DATA_PARALLEL=1), de-risked
+    on one GPU: EIGHT contexts of the full xxl model on this device (device-local arena copies), eight host threads, each
+    replaying its own ~440-node hipGraph 50 times under one GIL with the process-wide set-up lock, an 8-clip batch sharded one
+    clip per context.  Checks: every clip equals the single-context run of the same clip (bf16 mode: bit-identical - same
+    tiles, same shapes), and the threaded run's wall time against the same eight clips run one after the other on ONE
+    context - the difference per loop iteration is the host-side price of the eight concurrent launch streams (reported;
+    gate: the threaded run may not be slower than the sequential one by more than 15 %)."""
+    import time
+    from foley_amd import nodes
+    cfg = C.XXL
+    sd = synth.synth_dit_state_dict(cfg, device=dev)
+    cond = synth.synth_conditioning(cfg, 5.0, t2a=False, sd=sd, device=dev)
+    model = nodes.HunyuanModelLoader.pack_state_dict(sd, "bf16", "none", device=dev, cfg=cfg)
+    del sd
+    torch.cuda.empty_cache()
+    dac = sampler.FoleyDAC(synth.synth_dac_state_dict(C.DAC48K, device=dev), dev)
+    vis = {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]}
+    txt = {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]}
+    n = 8
+    noise = sampler.draw_noise(n, 128, 250, torch.bfloat16, torch.Generator("cpu").manual_seed(1234))
+    seq = []
+    for rep in range(2):            # the first round captures the graph and warms the device up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        seq = [sampler.denoise_process_with_generator(vis, txt, 5.0, model, dac, 4.5, 50, 1, "euler", noise=noise[i:i + 1])[0] for i in range(n)]
+        torch.cuda.synchronize()
+        t_seq = time.perf_counter() - t0
+    reps = sampler.replicate(model, dac, [dev] * n)
+    assert len({id(m) for m, _ in reps}) == n and model.last_broadcast_s == 0.0       # one device: local copies, no RCCL
+    gen = lambda: torch.Generator("cpu").manual_seed(1234)
+    t_multi = None
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        multi, _sr = sampler.denoise_process_multi(vis, txt, 5.0, reps, 4.5, 50, n, "euler", generator=gen())
+        torch.cuda.synchronize()
+        t_multi = time.perf_counter() - t0
+    assert multi.shape == (n, 1, 240000)
+    for i in range(n):
+        assert torch.equal(multi[i], seq[i][0]), i
+    per_it_us = 1e6 * (t_multi - t_seq) / 50
+    print("8 contexts / 8 threads on one device: %.3f s; the same 8 clips sequentially on one context: %.3f s; "
+          "difference per loop iteration %.0f us (8 concurrent ~440-node graph launches)" % (t_multi, t_seq, per_it_us))
+    record_parity("eight_contexts_one_device", threaded_s=t_multi, sequential_s=t_seq, host_overhead_us_per_iteration=per_it_us)
+    assert t_multi < 1.15 * t_seq
+
+
+def test_replicas_share_the_sticky_text_bucket(tiny, dev):
+    """The sticky text length is ONE value per model in the reference (utils.py:166-188).  A replica that sat out a
+    long-prompt batch (empty shard) must still pad the next short prompt to 128 like the replica that saw it - otherwise clips
+    of one batch are padded differently (text padding is unmasked) and differ from a single-GPU run."""
+    import dataclasses
+    sd, dsd, _model, _dac = tiny
+    cfg128 = dataclasses.replace(C.TINY, text_len=128)          # the yaml's text_length caps the bucket (utils.py:95-99); 128 lets it trigger
+    model = sampler.FoleyModel(cfg128, sd, torch.float32, dev, dac_cfg=C.DAC_TINY)
+    dac = sampler.FoleyDAC(dsd, dev, C.DAC_TINY)
+    cond = synth.synth_conditioning(C.TINY, 1.0, t2a=False)
+    vis = {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]}
+    long_txt = {"text_feat": synth.synth_tensor("t.long", (1, 90, 768), 1.0), "uncond_text_feat": cond["uncond_text"]}
+    short_txt = {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]}
+    reps = sampler.replicate(model, dac, [dev, dev])
+    sampler.denoise_process_multi(vis, long_txt, 1.0, reps, 4.5, 4, 1, "euler", generator=torch.Generator("cpu").manual_seed(3))   # replica 1 idle
+    assert [m._text_len_fixed for m, _ in reps] == [128, 128]
+    multi, _sr = sampler.denoise_process_multi(vis, short_txt, 1.0, reps, 4.5, 4, 2, "euler", generator=torch.Generator("cpu").manual_seed(3))
+    single, _sr = sampler.denoise_process_with_generator(vis, short_txt, 1.0, model, dac, 4.5, 4, 2, "euler",
+                                                          generator=torch.Generator("cpu").manual_seed(3))
+    assert model._text_len_fixed == 128 and rel_err(multi, single) < 1e-5
+
+
 def test_bcast_local_grouped_rccl_launch(dev):
     """foley_bcast_local (the in-process form of the single weight broadcast, used by sampler.replicate): ncclCommInitAll over
     every visible device + ONE grouped launch carrying two buffers per device.  On the 1-GPU boxes the communicator has one

@@ -2,9 +2,9 @@
 # Runs on the GPU box (via gpurun): bench lines, rocprofv3 kernel-trace stats of the bench command and
 # the PMC passes (separate runs, kernel filter - rocprofv3 segfaults in PyTorch's own kernels
 # otherwise), summarised into gpurun_out/ (the raw databases stay in /tmp: too large to ship back).
-#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r04 [tag-suffix]'
+#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r05 [tag-suffix]'
 set -u
-TAG=${1:-r04}${2:+_$2}
+TAG=${1:-r05}${2:+_$2}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out
 mkdir -p $OUT
@@ -33,11 +33,12 @@ python $R/bench.py --precision fp16 --steps 3 --warmup 1 --no-cpu-baseline --no-
 
 # kernel-trace stats of the bench command itself (1 timed pass + the event-timed loop / decode)
 rocprofv3 --kernel-trace --stats -d /tmp/kt1 -o kt -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > /tmp/kt1.log 2>&1
-python $R/tools/prof_summary.py $(find /tmp/kt1 -name "*.db" | head -1) > $OUT/${TAG}_bench_bs1_kernel_stats.md
+python $R/tools/prof_summary.py $(find /tmp/kt1 -name "*.db" | head -1) --dominant-json $OUT/${TAG}_rocprof_dominant.json --workload c2/bs1/bf16/xxl > $OUT/${TAG}_bench_bs1_kernel_stats.md
+cp $OUT/${TAG}_rocprof_dominant.json $R/profiles/${TAG}_rocprof_dominant.json
 rocprofv3 --kernel-trace --stats -d /tmp/kt8 -o kt -- python $R/bench.py --steps 1 --warmup 0 --bs 8 --no-cpu-baseline --no-extra > /tmp/kt8.log 2>&1
 python $R/tools/prof_summary.py $(find /tmp/kt8 -name "*.db" | head -1) > $OUT/${TAG}_bench_bs8_kernel_stats.md
 rocprofv3 --kernel-trace --stats -d /tmp/kt3 -o kt -- python $R/bench.py --config c3 --with-encoders --steps 1 --warmup 0 --no-cpu-baseline --no-extra > /tmp/kt3.log 2>&1
-python $R/tools/prof_summary.py $(find /tmp/kt3 -name "*.db" | head -1) > $OUT/${TAG}_bench_c3_kernel_stats.md
+python $R/tools/prof_summary.py $(find /tmp/kt3 -name "*.db" | head -1) --all > $OUT/${TAG}_bench_c3_kernel_stats.md   # --all: the encoders' torch glue kernels are part of this configuration
 rocprofv3 --kernel-trace --stats -d /tmp/kt5 -o kt -- python $R/bench.py --config c5 --steps 1 --warmup 0 --no-cpu-baseline --no-extra > /tmp/kt5.log 2>&1
 python $R/tools/prof_summary.py $(find /tmp/kt5 -name "*.db" | head -1) > $OUT/${TAG}_bench_c5_kernel_stats.md
 
