@@ -36,6 +36,13 @@ __device__ __forceinline__ void buf_lds16(const void* base, unsigned bytes, unsi
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
 
+// the same with cache-policy bits (aux 2 = nt: a weight stream every line of which is read once or twice and never again)
+template <int AUX>
+__device__ __forceinline__ void buf_lds16_aux(const void* base, unsigned bytes, unsigned char* lds_wave_base, int voff, int soff) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, AUX);
+}
+
 // s_barrier the compiler may not move MFMAs across: they touch no memory, so nothing else orders them against the builtin (left
 // alone hipcc sank a whole MFMA block below the second barrier of the strict-alternation loops, see gemm_wide_impl.h)
 __device__ __forceinline__ void hard_barrier() {
@@ -711,6 +718,287 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_conv3_kernel(cons
   tl_stamp(g, 3);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 5: the 256x64 tap-fused conv tile with K-SPLIT WAVE PAIRS and slice read-ahead (tile 22 at small M: w1 / w3, w2, linear1
+// of the single-stream blocks = 39 % of a bs=1 iteration).  tools/ubench/vmem_paths.hip + mfma_rate.hip (profiles/r05_*):
+//  * the matrix pipe alone sustains one s_barrier per 16-MFMA slice at 515 cycles per slice (512 = full), also next to a
+//    20 KiB-per-slice LDS-DMA stream - but the early / late consumer halves above take 740 - 850: after the barrier a wave
+//    either requests fragments and waits for them before it multiplies, or multiplies and only then requests, so every slice
+//    exposes one LDS round trip and the two waves of a SIMD multiply at once half of the time;
+//  * here every wave, after the barrier of slice kt, multiplies slice kt-1 from a second fragment register set and requests the
+//    fragments of slice kt IN THE SHADOW of those MFMAs (two ds_read_b128 behind each of the first four MFMAs, the last four
+//    cover their latency; order pinned with sched_group_barrier - left alone hipcc re-merges the two sets);
+//  * two fragment sets of a 32x64 wave tile would be 96 registers (the tile spills at the 168-register cap of a 768-thread
+//    kernel), so waves w and w + 4 - the two consumer waves of a SIMD - share the 64x64 tile of rows (w & 3) * 64 and SPLIT THE
+//    K-STEPS of every slice (0 / 1 and 2 / 3): 8 fragment reads per 8 MFMAs instead of 12, two sets = 64 registers, 64
+//    accumulator registers; the partner's partial tile is added once, through the dead ring, before the epilogue.
+// Loader waves, ring protocol, K permutation, zero padding and epilogues are those of gemm_ws_conv3_kernel<256, 64, 8, 1, 6, 3, 4>.
+template <typename T, int EPI, int WNT>
+__global__ __launch_bounds__(768) void gemm_ws_conv3_ks_kernel(const GemmPair pr) {
+  const GemmArgs& g = pr.g[0];
+  constexpr int BM = 256, BN = 64, LW = 4, NSB = 6, NAB = 3, NW = 8;
+  constexpr int BK = 64, ESZ = 2, OOB = 0x7ffffff0;
+  constexpr int APC = (BM + 2 + 7) / 8, AI = (APC + LW - 1) / LW, ABUF = AI * LW * 1024;
+  constexpr int BI = BN * 128 / 1024 / LW, BSL = BN * 128;
+  constexpr int ZROW = 8 * APC;     // first staged row of the surplus pieces: out of range for every lane, i.e. zero-filled by the DMA
+  static_assert(ZROW + 8 <= AI * LW * 8, "the zero rows live in the surplus pieces of an activation buffer");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  const int tiles_m = (g.M + BM - 1) / BM;
+  const int tiles_n = (g.N + BN - 1) / BN;
+  int bid = (int)blockIdx.x;
+  {  // bijective XCD remap (see gemm_ws_kernel)
+    const int nwg = tiles_m * tiles_n * (EPI == EPI_GATE_RES ? g.ksplit : 1);
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  int ks = 0;
+  if constexpr (EPI == EPI_GATE_RES) {
+    ks = bid % g.ksplit;
+    bid /= g.ksplit;
+  }
+  const int tm = bid % tiles_m, tn = bid / tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  tl_stamp(g, 0);
+  const int C = g.tapC;
+  int kc_begin = 0, nkc = C / BK;
+  if constexpr (EPI == EPI_GATE_RES) {
+    const int tot = nkc;
+    kc_begin = (int)((long)tot * ks / g.ksplit);
+    nkc = (int)((long)tot * (ks + 1) / g.ksplit) - kc_begin;
+  }
+  const int nk = 3 * nkc;
+
+  if (wave >= NW) {
+    // ------------------------------------------------------------------ loader wave (gemm_ws_conv3_kernel's)
+    const int lw = wave - NW;
+    const int lr = lane >> 3, lp = lane & 7;
+    int vA[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int j = (lw * AI + i) * 8 + lr;
+      const int r = m0 - 1 + j;
+      vA[i] = (j < BM + 2 && r >= 0 && r < g.M) ? (int)((unsigned)r * (unsigned)(g.lda * ESZ) + (unsigned)((lp ^ ((j >> 1) & 7)) * 16)) : OOB;
+    }
+    int vW[BI];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int rl = (lw * BI + i) * 8 + lr;
+      const int n = n0 + rl;
+      vW[i] = (n < g.N) ? (int)((unsigned)n * (unsigned)(g.ldw * ESZ) + (unsigned)((lp ^ ((rl >> 1) & 7)) * 16)) : OOB;
+    }
+    auto issue = [&](int sl) {
+      const int c = sl / 3, tap = sl - 3 * c;
+      const int ch = (kc_begin + c) * BK;
+      if (tap == 0) {
+        unsigned char* Ab = lds + (c % NAB) * ABUF;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) buf_lds16(g.A, g.a_bytes, Ab + (lw * AI + i) * 1024, vA[i], ch * ESZ);
+      }
+      unsigned char* Bs = lds + NAB * ABUF + (sl % NSB) * BSL;
+      const int sW = (tap * C + ch) * ESZ;
+#pragma unroll
+      for (int i = 0; i < BI; ++i) buf_lds16_aux<WNT ? 2 : 0>(g.W, g.w_bytes, Bs + (lw * BI + i) * 1024, vW[i], sW);
+    };
+#pragma unroll
+    for (int sl = 0; sl < NSB - 1; ++sl)
+      if (sl < nk) issue(sl);
+    for (int kt0 = 0; kt0 < nk; kt0 += 3) {
+#pragma unroll
+      for (int tap = 0; tap < 3; ++tap) {
+        const int kt = kt0 + tap;
+        if (kt + NSB - 2 < nk) {
+          if (tap == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(conv3_inflight(NSB, 0, AI, BI)) : "memory");
+          else if (tap == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(conv3_inflight(NSB, 1, AI, BI)) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(conv3_inflight(NSB, 2, AI, BI)) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (kt + NSB - 1 < nk) issue(kt + NSB - 1);
+      }
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------- consumer wave: 64 rows x 64 columns x half of the k-steps
+  const int wq = wave & 3, kq = wave >> 2;
+  const int fi = lane & 31, kh = lane >> 5;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // fragment row i at tap t reads staged row (tile row + t); taps that leave the clip read a zero row of the same buffer
+  // LDS byte offsets are kept as ONE register per (tap, row fragment) / per column fragment - k-step 0 of this wave; k-step 1 is
+  // the neighbouring 16-byte chunk (offset ^ 16) and the buffer / stage base is a scalar: both are folded in at the point of
+  // use through opaque scalars, so that the compiler cannot hoist 24 + 8 finished addresses out of the loop (it did: 178 spilled
+  // registers at the 168-register cap of a 768-thread kernel)
+  int a_adr[3][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int tr = wq * 64 + i * 32 + fi;
+    const int q = (m0 + tr) % g.segV;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const bool ok = !((t == 0 && q == 0) || (t == 2 && q == g.segV - 1));
+      const int j = ok ? tr + t : ZROW;
+      a_adr[t][i] = j * 128 + (((4 * kq + 2 * kh) ^ ((j >> 1) & 7)) << 4);   // chunk a_chunk(2 kq), see gemm_ws_body
+    }
+  }
+  int b_adr[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = j * 32 + fi;
+    b_adr[j] = NAB * ABUF + r * 128 + (((4 * kq + 2 * kh) ^ ((r >> 1) & 7)) << 4);
+  }
+  bf16x8 fa[2][2][2], fb[2][2][2];   // [set][k-step][fragment]
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      fa[1][s][i] = __builtin_bit_cast(bf16x8, z);   // the first step multiplies set 1 before anything was read into it: zeros
+      fb[1][s][i] = __builtin_bit_cast(bf16x8, z);
+    }
+  // one step: barrier of slice kt, then MFMAs of the previous slice with this slice's fragment requests in their shadow
+  auto step = [&](auto set, auto tapc, int ab_off, int stage) {
+    constexpr int S = decltype(set)::value, TAP = decltype(tapc)::value;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's requests of the previous slice have returned: its stage may be refilled
+    hard_barrier();
+    int ab = ab_off, bs = stage * BSL, sx = 16;
+    asm volatile("" : "+s"(ab), "+s"(bs), "+s"(sx));
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[S][s][i] = *(const bf16x8*)(lds + (ab + (s ? (a_adr[TAP][i] ^ sx) : a_adr[TAP][i])));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[S][s][j] = *(const bf16x8*)(lds + (bs + (s ? (b_adr[j] ^ sx) : b_adr[j])));
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<T>(fa[S ^ 1][s][i], fb[S ^ 1][s][j], acc[i][j]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA ...
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // (the address arithmetic of the next two requests)
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // ... two fragment requests behind it
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using T0 = std::integral_constant<int, 0>;
+  using T1 = std::integral_constant<int, 1>;
+  using T2 = std::integral_constant<int, 2>;
+  // slices alternate between the two sets; a chunk is three slices, so chunks alternate between (0,1,0) and (1,0,1); the ring
+  // stage of slice kt is kt % 6 = 3 * (chunk parity) + tap
+  int c = 0;
+  for (; c + 2 <= nkc; c += 2) {
+    const int Ab0 = (c % NAB) * ABUF, Ab1 = ((c + 1) % NAB) * ABUF;
+    step(S0{}, T0{}, Ab0, 0);
+    if (c == 0) tl_stamp(g, 1);
+    step(S1{}, T1{}, Ab0, 1);
+    step(S0{}, T2{}, Ab0, 2);
+    step(S1{}, T0{}, Ab1, 3);
+    step(S0{}, T1{}, Ab1, 4);
+    step(S1{}, T2{}, Ab1, 5);
+  }
+  if (c < nkc) {   // odd number of chunks: the tail chunk starts on set 0 / stage 0 again (an even number of chunks came before)
+    const int Ab0 = (c % NAB) * ABUF;
+    step(S0{}, T0{}, Ab0, 0);
+    step(S1{}, T1{}, Ab0, 1);
+    step(S0{}, T2{}, Ab0, 2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {   // the last slice sits in set 0: hand it to the common tail below
+        fa[1][s][i] = fa[0][s][i];
+        fb[1][s][i] = fb[0][s][i];
+      }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int s = 0; s < 2; ++s)     // the last slice (zeros if there was none)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<T>(fa[1][s][i], fb[1][s][j], acc[i][j]);
+  tl_stamp(g, 2);
+  // ---- the partner's partial tile (k-steps 2 / 3 of every slice) joins through the dead ring: lane-major 16-byte records
+  __syncthreads();   // the eight consumer waves (the loaders have left): every fragment read of the last slice has returned
+  {
+    f32x4* xch = (f32x4*)lds + (wq * 16) * 64 + lane;
+    if (kq == 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const f32x4 t = {acc[i][j][4 * v], acc[i][j][4 * v + 1], acc[i][j][4 * v + 2], acc[i][j][4 * v + 3]};
+            xch[((i * 2 + j) * 4 + v) * 64] = t;
+          }
+    }
+    __syncthreads();
+    if (kq == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const f32x4 t = xch[((i * 2 + j) * 4 + v) * 64];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][4 * v + e] += t[e];
+          }
+    }
+  }
+  // waves 0..3 own the summed 64x64 tiles (WM = 4, WN = 1); waves 4..7 take their share of the LDS -> global passes
+  gemm_epilogue_lds<T, EPI, BM, BN, 4, 1, 4>(g, acc, lds, m0, n0, ks);
+  tl_stamp(g, 3);
+}
+
+template <typename T, int EPI>
+int launch_ws_conv3_ks(const GemmArgs& g, hipStream_t st) {
+  constexpr int BM = 256, BN = 64, LW = 4, NSB = 6, NAB = 3;
+  constexpr size_t ai = ((BM + 2 + 7) / 8 + LW - 1) / LW;
+  constexpr size_t lds_ring = NAB * ai * LW * 1024 + (size_t)NSB * BN * 128;
+  constexpr size_t lds_epi = (size_t)BM * BN * 4;
+  constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  GemmPair pr;
+  pr.g[0] = g;
+  pr.g[1] = g;
+  pr.tiles0 = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * (EPI == EPI_GATE_RES ? g.ksplit : 1);
+  static const bool nt = []() { const char* e = getenv("FOLEY_W_NT"); return e && e[0] == '1'; }();
+  static std::atomic<unsigned long long> raised{0}, raised_nt{0};
+  if (nt) {
+    auto k = gemm_ws_conv3_ks_kernel<T, EPI, 1>;
+    hipError_t e = foley_raise_lds((const void*)k, (int)lds, raised_nt);
+    if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);
+    FOLEY_LAUNCH(k, dim3(pr.tiles0), dim3(768), lds, st, pr);
+  } else {
+    auto k = gemm_ws_conv3_ks_kernel<T, EPI, 0>;
+    hipError_t e = foley_raise_lds((const void*)k, (int)lds, raised);
+    if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);
+    FOLEY_LAUNCH(k, dim3(pr.tiles0), dim3(768), lds, st, pr);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);
+  return 0;
+}
+
 template <typename T, int BM, int EPI, int WF>
 int launch_ws_conv3_one(const GemmArgs& g, hipStream_t st) {
   // 128x128: activation chunks 3 deep + 6 weight slices; 256x128 (large grids): 2 + 4 (fp8 weights: 3 + 6)
@@ -829,6 +1117,13 @@ int launch_gemm_ws_t(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, h
     return foley_set_err("wave-specialised GEMM: bad / mixed weight formats", __FILE__, __LINE__);
   if (tile == 22) {   // tap-fused conv k=3, 256x64 (bf16 weights; gated residual / fp32 store)
     if (g1 || g.wfmt) return foley_set_err("wave-specialised conv3 256x64: single problem, bf16 weights", __FILE__, __LINE__);
+    // round 5: K-split wave pairs + slice read-ahead (vector epilogue only; FOLEY_CONV3_KS=0 keeps the early / late form)
+    static const bool ksp = []() { const char* e = getenv("FOLEY_CONV3_KS"); return !(e && e[0] == '0'); }();
+    if (ksp && g.vec_out) {
+      if (epi == EPI_GATE_RES) return launch_ws_conv3_ks<T, EPI_GATE_RES>(g, st);
+      if (epi == EPI_STORE_F32) return launch_ws_conv3_ks<T, EPI_STORE_F32>(g, st);
+      if (epi == EPI_SILUGATE_T) return launch_ws_conv3_ks<T, EPI_SILUGATE_T>(g, st);
+    }
     if (epi == EPI_GATE_RES) return launch_ws_conv3_tall<T, EPI_GATE_RES>(g, st);
     if (epi == EPI_STORE_F32) return launch_ws_conv3_tall<T, EPI_STORE_F32>(g, st);
     if (epi == EPI_SILUGATE_T) return launch_ws_conv3_tall<T, EPI_SILUGATE_T>(g, st);
