@@ -1400,6 +1400,12 @@ extern "C" int foley_op_attention(const void* q, const void* k, const void* v, i
   return foley_op_attention_hd(q, k, v, in_dtype, vt_pitch, Bq, H, Sq, Skv, kv_bdiv, outA, outB, split, out_dtype, 128, stream);
 }
 
+extern "C" int foley_op_qkv_regroup(const void* qkv, int dtype, int H, const int32_t* idx_q, int G, int Sq, const int32_t* idx_kv, int Skv,
+                                    void* q, void* k, void* v, int vt_pitch, void* stream) {
+  if (!qkv || !idx_q || !idx_kv || !q || !k || !v) return FAIL(FOLEY_ERR_INVALID, "null argument");
+  return launch_qkv_regroup(qkv, dtype, H, idx_q, G, Sq, idx_kv, Skv, q, k, v, vt_pitch, (hipStream_t)stream);
+}
+
 extern "C" int foley_op_ln_mod(const float* x, int M, int D, float eps, const foley_rowbcast* shift,
                                const foley_rowbcast* scale, void* out, int out_dtype, void* stream) {
   return launch_ln_mod(x, M, D, eps, to_rb(shift), to_rb(scale), out, out_dtype, (hipStream_t)stream);

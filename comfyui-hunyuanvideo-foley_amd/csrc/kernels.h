@@ -209,5 +209,7 @@ int launch_solver_step(const StepArgs& a, hipStream_t st);
 int launch_dac_in(const float* x, const float* w, const float* bias, const float* alpha, int B, int T, int C,
                   float* out0, float* out1, hipStream_t st);
 int launch_rows_to_planes(const float* rows, int B, int T, int C, float* out, hipStream_t st);
+int launch_qkv_regroup(const void* qkv, int dtype, int H, const int* idx_q, int G, int Sq, const int* idx_kv, int Skv, void* q, void* k,
+                       void* v, int vt_pitch, hipStream_t st);
 int launch_dac_out(const float* s, const float* w, const float* bias, int B, int T, int C, float* out,
                    hipStream_t st);

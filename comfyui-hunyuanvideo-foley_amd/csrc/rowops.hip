@@ -844,6 +844,74 @@ int launch_dac_in(const float* x, const float* w, const float* bias, const float
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Token regrouping between a fused q / k / v projection and the attention of the conditioning encoders (round 5): the
+// divided space-time attention of the Synchformer (reference models/synchformer/vit_helper.py:37-105: patch tokens attend over
+// the frames of their location or the locations of their frame, the CLS key / value prepended to every group) and the plain
+// ViT attention of SigLIP2 / CLAP.  qkv [rows, 3*H*64] ('(K H D)' packing of nn.Linear(dim, 3 dim)); group g takes source rows
+// idx_q[g][0..Sq) as queries and idx_kv[g][0..Skv) as keys / values, written head-major as foley_op_attention_hd reads them:
+// q [G,H,Sq,64], k [G,H,Skv,64], v [G,H,Skv,64] or - 16-bit operands - v^T [G,H,64,pitch] (zeros beyond Skv) through a 64x64 LDS
+// transpose.  One launch replaces ~10 full-tensor torch copies (permute / cat / contiguous / the transposed-V staging).
+template <typename E>   // E = the element's storage type (uint16_t: bf16 / fp16, uint32_t: fp32)
+__global__ __launch_bounds__(256) void qkv_regroup_kernel(const E* __restrict__ qkv, int H, const int* __restrict__ idx_q, int Sq,
+                                                          const int* __restrict__ idx_kv, int Skv, E* __restrict__ q, E* __restrict__ k,
+                                                          E* __restrict__ v, int vt_pitch) {
+  constexpr int HD = 64, CPR = HD * sizeof(E) / 16;   // 16-byte chunks per head row
+  __shared__ __attribute__((aligned(16))) E tile[64][HD + 16 / sizeof(E)];
+  const int t0 = blockIdx.x * 64, h = blockIdx.y, g = blockIdx.z;
+  const long ld = 3L * H * HD;
+  const int tid = threadIdx.x;
+  for (int c = tid; c < 64 * CPR; c += 256) {
+    const int t = t0 + c / CPR, ch = c % CPR;
+    if (t < Sq) {
+      const long r = idx_q[(long)g * Sq + t];
+      *(u32x4*)(q + (((long)g * H + h) * Sq + t) * HD + ch * (16 / sizeof(E))) = *(const u32x4*)(qkv + r * ld + (long)h * HD + ch * (16 / sizeof(E)));
+    }
+    if (t < Skv) {
+      const long r = idx_kv[(long)g * Skv + t];
+      const E* src = qkv + r * ld + (long)(H + h) * HD + ch * (16 / sizeof(E));
+      *(u32x4*)(k + (((long)g * H + h) * Skv + t) * HD + ch * (16 / sizeof(E))) = *(const u32x4*)src;
+      const u32x4 vv = *(const u32x4*)(src + (long)H * HD);
+      if (vt_pitch == 0) *(u32x4*)(v + (((long)g * H + h) * Skv + t) * HD + ch * (16 / sizeof(E))) = vv;
+      else *(u32x4*)&tile[c / CPR][ch * (16 / sizeof(E))] = vv;
+    } else if (vt_pitch != 0) {
+      *(u32x4*)&tile[c / CPR][ch * (16 / sizeof(E))] = u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+  if (vt_pitch == 0) return;   // grid-uniform
+  __syncthreads();
+  // v^T rows: d-major, 8 tokens (16-bit) per 16-byte store
+  constexpr int TPS = 16 / sizeof(E);   // tokens per store
+  for (int c = tid; c < HD * (64 / TPS); c += 256) {
+    const int d = c / (64 / TPS), tb = (c % (64 / TPS)) * TPS;
+    if (t0 + tb >= vt_pitch) continue;
+    E tmp[TPS];
+#pragma unroll
+    for (int u = 0; u < TPS; ++u) tmp[u] = tile[tb + u][d];
+    *(u32x4*)(v + (((long)g * H + h) * HD + d) * vt_pitch + t0 + tb) = *(const u32x4*)tmp;
+  }
+}
+
+int launch_qkv_regroup(const void* qkv, int dtype, int H, const int* idx_q, int G, int Sq, const int* idx_kv, int Skv, void* q, void* k,
+                       void* v, int vt_pitch, hipStream_t st) {
+  if (G < 1 || H < 1 || Sq < 1 || Skv < 1) return foley_set_err("qkv_regroup: empty problem", __FILE__, __LINE__);
+  if (vt_pitch && (vt_pitch % 8 || vt_pitch < Skv || vt_pitch > (Skv + 63) / 64 * 64))
+    return foley_set_err("qkv_regroup: the transposed-V pitch must be a multiple of 8 in [Skv, ceil64(Skv)]", __FILE__, __LINE__);
+  if (((uintptr_t)qkv | (uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) return foley_set_err("qkv_regroup: operands must be 16-byte aligned", __FILE__, __LINE__);
+  const int S = Sq > Skv ? Sq : Skv;
+  const dim3 grid((S + 63) / 64, H, G);
+  if (dtype == FOLEY_F32) {
+    if (vt_pitch) return foley_set_err("qkv_regroup: fp32 operands keep V untransposed", __FILE__, __LINE__);
+    FOLEY_LAUNCH(qkv_regroup_kernel<uint32_t>, grid, dim3(256), 0, st, (const uint32_t*)qkv, H, idx_q, Sq, idx_kv, Skv, (uint32_t*)q, (uint32_t*)k, (uint32_t*)v, 0);
+  } else if (foley_is_half(dtype)) {
+    FOLEY_LAUNCH(qkv_regroup_kernel<uint16_t>, grid, dim3(256), 0, st, (const uint16_t*)qkv, H, idx_q, Sq, idx_kv, Skv, (uint16_t*)q, (uint16_t*)k, (uint16_t*)v, vt_pitch);
+  } else {
+    return foley_set_err("qkv_regroup: fp32, bf16 or fp16 operands", __FILE__, __LINE__);
+  }
+  FOLEY_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_rows_to_planes(const float* rows, int B, int T, int C, float* out, hipStream_t st) {
   FOLEY_LAUNCH(rows_to_planes_kernel, dim3(grid1d((long)B * T * C, 256)), dim3(256), 0, st, rows, B, T, C, out);
   FOLEY_LAUNCH_CHECK();

@@ -36,6 +36,7 @@ class _Engine:
         self.mats: Dict[str, Tensor] = {}
         self.vecs: Dict[str, Tensor] = {}
         self.ones: Dict[int, Tensor] = {}
+        self.tabs: Dict = {}
 
     def mat(self, key: str, w: Tensor) -> Tensor:
         t = self.mats.get(key)
@@ -97,6 +98,22 @@ class _Engine:
         b = self.vec(bkey, sd[bkey]) if bkey else None
         rt.op_gemm(a, W, b, out0=x, epilogue=rt.EPI_GATE_RES, rb=rt.rowbcast(self.one(W.shape[0]), 0), ksplit=1)
 
+    def index(self, key, build) -> Tensor:
+        """int32 index table on the device, built once per (shape) key by `build()` (a CPU / torch expression)."""
+        t = self.tabs.get(key)
+        if t is None:
+            t = self.tabs[key] = build().to(self.dev, torch.int32).contiguous()
+        return t
+
+    def attention_regrouped(self, qkv: Tensor, heads: int, idx_q: Tensor, idx_kv: Tensor) -> Tensor:
+        """Attention straight from a fused projection qkv [rows, 3*H*64]: ONE regroup launch (foley_op_qkv_regroup: head split,
+        token gather per group, transposed V for the 16-bit kernels) + the attention -> [G, Sq, H*64] token-major."""
+        q, k, v = rt.op_qkv_regroup(qkv, heads, idx_q, idx_kv)
+        G, H, Sq, hd = q.shape
+        out = torch.empty(G, Sq, H * hd, device=self.dev, dtype=self.dtype)
+        rt.op_attention(q, k, v, out, out, 0)
+        return out
+
     def attention(self, q: Tensor, k: Tensor, v: Tensor) -> Tensor:
         """q [G, H, Sq, 64], k / v [G, H, Skv, 64] (compute dtype; any strides) -> [G, Sq, H*64] token-major."""
         G, H, Sq, hd = q.shape
@@ -123,19 +140,27 @@ def _split_heads(qkv: Tensor, B: int, N: int, heads: int = HEADS):
 def _divided_attention(E: _Engine, h: Tensor, sd: SD, key: str, B: int, frames: int, space: int, over: str) -> Tensor:
     """vit_helper.DividedAttention (vit_helper.py:37-105) on the engine: h [B*N, D] (normed tokens, compute dtype) ->
     attention output [B*N, D] before the projection.  The CLS query attends to every token; patch tokens attend, with
-    the CLS key / value prepended, across the frames of their location (over='time') or the locations of their frame."""
+    the CLS key / value prepended, across the frames of their location (over='time') or the locations of their frame.
+    The token grouping is an index table (built once per shape) consumed by foley_op_qkv_regroup - no torch copies."""
     N = 1 + frames * space
-    q, k, v = _split_heads(E.linear(h, sd, key + ".qkv.weight", key + ".qkv.bias"), B, N)     # [B, H, N, 64]
-    cls_out = E.attention(q[:, :, :1], k, v)                                                    # [B, 1, D]
+    qkv = E.linear(h, sd, key + ".qkv.weight", key + ".qkv.bias")                               # [B*N, 3*H*64]
+    base = lambda: (torch.arange(B) * N)[:, None]
+    all_rows = E.index(("all", B, N), lambda: base() + torch.arange(N)[None])                   # [B, N]
+    cls_rows = E.index(("cls", B, N), lambda: base().clone())                                   # [B, 1]
+    cls_out = E.attention_regrouped(qkv, HEADS, cls_rows, all_rows)                             # [B, 1, D]
     if over == "time":      # groups = (batch, location), sequence = frames
-        grp = lambda t: t[:, :, 1:].reshape(B, HEADS, frames, space, HD).permute(0, 3, 1, 2, 4).reshape(B * space, HEADS, frames, HD)
-        G = space
+        def build():
+            tok = 1 + torch.arange(frames)[None, :] * space + torch.arange(space)[:, None]     # [space, frames]
+            return ((torch.arange(B) * N)[:, None, None] + tok[None]).reshape(B * space, frames)
     else:                   # groups = (batch, frame), sequence = locations
-        grp = lambda t: t[:, :, 1:].reshape(B, HEADS, frames, space, HD).permute(0, 2, 1, 3, 4).reshape(B * frames, HEADS, space, HD)
-        G = frames
-    ck = k[:, None, :, :1].expand(B, G, HEADS, 1, HD).reshape(B * G, HEADS, 1, HD)
-    cv = v[:, None, :, :1].expand(B, G, HEADS, 1, HD).reshape(B * G, HEADS, 1, HD)
-    out = E.attention(grp(q), torch.cat((ck, grp(k)), dim=2), torch.cat((cv, grp(v)), dim=2))  # [B*G, s, D]
+        def build():
+            tok = 1 + torch.arange(frames)[:, None] * space + torch.arange(space)[None, :]     # [frames, space]
+            return ((torch.arange(B) * N)[:, None, None] + tok[None]).reshape(B * frames, space)
+    G = space if over == "time" else frames
+    iq = E.index((over, "q", B, frames, space), build)
+    ikv = E.index((over, "kv", B, frames, space),
+                  lambda: torch.cat(((torch.arange(B) * N).repeat_interleave(G)[:, None], build()), dim=1))   # CLS key / value first
+    out = E.attention_regrouped(qkv, HEADS, iq, ikv)                                            # [B*G, s, D]
     D = HEADS * HD
     if over == "time":
         out = out.view(B, space, frames, D).permute(0, 2, 1, 3)
@@ -182,9 +207,9 @@ def synchformer_segments_hip(sd: SD, x: Tensor, dtype: torch.dtype = torch.float
     G, L = S * frames, 1 + space
     y = torch.cat((sd[a_ + ".cls_token"].to(E.dev, torch.float32).expand(G, -1, -1), normed.view(G, space, D)), dim=1)
     y = y.reshape(G * L, D).contiguous()
-    q, k, v = _split_heads(E.linear(E.ln(y, sd, a_ + ".norm1"), sd, a_ + ".self_attn.in_proj_weight",
-                                    a_ + ".self_attn.in_proj_bias"), G, L)
-    att = E.attention(q, k, v).reshape(G * L, D)
+    rows = E.index(("all", G, L), lambda: (torch.arange(G) * L)[:, None] + torch.arange(L)[None])
+    att = E.attention_regrouped(E.linear(E.ln(y, sd, a_ + ".norm1"), sd, a_ + ".self_attn.in_proj_weight", a_ + ".self_attn.in_proj_bias"),
+                                HEADS, rows, rows).reshape(G * L, D)
     E.linear_residual(y, att, sd, a_ + ".self_attn.out_proj.weight", a_ + ".self_attn.out_proj.bias")
     hid = E.linear(E.ln(y, sd, a_ + ".norm2"), sd, a_ + ".linear1.weight", a_ + ".linear1.bias", act="gelu_erf")
     E.linear_residual(y, hid, sd, a_ + ".linear2.weight", a_ + ".linear2.bias")
@@ -253,8 +278,8 @@ def siglip_image_features_hip(sd: SD, pixels: Tensor, dtype: torch.dtype = torch
         l = f"{p}encoder.layers.{i}"
         h = E.ln(x, sd, l + ".layer_norm1", eps)
         fq = E.fused(sd, l + ".self_attn.qkv#", [l + f".self_attn.{n}_proj.weight" for n in "qkv"], [l + f".self_attn.{n}_proj.bias" for n in "qkv"])
-        q, k, v = _split_heads(E.linear(h, fq, l + ".self_attn.qkv#.w", l + ".self_attn.qkv#.b"), B, N, heads)      # one [B*N, 3*D] projection
-        att = E.attention(q, k, v).reshape(B * N, D)
+        rows = E.index(("all", B, N), lambda: (torch.arange(B) * N)[:, None] + torch.arange(N)[None])
+        att = E.attention_regrouped(E.linear(h, fq, l + ".self_attn.qkv#.w", l + ".self_attn.qkv#.b"), heads, rows, rows).reshape(B * N, D)   # one [B*N, 3*D] projection
         E.linear_residual(x, att, sd, l + ".self_attn.out_proj.weight", l + ".self_attn.out_proj.bias")
         hid = E.linear(E.ln(x, sd, l + ".layer_norm2", eps), sd, l + ".mlp.fc1.weight", l + ".mlp.fc1.bias", act="gelu_tanh")
         E.linear_residual(x, hid, sd, l + ".mlp.fc2.weight", l + ".mlp.fc2.bias")

@@ -91,7 +91,7 @@ class ProfEntryC(C.Structure):
 
 
 PROGRESS_CB = C.CFUNCTYPE(None, C.c_int32, C.c_int32, C.c_void_p)
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _SIGNATURES = {
     "foley_abi_version": (C.c_uint32, []),
@@ -129,6 +129,8 @@ _SIGNATURES = {
                                            C.POINTER(RowBcastC), C.c_void_p]),
     "foley_op_ln_mod": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.POINTER(RowBcastC),
                                   C.POINTER(RowBcastC), C.c_void_p, C.c_int, C.c_void_p]),
+    "foley_op_qkv_regroup": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "foley_op_qkv_split": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
                                      C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -498,6 +500,25 @@ def op_attention(q, k, v, outA, outB, split: int, kv_bdiv: int = 1):
     vt_pitch = v.shape[3] if q.dtype in (torch.bfloat16, torch.float16) else 0
     _check(lib, lib.foley_op_attention_hd(_ptr(q), _ptr(k), _ptr(v), dt_of(q), vt_pitch, Bq, H, Sq, Skv, kv_bdiv,
                                           _ptr(outA), _ptr(outB), split, dt_of(outB), hd, _stream()), "foley_op_attention_hd")
+
+
+def op_qkv_regroup(qkv: torch.Tensor, heads: int, idx_q: torch.Tensor, idx_kv: torch.Tensor):
+    """qkv [rows, 3*heads*64] (fp32 / bf16 / fp16) -> (q [G,H,Sq,64], k [G,H,Skv,64], v): v [G,H,Skv,64] for fp32 operands, v
+    TRANSPOSED [G,H,64,ceil32(Skv)] (zeros beyond Skv) for 16-bit operands - what op_attention reads.  idx_q [G,Sq] / idx_kv [G,Skv]
+    int32 source rows on the device."""
+    lib = load_library()
+    G, Sq = idx_q.shape
+    Skv = idx_kv.shape[1]
+    if qkv.shape[1] != 3 * heads * 64 or idx_kv.shape[0] != G or idx_q.dtype != torch.int32 or idx_kv.dtype != torch.int32:
+        raise FoleyRuntimeError("op_qkv_regroup: qkv [rows, 3*H*64], int32 index tables with one row per group")
+    half = qkv.dtype in (torch.bfloat16, torch.float16)
+    pitch = (Skv + 31) // 32 * 32 if half else 0
+    q = torch.empty(G, heads, Sq, 64, device=qkv.device, dtype=qkv.dtype)
+    k = torch.empty(G, heads, Skv, 64, device=qkv.device, dtype=qkv.dtype)
+    v = torch.empty((G, heads, 64, pitch) if half else (G, heads, Skv, 64), device=qkv.device, dtype=qkv.dtype)
+    _check(lib, lib.foley_op_qkv_regroup(_ptr(qkv), dt_of(qkv), heads, _ptr(idx_q), G, Sq, _ptr(idx_kv), Skv, _ptr(q), _ptr(k), _ptr(v),
+                                         pitch, _stream()), "foley_op_qkv_regroup")
+    return q, k, v
 
 
 def op_ln_mod(x, eps, shift: Optional[RowBcastC], scale: Optional[RowBcastC], out):

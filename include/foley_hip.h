@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FOLEY_ABI_VERSION 9   /* 9: foley_bcast_local (single-process grouped broadcast of the arenas); 8: foley_qkv_split_desc.attn_* (cross attention in the epilogue of its q projection), foley_abort / FOLEY_ERR_ABORTED; 7: FOLEY_DT_F16 as a compute dtype (foley_config.compute_dtype, op descriptors); 6: foley_rowbcast.Ls (mode 2: nearest-exact up-sampled operand); 5: reference-keyed loading (foley_weights_*, foley_load_tensor, foley_bcast_weights); 4: fp8 weight storage (dtype codes 3/4, foley_gemm_desc.ldw/.wfmt); 3: foley_profile_forward; 2: foley_gemm_desc gained partials / qkv / rstride; foley_op_ln_mod_pending, foley_dac_encode */
+#define FOLEY_ABI_VERSION 10   /* 10: foley_op_qkv_regroup (token regrouping of the conditioning encoders' attention); 9: foley_bcast_local (single-process grouped broadcast of the arenas); 8: foley_qkv_split_desc.attn_* (cross attention in the epilogue of its q projection), foley_abort / FOLEY_ERR_ABORTED; 7: FOLEY_DT_F16 as a compute dtype (foley_config.compute_dtype, op descriptors); 6: foley_rowbcast.Ls (mode 2: nearest-exact up-sampled operand); 5: reference-keyed loading (foley_weights_*, foley_load_tensor, foley_bcast_weights); 4: fp8 weight storage (dtype codes 3/4, foley_gemm_desc.ldw/.wfmt); 3: foley_profile_forward; 2: foley_gemm_desc gained partials / qkv / rstride; foley_op_ln_mod_pending, foley_dac_encode */
 
 enum foley_dtype {
   FOLEY_DT_F32 = 0, FOLEY_DT_BF16 = 1, FOLEY_DT_I32 = 2,
@@ -261,6 +261,14 @@ int foley_op_attention(const void* q, const void* k, const void* v, int in_dtype
 int foley_op_attention_hd(const void* q, const void* k, const void* v, int in_dtype, int vt_pitch, int Bq, int H,
                           int Sq, int Skv, int kv_bdiv, void* outA, void* outB, int split, int out_dtype,
                           int head_dim, void* stream);
+/* Token regrouping between a fused q/k/v projection and foley_op_attention_hd at head_dim 64 - the conditioning encoders
+ * (reference models/synchformer/vit_helper.py:37-105 DividedAttention: patch tokens attend over the frames of their location or
+ * the locations of their frame with the CLS key / value prepended; transformers' SiglipAttention / ClapTextSelfAttention head split):
+ * qkv [rows, 3*H*64] in nn.Linear(dim, 3*dim)'s (K H D) packing; group g reads source rows idx_q[g*Sq + t] as its queries and
+ * idx_kv[g*Skv + t] as its keys / values and writes q [G,H,Sq,64], k [G,H,Skv,64] and v [G,H,Skv,64] (vt_pitch 0) or - 16-bit
+ * operands - v TRANSPOSED [G,H,64,vt_pitch] with zeros beyond Skv (vt_pitch a multiple of 8 in [Skv, ceil64(Skv)]). */
+int foley_op_qkv_regroup(const void* qkv, int dtype, int H, const int32_t* idx_q, int G, int Sq, const int32_t* idx_kv, int Skv,
+                         void* q, void* k, void* v, int vt_pitch, void* stream);
 int foley_op_ln_mod(const float* x, int M, int D, float eps, const foley_rowbcast* shift,
                     const foley_rowbcast* scale, void* out, int out_dtype, void* stream);
 /* LayerNorm (+ modulation) of a residual stream that first receives the pending update of a deferred

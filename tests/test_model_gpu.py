@@ -901,6 +901,8 @@ def test_bench_single_rank_forced_dist(dev):
     out = json.loads(r.stdout)
     assert out["n_gpus"] == 1 and out["config"]["collectives"] == 1 and out["value"] > 0
     assert out["roofline"]["kernels"] and out["roofline"]["frac"] > 0
+    assert out["config"]["rccl_nranks"] == 1 and out["config"]["backend"] == "nccl" and len(out["config"]["ranks"]) == 1
+    assert out["config"]["ranks"][0]["clips"] == 1 and out["config"]["ranks"][0]["uuid"]
 
 
 def test_denoise_process_multi_shards_the_batch(tiny, dev):
@@ -1055,6 +1057,11 @@ def test_bench_two_ranks_sharing_one_gpu(dev):
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["config"]["collectives"] == 1 and out["config"]["clips_per_gpu"] == 2
     assert out["config"]["workload"].startswith("c4") and out["value"] > 0 and out["config"]["broadcast_s"] > 0
+    # the per-rank evidence of a multi-rank line: the communicator's size and every rank's own record, all-gathered
+    ranks = out["config"]["ranks"]
+    assert out["config"]["rccl_nranks"] == 2 and out["config"]["backend"] == "gloo"
+    assert [r_["rank"] for r_ in ranks] == [0, 1] and [r_["shard"] for r_ in ranks] == [[0, 2], [2, 4]]
+    assert all(r_["clips"] == 2 and r_["pass_ms"] > 0 and r_["loop_ms"] > 0 and r_["uuid"] for r_ in ranks)
 
 
 def test_v2a_node_with_image_input(dev):

@@ -756,3 +756,28 @@ def test_dac_out(dev):
     out = torch.empty(B, 1, T, device=dev)
     rt.op_dac_out(s.to(dev), w[0].permute(1, 0).reshape(-1).contiguous().to(dev), b.to(dev), out)
     assert rel_err(out, ref) < 2e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("G,H,Sq,Skv,rows", [(3, 12, 8, 9, 40), (2, 12, 1, 197, 400), (5, 4, 196, 197, 1000), (1, 12, 130, 130, 130)])
+def test_qkv_regroup(dev, dtype, G, H, Sq, Skv, rows):
+    """foley_op_qkv_regroup (the conditioning encoders' token regrouping: vit_helper.py:37-105 DividedAttention's rearranges + CLS
+    prepend, the HF encoders' head split) against the torch expression it replaces: exact copies; 16-bit operands get V transposed
+    with a zero pad up to ceil32(Skv).  Lengths off the 64-token tile, Sq != Skv, a single query, repeated source rows."""
+    from foley_amd.host import runtime as rt
+    g = torch.Generator().manual_seed(G * 1000 + Sq)
+    qkv = torch.randn(rows, 3 * H * 64, generator=g).to(dtype).to(dev)
+    iq = torch.randint(0, rows, (G, Sq), generator=g, dtype=torch.int32).to(dev)
+    ikv = torch.randint(0, rows, (G, Skv), generator=g, dtype=torch.int32).to(dev)
+    q, k, v = rt.op_qkv_regroup(qkv, H, iq, ikv)
+    t = qkv.view(rows, 3, H, 64)
+    want_q = t[iq.long(), 0].permute(0, 2, 1, 3)          # [G, H, Sq, 64]
+    want_k = t[ikv.long(), 1].permute(0, 2, 1, 3)
+    want_v = t[ikv.long(), 2].permute(0, 2, 1, 3)
+    assert torch.equal(q, want_q) and torch.equal(k, want_k)
+    if dtype == torch.float32:
+        assert torch.equal(v, want_v)
+    else:
+        pitch = (Skv + 31) // 32 * 32
+        assert v.shape == (G, H, 64, pitch)
+        assert torch.equal(v[..., :Skv], want_v.transpose(2, 3)) and not bool(v[..., Skv:].any())
