@@ -879,6 +879,187 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_long_kernel(const AttnArgs a
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 5 - bf16 / fp16, LONG sequences on small grids, KEY-SPLIT WAVE PAIRS.  The kernel above runs 1.3 waves per SIMD (336
+// workgroups of 128 queries on 256 CUs, 1.3 rounds of them on the busiest CUs) and its time is one wave's chain: per 64 keys a
+// wave needs ~1000 matrix-pipe cycles AND ~1500 cycles of softmax VALU work (exponentials, maxima, packing) that nothing
+// overlaps.  Here a workgroup covers NQ = 4 / 5 / 6 blocks of 32 queries - chosen per problem so that ALL workgroups fit one
+// round of 256 CUs (S = 1740: 10 x 24 tiles of 192 queries, S = 1500: 10 x 24 tiles of 160) - and every query block is served
+// by TWO waves that split each staged 64-key tile (keys 0..31 / 32..63): 8 - 12 waves per CU = 2 - 3 per SIMD, so one wave's
+// softmax VALU runs under another wave's MFMAs, K / V^T are read from L2 once per 128 - 192 queries, and the halves' softmax
+// states (m, l, O) are merged once at the end through the dead staging buffers.  Per wave the loop body is the wide kernel's
+// 32-key step.  Same operand layout, staging and output mapping as attn_bf16_long_kernel.
+template <typename T, typename OutT, int NQ>
+__global__ __launch_bounds__(NQ * 128) void attn_bf16_pair_kernel(const AttnArgs a) {
+  constexpr int HD = 128, KT = 64, NTH = NQ * 128;
+  constexpr int KP = 2 * HD + 16, VP = 2 * KT + 16;      // LDS row pitches in bytes (K rows: 272, V^T rows: 144)
+  constexpr int STG = KT * KP + HD * VP;                 // one stage: K tile + V^T tile = 35 840 B
+  constexpr int NS = HD / 16, ND = HD / 32;
+  constexpr int NPC = (1024 + NTH - 1) / NTH;            // staging pieces per thread and operand (K tile = V^T tile = 1024 pieces of 16 B)
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qb = w % NQ, kh2 = w / NQ;                   // query block, key half of every staged tile
+  const int j = lane & 31, kh = lane >> 5;
+  int qt, h, b;
+  attn_block_coords(a, 32 * NQ, qt, h, b);
+  const int q0 = qt * (32 * NQ) + qb * 32;
+  const int bk = b / a.kv_bdiv;
+  const T* __restrict__ Q = (const T*)a.q + ((long)(b * a.H + h) * a.Sq) * HD;
+  const T* __restrict__ K = (const T*)a.k + ((long)(bk * a.H + h) * a.Skv) * HD;
+  const T* __restrict__ VT = (const T*)a.v + ((long)(bk * a.H + h) * HD) * a.vt_pitch;
+  const float scale2 = 0.08838834764831845f * 1.4426950408889634f;   // log2(e) / sqrt(128)
+
+  bf16x8 qf[NS];
+  {
+    const T* p = Q + (long)min(q0 + j, a.Sq - 1) * HD + 8 * kh;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) qf[s] = *(const bf16x8*)(p + 16 * s);
+  }
+  f32x16 o[ND];
+#pragma unroll
+  for (int d = 0; d < ND; ++d)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int vmax = a.vt_pitch - 8;                       // last 16-byte chunk of a V^T row (the pitch covers Skv rounded up to 32, not to 64)
+  u32x4 rk[NPC], rv[NPC];
+  auto gload = [&](int t) {
+    const int kt = t * KT;
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+      const int p = tid + i * NTH;
+      if (p < 1024) {                                    // wave-uniform (NTH and 1024 are multiples of 64)
+        rk[i] = *(const u32x4*)(K + (long)min(kt + (p >> 4), a.Skv - 1) * HD + (p & 15) * 8);
+        rv[i] = *(const u32x4*)(VT + (long)(p >> 3) * a.vt_pitch + min(kt + (p & 7) * 8, vmax));   // clamped chunks carry masked (p = 0) keys
+      }
+    }
+  };
+  auto lstore = [&](int stage) {
+    unsigned char* base = lds + stage * STG;
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+      const int p = tid + i * NTH;
+      if (p < 1024) {
+        *(u32x4*)(base + (p >> 4) * KP + (p & 15) * 16) = rk[i];
+        *(u32x4*)(base + KT * KP + (p >> 3) * VP + (p & 7) * 16) = rv[i];
+      }
+    }
+  };
+  const int nt = (a.Skv + KT - 1) / KT;
+  const int pi = 16 * ((j >> 2) & 1) + (j & 3) + 4 * (j >> 3);  // A-row j of a 32-key score tile carries key pi
+  f32x16 s;                                       // raw scores of this wave's 32 keys of a tile
+  auto qk = [&](int stg) {                        // s[e] = score(key 64 t + 32 kh2 + 16 kh + e, query q0 + j), tile t staged in buffer `stg`
+    const unsigned char* Ks = lds + stg * STG + (32 * kh2) * KP;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int st = 0; st < NS; ++st) s = mfma16<T>(*(const bf16x8*)(Ks + pi * KP + (16 * st + 8 * kh) * 2), qf[st], s);
+  };
+  auto softmax_pv = [&](int t, int stg) {         // online softmax of s (tile t) in the log2 domain (scale2 > 0 commutes with the maximum), then O += V^T P
+    const int kt = t * KT + 32 * kh2;
+    const unsigned char* Vs = lds + stg * STG + KT * KP + (32 * kh2) * 2;
+    if (kt + 32 > a.Skv) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[e] = (kt + 16 * kh + e < a.Skv) ? s[e] : -INFINITY;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[e]);
+    mx = xhalf_max(mx);
+    const float m_new = fmaxf(m_run, mx * scale2);
+    float ps = 0.f;
+    bf16x8 pb[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], scale2, -m_new));
+      ps += pv;
+      pb[e >> 3][e & 7] = to_carrier<T>(pv);
+    }
+    ps = xhalf_sum(ps);
+    if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {   // the 64 accumulator rescales only when some query's maximum moved
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // exp2(-inf) = 0 on the first tile
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+    }
+    l_run += ps;
+    m_run = m_new;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int d = 0; d < ND; ++d)
+        o[d] = mfma16<T>(*(const bf16x8*)(Vs + (d * 32 + j) * VP + (16 * kh + 8 * u) * 2), pb[u], o[d]);
+  };
+  // All waves walk the tiles in lock step (one barrier per tile).  Running the two key halves HALF AN ITERATION APART (second half:
+  // softmax(t-1) -> PV(t-1) -> QK(t), three staging buffers) so that one half multiplies while the other exponentiates was built
+  // and measured: 72.6 / 72.2 us against 62.4 / 52.7 - the rotated loop keeps two score tiles live and spills at the 168-register
+  // cap; an s_sleep skew of the second half: 65.7 / 55.3.
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) gload(t + 1);               // next tile's global loads fly during this tile's math
+    if (t * KT + 32 * kh2 < a.Skv) {            // wave-uniform: the second half of the last tile may hold no key at all
+      qk(t & 1);
+      softmax_pv(t, t & 1);
+    }
+    if (t + 1 < nt) {
+      lstore((t + 1) & 1);                      // stage (t+1)&1 was last read in iteration t-1: every wave passed the barrier below since
+      __syncthreads();
+    }
+  }
+  // ---- merge the two key halves of every query block through the dead staging buffers: the second-half wave publishes its
+  // (m, l, O) lane-major (16.5 KiB per query block: the launcher sizes the LDS for max(two staging buffers, NQ records)), the first-half wave
+  // folds them in and stores.  A half that saw no key publishes m = -inf, l = 0, O = 0: weight exp2(-inf) = 0.
+  __syncthreads();
+  float* xm = (float*)lds + qb * (66 * 64);
+  if (kh2 == 1) {
+    xm[lane] = m_run;
+    xm[64 + lane] = l_run;
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const f32x4 t4 = {o[d][4 * v], o[d][4 * v + 1], o[d][4 * v + 2], o[d][4 * v + 3]};
+        *(f32x4*)(xm + 128 + ((d * 4 + v) * 64 + lane) * 4) = t4;
+      }
+  }
+  __syncthreads();
+  if (kh2 == 1) return;
+  {
+    const float m_b = xm[lane], l_b = xm[64 + lane];
+    const float m = fmaxf(m_run, m_b);
+    const float fa = __builtin_amdgcn_exp2f(m_run - m), fb = __builtin_amdgcn_exp2f(m_b - m);
+    l_run = l_run * fa + l_b * fb;
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const f32x4 t4 = *(const f32x4*)(xm + 128 + ((d * 4 + v) * 64 + lane) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[d][4 * v + e] = o[d][4 * v + e] * fa + t4[e] * fb;
+      }
+  }
+  const int tok = q0 + j;
+  if (tok >= a.Sq) return;
+  const float inv = 1.0f / l_run;
+  OutT* dst;
+  if (tok < a.split) dst = (OutT*)a.outA + ((long)b * a.split + tok) * (a.H * HD);
+  else dst = (OutT*)a.outB + ((long)b * (a.Sq - a.split) + (tok - a.split)) * (a.H * HD);
+  dst += h * HD;
+#pragma unroll
+  for (int d = 0; d < ND; ++d)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const f32x4 v = {o[d][g4 * 4 + 0] * inv, o[d][g4 * 4 + 1] * inv, o[d][g4 * 4 + 2] * inv, o[d][g4 * 4 + 3] * inv};
+      Pack4Out<OutT>::store(dst + d * 32 + 8 * g4 + 4 * kh, v);
+    }
+}
+
 }  // namespace
 
 static long long* g_attn_dbg = nullptr;
@@ -908,6 +1089,18 @@ int launch_attention(const AttnArgs& a_in, int out_dtype, hipStream_t st) {
     // FOLEY_ATTN_LONG=0 keeps the 32-key form)
     static const bool long_on = []() { const char* e = getenv("FOLEY_ATTN_LONG"); return !(e && e[0] == '0'); }();
     const bool longk = long_on && wide && hd == 128 && a.Skv >= 512 && (long)gw.x * 4 <= 2048;
+    // ... and where 128 / 160 / 192-query workgroups of key-split wave pairs cover the problem in ONE round of 256 CUs, that form
+    // (attn_bf16_pair_kernel; FOLEY_ATTN_PAIR=0 keeps the 64-key chain): the largest workgroup count <= 256 wins
+    static const bool pair_on = []() { const char* e = getenv("FOLEY_ATTN_PAIR"); return !(e && e[0] == '0'); }();
+    int pair_nq = 0;
+    if (pair_on && longk) {
+      long best = 0;
+      for (int nq = 6; nq >= 4; --nq) {
+        const long wgs = (long)((a.Sq + 32 * nq - 1) / (32 * nq)) * a.H * a.Bq;
+        if (wgs <= 256 && wgs > best) { best = wgs; pair_nq = nq; }
+      }
+      if (best < 160) pair_nq = 0;              // too few workgroups: the chain kernel's two per CU do better
+    }
     // small grids whose operands fit the LDS: the DMA-staged form (FOLEY_ATTN_LDS=0 keeps the register-loaded kernel)
     static const bool lds_on = []() { const char* e = getenv("FOLEY_ATTN_LDS"); return !(e && e[0] == '0'); }();
     const int nt = (a.Skv + 31) >> 5;
@@ -923,6 +1116,15 @@ int launch_attention(const AttnArgs& a_in, int out_dtype, hipStream_t st) {
         hipError_t e_ = foley_raise_lds((const void*)attn_lds_kernel<T, O>, 160 * 1024, raised);     \
         if (e_ != hipSuccess) return foley_set_err(hipGetErrorString(e_), __FILE__, __LINE__);       \
         FOLEY_LAUNCH((attn_lds_kernel<T, O>), grid1, dim3(256), lds16, st, a, merge_off);            \
+      } else                                                                                         \
+      if (pair_nq) {                                                                                 \
+        static std::atomic<unsigned long long> r4{0}, r5{0}, r6{0};                                  \
+        const dim3 gp(((a.Sq + 32 * pair_nq - 1) / (32 * pair_nq)) * a.H * a.Bq);                    \
+        hipError_t e_ = hipSuccess;                                                                  \
+        if (pair_nq == 6) { e_ = foley_raise_lds((const void*)attn_bf16_pair_kernel<T, O, 6>, 6 * 16896, r6); if (e_ == hipSuccess) FOLEY_LAUNCH((attn_bf16_pair_kernel<T, O, 6>), gp, dim3(768), 6 * 16896, st, a); } \
+        else if (pair_nq == 5) { e_ = foley_raise_lds((const void*)attn_bf16_pair_kernel<T, O, 5>, 5 * 16896, r5); if (e_ == hipSuccess) FOLEY_LAUNCH((attn_bf16_pair_kernel<T, O, 5>), gp, dim3(640), 5 * 16896, st, a); } \
+        else { e_ = foley_raise_lds((const void*)attn_bf16_pair_kernel<T, O, 4>, 2 * 35840, r4); if (e_ == hipSuccess) FOLEY_LAUNCH((attn_bf16_pair_kernel<T, O, 4>), gp, dim3(512), 2 * 35840, st, a); } \
+        if (e_ != hipSuccess) return foley_set_err(hipGetErrorString(e_), __FILE__, __LINE__);       \
       } else                                                                                         \
       if (longk) {                                                                                   \
         static std::atomic<unsigned long long> raised{0};                                            \
