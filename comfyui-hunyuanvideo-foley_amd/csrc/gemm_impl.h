@@ -539,6 +539,10 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
   g.dbg = g_gemm_dbg;
   g.dbg_mode = g_gemm_dbg_mode;
   g.pf_dist = g_gemm_pf_dist;
+  {  // round 5: K-range-major workgroup order for the wave-specialised split-K tiles (FOLEY_KS_MAJOR=0: range fastest)
+    static const int ksm = []() { const char* e = getenv("FOLEY_KS_MAJOR"); return (e && e[0] == '0') ? 0 : 1; }();
+    g.ks_major = ksm;
+  }
   if (g.ldw <= 0) g.ldw = g.K;
   GemmArgs g1s;
   const GemmArgs* g1 = nullptr;
@@ -547,6 +551,7 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     g1s = *g1_in;
     g1s.dbg = nullptr;
     g1s.pf_dist = g_gemm_pf_dist;
+    g1s.ks_major = g.ks_major;
     if (g1s.ldw <= 0) g1s.ldw = g1s.K;
     g1 = &g1s;
   }

@@ -80,8 +80,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_wide_kernel(const GemmPair pr) {
   }
   int ks = 0;
   if constexpr (EPI == EPI_GATE_RES) {
-    ks = bid % g.ksplit;
-    bid /= g.ksplit;
+    if (g.ks_major) {   // K-range-major order: only the one or two XCDs that run a range fetch its activation columns (gemm_ws_impl.h)
+      const int tiles = tiles_m * tiles_n;
+      ks = bid / tiles;
+      bid -= ks * tiles;
+    } else {
+      ks = bid % g.ksplit;
+      bid /= g.ksplit;
+    }
   }
   const int tm = bid % tiles_m, tn = bid / tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;

@@ -127,8 +127,17 @@ __device__ __forceinline__ void gemm_ws_body(const GemmPair& pr) {
   }
   int ks = 0;
   if constexpr (EPI == EPI_GATE_RES) {
-    ks = bid % g.ksplit;
-    bid /= g.ksplit;
+    // K-range-major order (round 5): the XCD remap above hands consecutive ids to one XCD, so all tiles of a K range sit on one or
+    // two XCDs and only those L2s fetch the range's activation columns (range-fastest order: every XCD fetches ALL of A - 8 x 4 MB
+    // of fabric reads per w2 launch against 4 MB of activations)
+    if (g.ks_major) {
+      const int tiles = tiles_m * tiles_n;
+      ks = bid / tiles;
+      bid -= ks * tiles;
+    } else {
+      ks = bid % g.ksplit;
+      bid /= g.ksplit;
+    }
   }
   const int tm = bid % tiles_m, tn = bid / tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
@@ -530,8 +539,17 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_conv3_kernel(cons
   }
   int ks = 0;
   if constexpr (EPI == EPI_GATE_RES) {
-    ks = bid % g.ksplit;
-    bid /= g.ksplit;
+    // K-range-major order (round 5): the XCD remap above hands consecutive ids to one XCD, so all tiles of a K range sit on one or
+    // two XCDs and only those L2s fetch the range's activation columns (range-fastest order: every XCD fetches ALL of A - 8 x 4 MB
+    // of fabric reads per w2 launch against 4 MB of activations)
+    if (g.ks_major) {
+      const int tiles = tiles_m * tiles_n;
+      ks = bid / tiles;
+      bid -= ks * tiles;
+    } else {
+      ks = bid % g.ksplit;
+      bid /= g.ksplit;
+    }
   }
   const int tm = bid % tiles_m, tn = bid / tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
@@ -755,8 +773,17 @@ __global__ __launch_bounds__(768) void gemm_ws_conv3_ks_kernel(const GemmPair pr
   }
   int ks = 0;
   if constexpr (EPI == EPI_GATE_RES) {
-    ks = bid % g.ksplit;
-    bid /= g.ksplit;
+    // K-range-major order (round 5): the XCD remap above hands consecutive ids to one XCD, so all tiles of a K range sit on one or
+    // two XCDs and only those L2s fetch the range's activation columns (range-fastest order: every XCD fetches ALL of A - 8 x 4 MB
+    // of fabric reads per w2 launch against 4 MB of activations)
+    if (g.ks_major) {
+      const int tiles = tiles_m * tiles_n;
+      ks = bid / tiles;
+      bid -= ks * tiles;
+    } else {
+      ks = bid % g.ksplit;
+      bid /= g.ksplit;
+    }
   }
   const int tm = bid % tiles_m, tn = bid / tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;

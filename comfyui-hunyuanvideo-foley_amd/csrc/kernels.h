@@ -88,6 +88,8 @@ struct GemmArgs {
                       // the LayerNorm; the sum of k rounded partials carries about the error of ONE rounding of the total
   long partial_stride;
   int partial_cap;
+  int ks_major;       // set by the launcher: workgroup order of a split - 1: K range slowest (all tiles of a range are neighbours, i.e. on
+                      // one or two XCDs: only those L2s fetch that range's activation columns), 0: K range fastest
   QkvSplitArgs qs;    // EPI_QKV_SPLIT: destination / norm / rotation description (qs.qkv, qs.M unused)
   int vec_out;        // set by the launcher: the problem qualifies for the LDS-transposed vector epilogue
   int wfmt;           // storage of W: 0 = the operand dtype, 1 = fp8 e4m3fn, 2 = fp8 e5m2 (bf16 activations; wave-specialised
