@@ -542,6 +542,7 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
   {  // round 5: K-range-major workgroup order for the wave-specialised split-K tiles (FOLEY_KS_MAJOR=0: range fastest)
     static const int ksm = []() { const char* e = getenv("FOLEY_KS_MAJOR"); return (e && e[0] == '0') ? 0 : 1; }();
     g.ks_major = ksm;
+    g.n_groups = 0;   // decided below, once the tile is known
   }
   if (g.ldw <= 0) g.ldw = g.K;
   GemmArgs g1s;
@@ -552,6 +553,7 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     g1s.dbg = nullptr;
     g1s.pf_dist = g_gemm_pf_dist;
     g1s.ks_major = g.ks_major;
+    g1s.n_groups = 0;
     if (g1s.ldw <= 0) g1s.ldw = g1s.K;
     g1 = &g1s;
   }
@@ -775,6 +777,34 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     if (!ok && (tile == 21 || tile == 22 || tile == 23)) return foley_set_err("GEMM: conv3 operands exceed the 2 GiB buffer-offset range", __FILE__, __LINE__);
     if (!ok && (tile == 31 || tile == 32)) return foley_set_err("GEMM: the 256x256 tiles range every load against 32-bit buffer extents: operands exceed the 2 GiB buffer-offset range", __FILE__, __LINE__);
     if (!ok && ((tile >= 5 && tile <= 9) || tile == 15 || tile == 19 || tile == 25 || tile == 26 || tile == 27 || tile == 28 || tile == 29)) tile = (tile == 6) ? 3 : ((tile == 8 || tile == 27) ? 2 : 1);   // register-staged twins
+  }
+  {
+    // Large grids (several rounds of workgroups, activation panel larger than an L2): tile order [panel group][M tile][panel in group]
+    // (tile_coords, gemm_ws_impl.h) so that the ~32 workgroups an XCD runs at a time cover a near-square block of tiles - panels
+    // per group ~ sqrt(32 BM / BN) minimises the rows + columns the block pulls out of the fabric per K-slice.  Measured at
+    // bs = 8 (one box, both orders twice): q/k/v 85 -> 77 us, fc1 115 -> 111, loop 1459 -> 1436 ms (+1.6 %); C5 +1 %.
+    // FOLEY_TILE_GROUPS: unset = automatic, 0 = [panel][M tile] everywhere, n = n groups.
+    static const int ngr = []() { const char* e = getenv("FOLEY_TILE_GROUPS"); return e ? atoi(e) : -1; }();
+    int tbm = 0, tbn = 0;
+    switch (tile) {
+      case 15: case 25: case 21: tbm = 128; tbn = 128; break;
+      case 19: case 29: case 23: tbm = 256; tbn = 128; break;
+      case 28: tbm = 192; tbn = 128; break;
+      case 31: case 32: tbm = 256; tbn = 256; break;
+    }
+    g.n_groups = 0;
+    if (tbm && ngr != 0 && g.M >= 1536 && !g1) {
+      const long tm_ = (g.M + tbm - 1) / tbm, tn_ = (g.N + tbn - 1) / tbn;
+      if (tm_ * tn_ * (epi == EPI_GATE_RES ? g.ksplit : 1) > 256 && tn_ >= 2) {
+        if (ngr > 0) g.n_groups = ngr;
+        else {
+          int pg = 1;
+          while ((pg + 1) * (pg + 1) * tbn <= 32 * tbm) ++pg;   // floor(sqrt(32 BM / BN))
+          int n = (int)((tn_ + pg / 2) / pg);
+          g.n_groups = n < 1 ? 1 : n;
+        }
+      }
+    }
   }
   g.vec_out = gemm_vec_out_ok<T>(g, epi) ? 1 : 0;
   if (g1) g1s.vec_out = gemm_vec_out_ok<T>(g1s, epi) ? 1 : 0;

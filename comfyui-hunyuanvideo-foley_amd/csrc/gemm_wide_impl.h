@@ -89,7 +89,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_wide_kernel(const GemmPair pr) {
       bid /= g.ksplit;
     }
   }
-  const int tm = bid % tiles_m, tn = bid / tiles_m;
+  int tm, tn;
+  tile_coords(bid, tiles_m, tiles_n, g.n_groups, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -43,6 +43,34 @@ __device__ __forceinline__ void buf_lds16_aux(const void* base, unsigned bytes, 
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, AUX);
 }
 
+// logical tile id -> (tm, tn).  Default order [panel][M tile]: the M tiles of a weight panel are neighbours (one XCD after the remap).
+// Large grids (GemmArgs::n_groups > 0): [panel group][M tile][panel inside the group] - the ~32 workgroups an XCD runs at a time then
+// cover a near-square block (a few M tiles x the group's panels) instead of all M tiles of one or two panels, so that every line
+// the block pulls out of the fabric is shared by more of them.
+__device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int n_groups, int& tm, int& tn) {
+  if (n_groups <= 0 || n_groups > tiles_n) {
+    tm = id % tiles_m;
+    tn = id / tiles_m;
+    return;
+  }
+  const int P = tiles_n / n_groups, r = tiles_n % n_groups;   // the first r groups hold P + 1 panels
+  const int big = r * (P + 1) * tiles_m;
+  int pg, p0, local;
+  if (id < big) {
+    pg = P + 1;
+    const int gi = id / (pg * tiles_m);
+    local = id - gi * pg * tiles_m;
+    p0 = gi * pg;
+  } else {
+    pg = P;
+    const int i2 = id - big, gi = i2 / (pg * tiles_m);
+    local = i2 - gi * pg * tiles_m;
+    p0 = r * (P + 1) + gi * pg;
+  }
+  tm = local / pg;
+  tn = p0 + local - tm * pg;
+}
+
 // s_barrier the compiler may not move MFMAs across: they touch no memory, so nothing else orders them against the builtin (left
 // alone hipcc sank a whole MFMA block below the second barrier of the strict-alternation loops, see gemm_wide_impl.h)
 __device__ __forceinline__ void hard_barrier() {
@@ -139,7 +167,8 @@ __device__ __forceinline__ void gemm_ws_body(const GemmPair& pr) {
       bid /= g.ksplit;
     }
   }
-  const int tm = bid % tiles_m, tn = bid / tiles_m;
+  int tm, tn;
+  tile_coords(bid, tiles_m, tiles_n, g.n_groups, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: role branch, LDS piece addresses (m0) and tile offsets stay on the SALU
@@ -551,7 +580,8 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_conv3_kernel(cons
       bid /= g.ksplit;
     }
   }
-  const int tm = bid % tiles_m, tn = bid / tiles_m;
+  int tm, tn;
+  tile_coords(bid, tiles_m, tiles_n, g.n_groups, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   // scalar wave index (see gemm_ws_body) - except in the 256-row fp8 instantiations, which sit at the 168-register
@@ -785,7 +815,8 @@ __global__ __launch_bounds__(768) void gemm_ws_conv3_ks_kernel(const GemmPair pr
       bid /= g.ksplit;
     }
   }
-  const int tm = bid % tiles_m, tn = bid / tiles_m;
+  int tm, tn;
+  tile_coords(bid, tiles_m, tiles_n, g.n_groups, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -88,6 +88,8 @@ struct GemmArgs {
                       // the LayerNorm; the sum of k rounded partials carries about the error of ONE rounding of the total
   long partial_stride;
   int partial_cap;
+  int n_groups;       // set by the launcher, large grids: > 0 = tile order [column-panel group][M tile][panel inside the group] with this many
+                      // groups (the workgroups that run together then cover a near-square block of tiles); 0 = [panel][M tile]
   int ks_major;       // set by the launcher: workgroup order of a split - 1: K range slowest (all tiles of a range are neighbours, i.e. on
                       // one or two XCDs: only those L2s fetch that range's activation columns), 0: K range fastest
   QkvSplitArgs qs;    // EPI_QKV_SPLIT: destination / norm / rotation description (qs.qkv, qs.M unused)
