@@ -568,7 +568,8 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
   // tap-fused wave-specialised conv3 (tile 21): bf16 operands (any weight storage), dense k=3 'same' conv
   const bool ws_conv3_ok = sizeof(T) == 2 && !g1 && g.taps == 3 && g.dil == 1 && g.tap0 == -1 && g.rstride <= 1 && g.segV == g.segS &&
                            g.osegV >= g.M && (epi == EPI_STORE_F32 || epi == EPI_GATE_RES || epi == EPI_SILUGATE_T);
-  if ((tile == 21 || tile == 22 || tile == 23) && !ws_conv3_ok) return foley_set_err("GEMM: tiles 21 / 22 / 23 need a bf16 channels-last conv k=3", __FILE__, __LINE__);
+  if ((tile == 21 || tile == 22 || tile == 23 || tile == 24) && !ws_conv3_ok) return foley_set_err("GEMM: tiles 21 / 22 / 23 / 24 need a bf16 channels-last conv k=3", __FILE__, __LINE__);
+  if (tile == 24 && (g.wfmt || epi == EPI_SILUGATE_T)) return foley_set_err("GEMM: tile 24 (192x128 conv) serves bf16 weights, gated-residual / fp32-store epilogues", __FILE__, __LINE__);
   if (tile == 22 && g.wfmt) return foley_set_err("GEMM: tile 22 serves bf16 weights", __FILE__, __LINE__);
   const bool conv3_ok = !g.wfmt && !g1 && g.taps == 3 && g.dil == 1 && g.tap0 == -1 && g.rstride <= 1 && g.segV == g.segS && g.lda == g.tapC &&
                         g.osegV >= g.M && (epi == EPI_STORE_F32 || epi == EPI_GATE_RES || epi == EPI_SILUGATE_T);
@@ -675,6 +676,14 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
       if (ew >= 0.74 && ew >= eb - 0.13 && split_ok && gemm_vec_out_ok<T>(gt, epi)) tile = conv ? 31 : 32;
     }
   }
+  // A large conv grid whose 256-row tiles cover clearly less than one round of 256 CUs while 192-row tiles still fit it (w2 / linear1 at
+  // M = 4000: 16 x 12 = 192 workgroups against 21 x 12 = 252) takes the 192x128 form: every CU works, and each workgroup streams
+  // (192 + 128) instead of (256 + 128) rows per K-slice.  FOLEY_CONV3_192=0 keeps 256x128.
+  if (tile_auto && tile == 23 && !g.wfmt && epi != EPI_SILUGATE_T && g.N % 128 == 0) {
+    static const bool on192 = []() { const char* e = getenv("FOLEY_CONV3_192"); return !(e && e[0] == '0'); }();
+    const long b256 = (long)((g.M + 255) / 256) * (g.N / 128), b192 = (long)((g.M + 191) / 192) * (g.N / 128);
+    if (on192 && b256 <= 216 && b192 <= 256 && b192 > b256) tile = 24;
+  }
   if (g.wfmt && tile != 15 && tile != 19 && tile != 21 && tile != 23 && tile != 31 && tile != 32) {   // fp8 weights exist only in the wave-specialised mainloops
     if (!tile_auto) return foley_set_err("GEMM: fp8 weights need tile 15, 19 or 21", __FILE__, __LINE__);
     tile = 15;
@@ -733,14 +742,14 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     g.ksplit = 1;   // fp32 (parity) mode keeps a fixed summation order
   } else if (g.ksplit == 0) {
     // fill ~3 workgroups per CU, keep >= 12 K-slices per range
-    static const int bm[33] = {0, 128, 64, 64, 128, 128, 64, 128, 64, 256, 0, 128, 0, 64, 0, 128, 0, 0, 0, 256, 0, 128, 256, 256, 0, 128, 0, 0, 0, 256, 0, 256, 256};
-    static const int bn[33] = {0, 128, 128, 64, 64, 128, 64, 128, 128, 128, 0, 128, 0, 64, 0, 128, 0, 0, 0, 128, 0, 128, 64, 128, 0, 128, 0, 0, 0, 128, 0, 256, 256};
+    static const int bm[33] = {0, 128, 64, 64, 128, 128, 64, 128, 64, 256, 0, 128, 0, 64, 0, 128, 0, 0, 0, 256, 0, 128, 256, 256, 192, 128, 0, 0, 0, 256, 0, 256, 256};
+    static const int bn[33] = {0, 128, 128, 64, 64, 128, 64, 128, 128, 128, 0, 128, 0, 64, 0, 128, 0, 0, 0, 128, 0, 128, 64, 128, 128, 128, 0, 0, 0, 128, 0, 256, 256};
     if (tile < 0 || tile >= 33 || bm[tile] == 0) return foley_set_err("GEMM: unknown tile", __FILE__, __LINE__);
     const long blocks = (long)((g.M + bm[tile] - 1) / bm[tile]) * ((g.N + bn[tile] - 1) / bn[tile]);
-    const int nk = (tile == 11 || tile == 13 || tile == 21 || tile == 22 || tile == 23 || tile == 31) ? 3 * (g.tapC / BK) / 3 : g.K / BK;   // conv3 splits over channel chunks
+    const int nk = (tile == 11 || tile == 13 || tile == 21 || tile == 22 || tile == 23 || tile == 24 || tile == 31) ? 3 * (g.tapC / BK) / 3 : g.K / BK;   // conv3 splits over channel chunks
     // small tiles want ~3 workgroups per CU; the large, efficient tiles only split when they
     // cannot even cover the chip once (the fp32 atomics are not free)
-    const long target = (tile == 1 || tile == 5 || tile == 7 || tile == 9 || tile == 11 || tile == 15 || tile == 19 || tile == 21 || tile == 22 || tile == 23 || tile == 25 || tile == 29 || tile >= 31) ? 192 : (tile == 13 ? 512 : 768);
+    const long target = (tile == 1 || tile == 5 || tile == 7 || tile == 9 || tile == 11 || tile == 15 || tile == 19 || tile == 21 || tile == 22 || tile == 23 || tile == 24 || tile == 25 || tile == 29 || tile >= 31) ? 192 : (tile == 13 ? 512 : 768);
     long want = (target + blocks - 1) / blocks;
     if (want > nk / 12) want = nk / 12;
     if (deferred) {   // one resident round of workgroups: as many K ranges as fit on 256 CUs (>= 4 slices each)
@@ -774,7 +783,7 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     bool ok = extent(g);
     if (g1) ok = extent(g1s) && ok;
     if (!ok && g.wfmt) return foley_set_err("GEMM: fp8-weight operands exceed the 2 GiB buffer-offset range", __FILE__, __LINE__);
-    if (!ok && (tile == 21 || tile == 22 || tile == 23)) return foley_set_err("GEMM: conv3 operands exceed the 2 GiB buffer-offset range", __FILE__, __LINE__);
+    if (!ok && (tile == 21 || tile == 22 || tile == 23 || tile == 24)) return foley_set_err("GEMM: conv3 operands exceed the 2 GiB buffer-offset range", __FILE__, __LINE__);
     if (!ok && (tile == 31 || tile == 32)) return foley_set_err("GEMM: the 256x256 tiles range every load against 32-bit buffer extents: operands exceed the 2 GiB buffer-offset range", __FILE__, __LINE__);
     if (!ok && ((tile >= 5 && tile <= 9) || tile == 15 || tile == 19 || tile == 25 || tile == 26 || tile == 27 || tile == 28 || tile == 29)) tile = (tile == 6) ? 3 : ((tile == 8 || tile == 27) ? 2 : 1);   // register-staged twins
   }
@@ -789,7 +798,7 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     switch (tile) {
       case 15: case 25: case 21: tbm = 128; tbn = 128; break;
       case 19: case 29: case 23: tbm = 256; tbn = 128; break;
-      case 28: tbm = 192; tbn = 128; break;
+      case 28: case 24: tbm = 192; tbn = 128; break;
       case 31: case 32: tbm = 256; tbn = 256; break;
     }
     g.n_groups = 0;
@@ -814,7 +823,7 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
   // single-block modulation GEMM once it was gone).  Problems that need the scalar epilogue take the twins.
   if ((tile == 25 || tile == 29) && epi != EPI_QKV_SPLIT && !(g.vec_out && (!g1 || g1s.vec_out))) tile = tile == 25 ? 15 : 19;
   if ((tile == 27 || tile == 26 || tile == 28) && (epi != EPI_QKV_SPLIT || g.wfmt)) return foley_set_err("GEMM: tile 27 (64x128) serves the fused head split with bf16 weights only", __FILE__, __LINE__);
-  if ((g.ldw != g.K || (g1 && g1s.ldw != g1s.K)) && tile != 31 && tile != 32 && !(tile == 15 || tile == 19 || tile == 21 || tile == 22 || tile == 23 || tile == 25 || tile == 26 || tile == 27 || tile == 28 || tile == 29))
+  if ((g.ldw != g.K || (g1 && g1s.ldw != g1s.K)) && tile != 31 && tile != 32 && !(tile == 15 || tile == 19 || tile == 21 || tile == 22 || tile == 23 || tile == 24 || tile == 25 || tile == 26 || tile == 27 || tile == 28 || tile == 29))
     return foley_set_err("GEMM: padded weight rows (ldw != K) need a wave-specialised tile", __FILE__, __LINE__);
   if (tile == 31 || tile == 32) {   // 256x256 tiles on the BK = 32 mainloop (gemm_wide_impl.h)
     if (g1) return foley_set_err("GEMM: the 256x256 tiles have no two-problem form", __FILE__, __LINE__);
@@ -843,7 +852,7 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     if (g1 && g1s.qs.attn_fused) *g1s.qs.attn_fused = fuse ? 1 : 0;
     if (fuse) epi = EPI_QKV_ATTN;
   }
-  if (tile == 15 || tile == 19 || tile == 21 || tile == 22 || tile == 23 || tile == 25 || tile == 26 || tile == 27 || tile == 28 || tile == 29) {
+  if (tile == 15 || tile == 19 || tile == 21 || tile == 22 || tile == 23 || tile == 24 || tile == 25 || tile == 26 || tile == 27 || tile == 28 || tile == 29) {
     if constexpr (__is_same(T, bf16_t)) return launch_gemm_ws_bf16(g, g1, epi, tile, st);
     else if constexpr (__is_same(T, f16_t)) return launch_gemm_ws_f16(g, g1, epi, tile, st);
     else return foley_set_err("GEMM: wave-specialised tiles are bf16 only", __FILE__, __LINE__);

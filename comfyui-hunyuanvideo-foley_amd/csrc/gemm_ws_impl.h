@@ -550,7 +550,7 @@ __global__ __launch_bounds__((WM * WN + LW) * 64) void gemm_ws_conv3_kernel(cons
   constexpr int BI = BN * BROW / 1024 / LW;             // weight pieces per loader wave and tap slice
   constexpr int BSL = BN * BROW;                        // bytes per weight slice
   constexpr int ZOFF = NAB * ABUF + NSB * BSL;          // 128 zero bytes
-  constexpr bool TWOB = BM == 256 && BN == 128;         // large-grid form: second barrier per slice (see gemm_ws_body; w1/w3 at M = 4000: 271 -> 262 us)
+  constexpr bool TWOB = BM >= 192 && BN == 128;         // large-grid forms: second barrier per slice (see gemm_ws_body; w1/w3 at M = 4000: 271 -> 262 us)
   static_assert(NW == 8 && (BN * BROW) % (1024 * LW) == 0 && BI >= 1, "bad tile");
   static_assert(3 * NAB >= NSB + 2, "an activation buffer would be refilled while its chunk is still being consumed");
   static_assert(conv3_inflight(NSB, 0, AI, BI) < 64 && conv3_inflight(NSB, 1, AI, BI) < 64 && conv3_inflight(NSB, 2, AI, BI) < 64,
@@ -1059,8 +1059,9 @@ int launch_ws_conv3_ks(const GemmArgs& g, hipStream_t st) {
 
 template <typename T, int BM, int EPI, int WF>
 int launch_ws_conv3_one(const GemmArgs& g, hipStream_t st) {
-  // 128x128: activation chunks 3 deep + 6 weight slices; 256x128 (large grids): 2 + 4 (fp8 weights: 3 + 6)
-  constexpr int BN = 128, WM = 4, WN = 2, LW = 4;
+  // 128x128: activation chunks 3 deep + 6 weight slices; 256x128 (large grids): 2 + 4 (fp8 weights: 3 + 6); 192x128 (tile 24: a
+  // large grid whose 256-row tiles would leave a quarter of the CUs idle): wave tiles 96x32, 2 + 4
+  constexpr int BN = 128, WM = BM == 192 ? 2 : 4, WN = BM == 192 ? 4 : 2, LW = 4;
   constexpr int NSB = BM == 128 ? 6 : (WF ? 6 : 4), NAB = (NSB + 2 + 2) / 3;
   constexpr size_t ai = ((BM + 2 + 7) / 8 + LW - 1) / LW;
   constexpr size_t lds_ring = NAB * ai * LW * 1024 + (size_t)NSB * BN * (WF ? 64 : 128) + 128;
@@ -1186,6 +1187,12 @@ int launch_gemm_ws_t(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, h
     if (epi == EPI_STORE_F32) return launch_ws_conv3_tall<T, EPI_STORE_F32>(g, st);
     if (epi == EPI_SILUGATE_T) return launch_ws_conv3_tall<T, EPI_SILUGATE_T>(g, st);
     return foley_set_err("wave-specialised conv3 256x64: unsupported epilogue", __FILE__, __LINE__);
+  }
+  if (tile == 24) {   // tap-fused conv k=3, 192x128 (bf16 weights; gated residual / fp32 store)
+    if (g1 || g.wfmt) return foley_set_err("wave-specialised conv3 192x128: single problem, bf16 weights", __FILE__, __LINE__);
+    if (epi == EPI_GATE_RES) return launch_ws_conv3_one<T, 192, EPI_GATE_RES, 0>(g, st);
+    if (epi == EPI_STORE_F32) return launch_ws_conv3_one<T, 192, EPI_STORE_F32, 0>(g, st);
+    return foley_set_err("wave-specialised conv3 192x128: unsupported epilogue", __FILE__, __LINE__);
   }
   if (tile == 21 || tile == 23) {   // tap-fused conv k=3, 128x128 / 256x128 (the launcher has checked the conv shape)
     if (g1) return foley_set_err("wave-specialised conv3 has no two-problem form", __FILE__, __LINE__);

@@ -236,7 +236,7 @@ def test_gemm_split_k(dev, ksplit, conv):
 
 
 @pytest.mark.parametrize("ksplit", [0, 2, 3, 7])
-@pytest.mark.parametrize("conv", [False, True, 11, 13, 15, 19, 21, 22, 23, 31, -32])
+@pytest.mark.parametrize("conv", [False, True, 11, 13, 15, 19, 21, 22, 23, 24, 31, -32])
 @pytest.mark.parametrize("tok_gate", [False, True])
 @pytest.mark.parametrize("slab_dt", [torch.float32, torch.bfloat16, torch.float16])
 def test_gemm_deferred_split_k(dev, ksplit, conv, tok_gate, slab_dt):
@@ -261,7 +261,7 @@ def test_gemm_deferred_split_k(dev, ksplit, conv, tok_gate, slab_dt):
     if conv and conv > 0:
         y = O.conv1d_cl(_q(x, dt), _q(w, dt), b, 1).reshape(B * L, N)
         Wp, kw = packers.conv_to_gemm(w), dict(conv=(L, C, 3, 1))
-        if conv in (11, 13, 15, 19, 21, 22, 23, 31):
+        if conv in (11, 13, 15, 19, 21, 22, 23, 24, 31):
             kw["tile"] = conv    # tap-fused / wave-specialised conv addressing
     else:
         y = F.linear(_q(x, dt).reshape(B * L, C), _q(w[:, :, 0], dt), b)
@@ -288,11 +288,11 @@ def test_gemm_deferred_split_k(dev, ksplit, conv, tok_gate, slab_dt):
 
 # ----------------------------------------------------------------------------- GEMM: conv addressing
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("tile", [0, 3, 5, 6, 11, 13, 15, 19, 21, 22, 23, 31])
+@pytest.mark.parametrize("tile", [0, 3, 5, 6, 11, 13, 15, 19, 21, 22, 23, 24, 31])
 @pytest.mark.parametrize("B,L,Cin,Cout", [(2, 50, 256, 384), (3, 7, 128, 64), (1, 250, 1536, 256), (5, 33, 128, 200), (2, 250, 64, 128),
                                           (4, 129, 192, 320), (16, 250, 128, 256)])
 def test_conv3_channels_last(dev, dtype, tile, B, L, Cin, Cout):
-    if tile in (15, 19, 21, 22, 23, 31) and dtype == torch.float32:
+    if tile in (15, 19, 21, 22, 23, 24, 31) and dtype == torch.float32:
         pytest.skip("wave-specialised tiles are bf16 only")
     """ChannelLastConv1d k=3 pad=1 (mlp_layers.py:104-110) as a GEMM over overlapping rows
     (register-staged and direct-to-LDS mainloops)."""
