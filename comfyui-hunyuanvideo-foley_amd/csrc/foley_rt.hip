@@ -1406,6 +1406,12 @@ extern "C" int foley_op_qkv_regroup(const void* qkv, int dtype, int H, const int
   return launch_qkv_regroup(qkv, dtype, H, idx_q, G, Sq, idx_kv, Skv, q, k, v, vt_pitch, (hipStream_t)stream);
 }
 
+extern "C" int foley_op_resize_aa_u8(const uint8_t* in, long outer, int len_in, long inner, int len_out, const int32_t* xmin,
+                                     const int32_t* xsize, const int16_t* weights, int kmax, int precision, uint8_t* out, void* stream) {
+  if (!in || !xmin || !xsize || !weights || !out) return FAIL(FOLEY_ERR_INVALID, "null argument");
+  return launch_resize_aa_u8(in, outer, len_in, inner, len_out, xmin, xsize, weights, kmax, precision, out, (hipStream_t)stream);
+}
+
 extern "C" int foley_op_ln_mod(const float* x, int M, int D, float eps, const foley_rowbcast* shift,
                                const foley_rowbcast* scale, void* out, int out_dtype, void* stream) {
   return launch_ln_mod(x, M, D, eps, to_rb(shift), to_rb(scale), out, out_dtype, (hipStream_t)stream);

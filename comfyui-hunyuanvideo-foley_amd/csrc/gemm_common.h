@@ -385,7 +385,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs& g, f32x16 (&ac
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
               const float t = a[w] + bias_a[u + w];
-              if constexpr (EPI == EPI_GELU_T) v[u + w] = ERF ? gelu_erf_f(t) : gelu_o<OutT>(t);
+              if constexpr (EPI == EPI_GELU_T) v[u + w] = ERF ? gelu_erf_o<OutT>(t) : gelu_o<OutT>(t);
               else v[u + w] = EPI == EPI_SILU_T ? silu_o<OutT>(t) : t;
             }
           }

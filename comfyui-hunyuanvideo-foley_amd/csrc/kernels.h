@@ -215,5 +215,7 @@ int launch_dac_in(const float* x, const float* w, const float* bias, const float
 int launch_rows_to_planes(const float* rows, int B, int T, int C, float* out, hipStream_t st);
 int launch_qkv_regroup(const void* qkv, int dtype, int H, const int* idx_q, int G, int Sq, const int* idx_kv, int Skv, void* q, void* k,
                        void* v, int vt_pitch, hipStream_t st);
+int launch_resize_aa_u8(const uint8_t* in, long outer, int len_in, long inner, int len_out, const int* xmin, const int* xsize,
+                        const short* w, int kmax, int prec, uint8_t* out, hipStream_t st);
 int launch_dac_out(const float* s, const float* w, const float* bias, int B, int T, int C, float* out,
                    hipStream_t st);

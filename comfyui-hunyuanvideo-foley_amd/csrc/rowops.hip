@@ -912,6 +912,77 @@ int launch_qkv_regroup(const void* qkv, int dtype, int H, const int* idx_q, int 
   return 0;
 }
 
+// One pass of the separable antialiased uint8 resize the reference pre-processes its frames with (torchvision v2.Resize(bicubic,
+// antialias=True) on uint8 CPU tensors, nodes.py:184-196 / utils.py:262-283 - ATen's native uint8 kernel, PIL's scheme): along the
+// resized axis every output sample is a fixed-point weighted sum of `xsize` input bytes starting at `xmin`, int16 weights scaled by
+// 2^prec, accumulator preset to 2^(prec-1), arithmetic shift, saturate to a byte.  The horizontal pass runs first and its rounded
+// uint8 image feeds the vertical pass - integer arithmetic end to end, so the result is the reference's bit for bit
+// (tests/test_encoders_gpu.py; the tables are built by host/encoders.py::aa_tables and pinned in tests/test_oracle_golden.py).
+// Layout [outer, len, inner]: inner = 1 is the horizontal pass (threads along the output row), inner = W the vertical one
+// (threads along x, V bytes each - one 32-bit load per tap when the row pitch allows).  HBM-bound byte work: 37 MB in, 31 MB out
+// for the 40 SigLIP2 frames of a 5 s clip; the taps of neighbouring outputs overlap in the L1 / L2.
+template <int V>
+__global__ __launch_bounds__(256) void resize_aa_u8_kernel(const uint8_t* __restrict__ in, long outer, int len_in, long inner, int len_out,
+                                                           const int* __restrict__ xmin, const int* __restrict__ xsize,
+                                                           const short* __restrict__ w, int kmax, int prec, uint8_t* __restrict__ out) {
+  const long inner_v = inner / V;
+  const long total = outer * len_out * inner_v;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+    const long iv = idx % inner_v, t = idx / inner_v;
+    const int xo = (int)(t % len_out);
+    const long o = t / len_out;
+    int x0 = xmin[xo], n = xsize[xo];   // clamped: a bad table must not read outside the image
+    x0 = x0 < 0 ? 0 : (x0 > len_in ? len_in : x0);
+    n = n > kmax ? kmax : n;
+    n = n > len_in - x0 ? len_in - x0 : n;
+    const short* wr = w + (long)xo * kmax;
+    const uint8_t* src = in + (o * len_in + x0) * inner + iv * V;
+    int acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = 1 << (prec - 1);
+    for (int j = 0; j < n; ++j) {
+      const int wj = wr[j];
+      if constexpr (V == 4) {
+        const uint32_t px = *(const uint32_t*)(src + (long)j * inner);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] += (int)((px >> (8 * v)) & 255u) * wj;
+      } else if constexpr (V == 2) {
+        const uint32_t px = *(const uint16_t*)(src + (long)j * inner);
+        acc[0] += (int)(px & 255u) * wj;
+        acc[1] += (int)(px >> 8) * wj;
+      } else {
+        acc[0] += (int)src[(long)j * inner] * wj;
+      }
+    }
+    uint32_t packed = 0;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      int r = acc[v] >> prec;
+      r = r < 0 ? 0 : (r > 255 ? 255 : r);
+      packed |= (uint32_t)r << (8 * v);
+    }
+    uint8_t* dst = out + (o * len_out + xo) * inner + iv * V;
+    if constexpr (V == 4) *(uint32_t*)dst = packed;
+    else if constexpr (V == 2) *(uint16_t*)dst = (uint16_t)packed;
+    else *dst = (uint8_t)packed;
+  }
+}
+
+int launch_resize_aa_u8(const uint8_t* in, long outer, int len_in, long inner, int len_out, const int* xmin, const int* xsize,
+                        const short* w, int kmax, int prec, uint8_t* out, hipStream_t st) {
+  if (outer < 1 || inner < 1 || len_in < 1 || len_out < 1 || kmax < 1) return foley_set_err("resize_aa_u8: empty problem", __FILE__, __LINE__);
+  if (prec < 1 || prec > 22) return foley_set_err("resize_aa_u8: weight precision must be in [1, 22] bits", __FILE__, __LINE__);
+  const int V = (inner % 4 == 0 && !(((uintptr_t)in | (uintptr_t)out) & 3)) ? 4 : (inner % 2 == 0 && !(((uintptr_t)in | (uintptr_t)out) & 1)) ? 2 : 1;
+  const long total = outer * len_out * (inner / V);
+  const long blocks = (total + 255) / 256;
+  const dim3 grid((unsigned)(blocks < 65536L * 16 ? blocks : 65536L * 16));
+  if (V == 4) FOLEY_LAUNCH(resize_aa_u8_kernel<4>, grid, dim3(256), 0, st, in, outer, len_in, inner, len_out, xmin, xsize, w, kmax, prec, out);
+  else if (V == 2) FOLEY_LAUNCH(resize_aa_u8_kernel<2>, grid, dim3(256), 0, st, in, outer, len_in, inner, len_out, xmin, xsize, w, kmax, prec, out);
+  else FOLEY_LAUNCH(resize_aa_u8_kernel<1>, grid, dim3(256), 0, st, in, outer, len_in, inner, len_out, xmin, xsize, w, kmax, prec, out);
+  FOLEY_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_rows_to_planes(const float* rows, int B, int T, int C, float* out, hipStream_t st) {
   FOLEY_LAUNCH(rows_to_planes_kernel, dim3(grid1d((long)B * T * C, 256)), dim3(256), 0, st, rows, B, T, C, out);
   FOLEY_LAUNCH_CHECK();

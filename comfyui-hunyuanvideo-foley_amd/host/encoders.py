@@ -81,24 +81,90 @@ def select_frames(image: Tensor, duration: float, frame_rate: float, device=None
 
 
 # ----------------------------------------------------------------------------- pre-processing
+_AA_TABLES: Dict = {}
+
+
+def aa_tables(n_in: int, n_out: int):
+    """Tap tables of ONE axis of the antialiased bicubic uint8 resize, as ATen's native uint8 kernel builds them (the kernel
+    torchvision's v2.Resize dispatches to on CPU tensors - where the reference pre-processes, utils.py:262-283): output sample i
+    sits at centre = scale*(i + 0.5), scale = n_in / n_out; its taps are the input samples within support = 2*max(scale, 1) of
+    the centre, weighted by the Keys cubic (a = -0.5) of their distance / max(scale, 1), normalised to sum 1 - all in double
+    precision - then stored as int16 at the largest precision (<= 22 bits) at which the biggest weight stays below 2^15,
+    rounded half away from zero.  Returns (xmin int32 [n_out], xsize int32 [n_out], weights int16 [n_out, kmax], precision)
+    as numpy arrays; cached per (n_in, n_out)."""
+    import numpy as np
+    key = (int(n_in), int(n_out))
+    hit = _AA_TABLES.get(key)
+    if hit is not None:
+        return hit
+    scale = n_in / n_out
+    support = 2.0 * scale if scale >= 1.0 else 2.0
+    inv = 1.0 / scale if scale >= 1.0 else 1.0
+    kmax = int(math.ceil(support)) * 2 + 1
+    i = np.arange(n_out, dtype=np.float64)
+    centre = scale * (i + 0.5)
+    xmin = np.maximum((centre - support + 0.5).astype(np.int64), 0)
+    xsize = np.clip(np.minimum((centre + support + 0.5).astype(np.int64), n_in) - xmin, 0, kmax)
+    j = np.arange(kmax, dtype=np.float64)[None, :]
+    x = np.abs((j + xmin[:, None] - centre[:, None] + 0.5) * inv)
+    a = -0.5
+    w = np.where(x < 1.0, ((a + 2.0) * x - (a + 3.0)) * x * x + 1.0, np.where(x < 2.0, (((x - 5.0) * x + 8.0) * x - 4.0) * a, 0.0))
+    w = np.where(j < xsize[:, None], w, 0.0)
+    # the kernel sums the taps one by one in index order (not pairwise): keep that order for the normaliser
+    tot = np.zeros(n_out, dtype=np.float64)
+    for c in range(kmax):
+        tot = tot + w[:, c]
+    w = np.where(tot[:, None] != 0.0, w / np.where(tot == 0.0, 1.0, tot)[:, None], w)
+    wmax = float(w.max()) if w.size else 0.0
+    precision = 0
+    while precision < 22 and int(0.5 + wmax * (1 << (precision + 1))) < (1 << 15):
+        precision += 1
+    v = w * float(1 << precision)
+    wi = np.where(v < 0.0, np.trunc(v - 0.5), np.trunc(v + 0.5)).astype(np.int16)
+    out = (xmin.astype(np.int32), xsize.astype(np.int32), wi, precision)
+    if len(_AA_TABLES) >= 64:
+        _AA_TABLES.pop(next(iter(_AA_TABLES)))
+    _AA_TABLES[key] = out
+    return out
+
+
+_AA_DEVICE: Dict = {}
+
+
+def _resize_pass_hip(x: Tensor, axis: int, n_out: int) -> Tensor:
+    """One axis of the resize on libfoley_hip.so (foley_op_resize_aa_u8), tables staged once per (sizes, device)."""
+    from . import runtime as rt
+    n_in = x.shape[axis]
+    key = (n_in, n_out, str(x.device))
+    tabs = _AA_DEVICE.get(key)
+    if tabs is None:
+        xmin, xsize, w, prec = aa_tables(n_in, n_out)
+        if len(_AA_DEVICE) >= 64:
+            _AA_DEVICE.pop(next(iter(_AA_DEVICE)))
+        tabs = _AA_DEVICE[key] = (torch.from_numpy(xmin).to(x.device), torch.from_numpy(xsize).to(x.device),
+                                  torch.from_numpy(w).to(x.device), prec)
+    return rt.op_resize_aa_u8(x, axis, n_out, tabs[0], tabs[1], tabs[2], tabs[3])
+
+
 def _resize_u8(frames: Tensor, size: Tuple[int, int]) -> Tensor:
     """v2.Resize(bicubic, antialias=True) on uint8 [T,C,H,W] as the reference runs it - on the CPU (utils.py:262-283
     pre-processes before the encoders' `.to(device)`), where torchvision dispatches to ATen's native uint8 kernel.  That
-    kernel is separable with a uint8 intermediate: a horizontal pass, rounded and clamped to [0, 255], then the vertical
-    pass (PIL's scheme).  On the GPU the same two passes are taken in float32 with the same intermediate rounding, which
-    reproduces the CPU result up to the uint8 kernel's fixed-point weights (<= 1 grey level on a few per cent of the
-    pixels; `tests/test_encoders_gpu.py`) - a single 2-D float interpolation differs by tens of levels on textured
-    frames because overshoots are not clamped between the passes."""
+    kernel is separable with a uint8 intermediate and fixed-point weights (PIL's scheme): a horizontal pass, rounded and
+    saturated to a byte, then the vertical pass.  On the GPU the same two integer passes run on libfoley_hip.so
+    (foley_op_resize_aa_u8 over `aa_tables`' taps) and reproduce the CPU result BIT FOR BIT
+    (`tests/test_encoders_gpu.py`; until round 5 this branch went through two float32 F.interpolate passes: <= 1 grey level off
+    on 0.6 % of the pixels and 3 ms per clip in ATen's generic antialias kernel) - a single 2-D float interpolation differs by
+    tens of levels on textured frames because overshoots are not clamped between the passes."""
     if tuple(frames.shape[-2:]) == tuple(size):
         return frames
     if frames.device.type == "cpu":
         return F.interpolate(frames, size=size, mode="bicubic", antialias=True)
-    x = frames.float()
+    x = frames.contiguous()
     if x.shape[-1] != size[1]:
-        x = F.interpolate(x, size=(x.shape[-2], size[1]), mode="bicubic", antialias=True).round_().clamp_(0, 255)
+        x = _resize_pass_hip(x, x.dim() - 1, size[1])
     if x.shape[-2] != size[0]:
-        x = F.interpolate(x, size=size, mode="bicubic", antialias=True).round_().clamp_(0, 255)
-    return x.to(torch.uint8)
+        x = _resize_pass_hip(x, x.dim() - 2, size[0])
+    return x
 
 
 def _scale_normalize(frames_u8: Tensor) -> Tensor:

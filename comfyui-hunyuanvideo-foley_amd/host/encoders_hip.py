@@ -102,6 +102,8 @@ class _Engine:
         """int32 index table on the device, built once per (shape) key by `build()` (a CPU / torch expression)."""
         t = self.tabs.get(key)
         if t is None:
+            if len(self.tabs) >= 512:          # prompt-length keyed tables (CLAP): bounded, oldest first
+                self.tabs.pop(next(iter(self.tabs)))
             t = self.tabs[key] = build().to(self.dev, torch.int32).contiguous()
         return t
 
@@ -129,12 +131,6 @@ class _Engine:
         out = torch.empty(G, Sq, H * hd, device=self.dev, dtype=self.dtype)
         rt.op_attention(q, k, v, out, out, 0)
         return out
-
-
-def _split_heads(qkv: Tensor, B: int, N: int, heads: int = HEADS):
-    """[B*N, 3*H*64] -> q, k, v views [B, H, N, 64] (the '(K H D)' packing of nn.Linear(dim, 3*dim) / in_proj_weight)."""
-    t = qkv.view(B, N, 3, heads, HD).permute(2, 0, 3, 1, 4)
-    return t[0], t[1], t[2]
 
 
 def _divided_attention(E: _Engine, h: Tensor, sd: SD, key: str, B: int, frames: int, space: int, over: str) -> Tensor:
@@ -331,8 +327,13 @@ def clap_text_hidden_hip(sd: SD, input_ids: Tensor, attention_mask: Tensor, dtyp
         xT = x.to(E.dtype)
         a_ = l + ".attention.self."
         fq = E.fused(sd, a_ + "qkv#", [a_ + n + ".weight" for n in ("query", "key", "value")], [a_ + n + ".bias" for n in ("query", "key", "value")])
-        q, k, v = _split_heads(E.linear(xT, fq, a_ + "qkv#.w", a_ + "qkv#.b"), B, T, heads)
-        att = torch.cat([E.attention(q[b:b + 1], k[b:b + 1, :, :lens_h[b]], v[b:b + 1, :, :lens_h[b]]) for b in range(B)])
+        qkv = E.linear(xT, fq, a_ + "qkv#.w", a_ + "qkv#.b")                  # [B*T, 3*D]
+        # per prompt: all T query rows against its first len_b keys - one regroup + one attention launch each (index tables per
+        # (prompt slot, T, len); until round 5: slices, .contiguous() copies and a padded V^T per prompt, ~14 launches per layer)
+        att = torch.cat([E.attention_regrouped(
+            qkv, heads,
+            E.index(("clap-q", b, T), lambda b=b: (b * T + torch.arange(T))[None]),
+            E.index(("clap-kv", b, T, lens_h[b]), lambda b=b: (b * T + torch.arange(lens_h[b]))[None])) for b in range(B)])
         E.linear_residual(x, att.reshape(B * T, D), sd, l + ".attention.output.dense.weight", l + ".attention.output.dense.bias")
         y = E.ln(x, sd, l + ".attention.output.LayerNorm", eps, out_dtype=torch.float32)
         hid = E.linear(y.to(E.dtype), sd, l + ".intermediate.dense.weight", l + ".intermediate.dense.bias", act="gelu_erf")

@@ -91,7 +91,7 @@ class ProfEntryC(C.Structure):
 
 
 PROGRESS_CB = C.CFUNCTYPE(None, C.c_int32, C.c_int32, C.c_void_p)
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _SIGNATURES = {
     "foley_abi_version": (C.c_uint32, []),
@@ -131,6 +131,8 @@ _SIGNATURES = {
                                   C.POINTER(RowBcastC), C.c_void_p, C.c_int, C.c_void_p]),
     "foley_op_qkv_regroup": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "foley_op_resize_aa_u8": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_int, C.c_void_p, C.c_void_p]),
     "foley_op_qkv_split": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
                                      C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -519,6 +521,31 @@ def op_qkv_regroup(qkv: torch.Tensor, heads: int, idx_q: torch.Tensor, idx_kv: t
     _check(lib, lib.foley_op_qkv_regroup(_ptr(qkv), dt_of(qkv), heads, _ptr(idx_q), G, Sq, _ptr(idx_kv), Skv, _ptr(q), _ptr(k), _ptr(v),
                                          pitch, _stream()), "foley_op_qkv_regroup")
     return q, k, v
+
+
+def op_resize_aa_u8(x: torch.Tensor, axis: int, len_out: int, xmin: torch.Tensor, xsize: torch.Tensor, weights: torch.Tensor,
+                     precision: int) -> torch.Tensor:
+    """One pass of the antialiased uint8 resize along `axis` of a contiguous uint8 tensor (foley_op_resize_aa_u8): tables xmin /
+    xsize int32 [len_out], weights int16 [len_out, kmax] on the device (host/encoders.py::aa_tables)."""
+    lib = load_library()
+    if x.dtype != torch.uint8 or not x.is_contiguous() or xmin.dtype != torch.int32 or xsize.dtype != torch.int32 or \
+            weights.dtype != torch.int16 or weights.shape[0] != len_out or xmin.numel() != len_out or xsize.numel() != len_out:
+        raise FoleyRuntimeError("op_resize_aa_u8: contiguous uint8 frames; int32 xmin / xsize [len_out], int16 weights [len_out, kmax]")
+    axis %= x.dim()
+    shape = list(x.shape)
+    outer = 1
+    for d in shape[:axis]:
+        outer *= d
+    inner = 1
+    for d in shape[axis + 1:]:
+        inner *= d
+    len_in = shape[axis]
+    shape[axis] = len_out
+    out = torch.empty(shape, device=x.device, dtype=torch.uint8)
+    if out.numel():
+        _check(lib, lib.foley_op_resize_aa_u8(_ptr(x), outer, len_in, inner, len_out, _ptr(xmin), _ptr(xsize), _ptr(weights),
+                                              weights.shape[1], precision, _ptr(out), _stream()), "foley_op_resize_aa_u8")
+    return out
 
 
 def op_ln_mod(x, eps, shift: Optional[RowBcastC], scale: Optional[RowBcastC], out):

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FOLEY_ABI_VERSION 10   /* 10: foley_op_qkv_regroup (token regrouping of the conditioning encoders' attention); 9: foley_bcast_local (single-process grouped broadcast of the arenas); 8: foley_qkv_split_desc.attn_* (cross attention in the epilogue of its q projection), foley_abort / FOLEY_ERR_ABORTED; 7: FOLEY_DT_F16 as a compute dtype (foley_config.compute_dtype, op descriptors); 6: foley_rowbcast.Ls (mode 2: nearest-exact up-sampled operand); 5: reference-keyed loading (foley_weights_*, foley_load_tensor, foley_bcast_weights); 4: fp8 weight storage (dtype codes 3/4, foley_gemm_desc.ldw/.wfmt); 3: foley_profile_forward; 2: foley_gemm_desc gained partials / qkv / rstride; foley_op_ln_mod_pending, foley_dac_encode */
+#define FOLEY_ABI_VERSION 11   /* 11: foley_op_resize_aa_u8 (the frames' antialiased uint8 resize, bit for bit); 10: foley_op_qkv_regroup (token regrouping of the conditioning encoders' attention); 9: foley_bcast_local (single-process grouped broadcast of the arenas); 8: foley_qkv_split_desc.attn_* (cross attention in the epilogue of its q projection), foley_abort / FOLEY_ERR_ABORTED; 7: FOLEY_DT_F16 as a compute dtype (foley_config.compute_dtype, op descriptors); 6: foley_rowbcast.Ls (mode 2: nearest-exact up-sampled operand); 5: reference-keyed loading (foley_weights_*, foley_load_tensor, foley_bcast_weights); 4: fp8 weight storage (dtype codes 3/4, foley_gemm_desc.ldw/.wfmt); 3: foley_profile_forward; 2: foley_gemm_desc gained partials / qkv / rstride; foley_op_ln_mod_pending, foley_dac_encode */
 
 enum foley_dtype {
   FOLEY_DT_F32 = 0, FOLEY_DT_BF16 = 1, FOLEY_DT_I32 = 2,
@@ -269,6 +269,15 @@ int foley_op_attention_hd(const void* q, const void* k, const void* v, int in_dt
  * operands - v TRANSPOSED [G,H,64,vt_pitch] with zeros beyond Skv (vt_pitch a multiple of 8 in [Skv, ceil64(Skv)]). */
 int foley_op_qkv_regroup(const void* qkv, int dtype, int H, const int32_t* idx_q, int G, int Sq, const int32_t* idx_kv, int Skv,
                          void* q, void* k, void* v, int vt_pitch, void* stream);
+/* One pass of the frames' antialiased bicubic uint8 resize - replaces torchvision's v2.Resize(interpolation=BICUBIC, antialias=True)
+ * on uint8 tensors in the nodes' pre-processing (reference nodes.py:184-196, utils.py:262-283; on the CPU that dispatches to ATen's
+ * native separable uint8 kernel: horizontal pass, uint8 intermediate, vertical pass).  in [outer, len_in, inner] -> out [outer,
+ * len_out, inner] along the middle axis: out = sat8((2^(precision-1) + sum_{j < xsize[x]} in[xmin[x] + j] * weights[x*kmax + j])
+ * >> precision).  inner = 1: horizontal pass over rows; inner = W: vertical pass.  Tables (device memory, one row per output
+ * sample; host/encoders.py::aa_tables builds them as ATen does - double-precision cubic (a = -0.5) taps over a support of
+ * 2*max(scale, 1), normalised, rounded half away from zero at the largest precision whose biggest weight fits int16). */
+int foley_op_resize_aa_u8(const uint8_t* in, long outer, int len_in, long inner, int len_out, const int32_t* xmin,
+                          const int32_t* xsize, const int16_t* weights, int kmax, int precision, uint8_t* out, void* stream);
 int foley_op_ln_mod(const float* x, int M, int D, float eps, const foley_rowbcast* shift,
                     const foley_rowbcast* scale, void* out, int out_dtype, void* stream);
 /* LayerNorm (+ modulation) of a residual stream that first receives the pending update of a deferred

@@ -511,3 +511,63 @@ def sample_waveform(dit_sd: SD, dac_sd: SD, heads: int, noise: Tensor, cond: Dic
     lat = sample_latents(dit_sd, heads, noise, cond["text"], cond["uncond_text"], cond["clip"],
                          cond["sync"], steps, guidance, solver, trace=trace)
     return dac_decode(dac_sd, lat.float(), rates)
+
+
+# ----------------------------------------------------------------------------- frame pre-processing (V2A conditioning)
+def _keys_cubic(x: float, a: float = -0.5) -> float:
+    x = abs(x)
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1.0
+    if x < 2.0:
+        return (((x - 5.0) * x + 8.0) * x - 4.0) * a
+    return 0.0
+
+
+def resize_u8_axis(x, axis: int, n_out: int):
+    """One axis of torchvision v2.Resize(interpolation=BICUBIC, antialias=True) on a uint8 array, the way the reference's frames
+    go through it on the CPU (nodes.py:184-196 builds the two pipelines, utils.py:262-283 runs them before `.to(device)`): for
+    uint8 CPU tensors v2.Resize dispatches to ATen's native uint8 kernel - PIL's scheme: per output sample a window of
+    `2*2*max(scale,1)` input samples around centre = scale*(i+0.5), Keys cubic (a = -0.5) weights normalised in double
+    precision, rounded half away from zero to int16 at the largest precision whose biggest weight stays below 2^15, an int32
+    accumulator preset to half an output step, arithmetic shift, saturation.  Plain loops over numpy rows.
+    Pinned against that very kernel (F.interpolate on uint8) in tests/test_oracle_golden.py - torchvision is not in the image."""
+    import numpy as np
+    x = np.moveaxis(np.asarray(x), axis, -1)
+    n_in = x.shape[-1]
+    if n_in == n_out:
+        return np.moveaxis(x, -1, axis)
+    scale = n_in / n_out
+    support = 2.0 * scale if scale >= 1.0 else 2.0
+    inv = 1.0 / scale if scale >= 1.0 else 1.0
+    kmax = int(math.ceil(support)) * 2 + 1
+    rows = []
+    wmax = 0.0
+    for i in range(n_out):
+        centre = scale * (i + 0.5)
+        lo = max(int(centre - support + 0.5), 0)
+        n = min(max(min(int(centre + support + 0.5), n_in) - lo, 0), kmax)
+        w = [_keys_cubic((j + lo - centre + 0.5) * inv) for j in range(n)]
+        tot = 0.0
+        for v in w:
+            tot += v
+        if tot != 0.0:
+            w = [v / tot for v in w]
+        wmax = max([wmax] + w)
+        rows.append((lo, w))
+    prec = 0
+    while prec < 22 and int(0.5 + wmax * (1 << (prec + 1))) < (1 << 15):
+        prec += 1
+    out = np.zeros(x.shape[:-1] + (n_out,), dtype=np.uint8)
+    for i, (lo, w) in enumerate(rows):
+        acc = np.full(x.shape[:-1], 1 << (prec - 1), dtype=np.int64)
+        for j, v in enumerate(w):
+            s = v * (1 << prec)
+            wi = int(s - 0.5) if s < 0 else int(s + 0.5)
+            acc += x[..., lo + j].astype(np.int64) * wi
+        out[..., i] = np.clip(acc >> prec, 0, 255).astype(np.uint8)
+    return np.moveaxis(out, -1, axis)
+
+
+def resize_u8(frames, size: Tuple[int, int]):
+    """uint8 [..., H, W] -> [..., size[0], size[1]]: the horizontal pass first, its uint8 image through the vertical pass."""
+    return resize_u8_axis(resize_u8_axis(frames, -1, size[1]), -2, size[0])

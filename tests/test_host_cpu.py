@@ -210,7 +210,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(rt.EXPORTED_SYMBOLS), declared ^ set(rt.EXPORTED_SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.foley_abi_version() == rt.ABI_VERSION == 10
+    assert lib.foley_abi_version() == rt.ABI_VERSION == 11
 
 
 def test_no_cpu_fallback():

@@ -169,3 +169,33 @@ def test_g10_dac_encoder():
         assert rel_err(params, g[tag + "_params"]) < 1e-5
         mean, std = O.gaussian_posterior(params)
         assert torch.equal(mean, params[:, :dc.latent_dim]) and rel_err(std, g[tag + "_std"]) < 1e-5
+
+
+RESIZE_CASES = (((2, 3, 96, 160), (224, 373)), ((1, 3, 480, 640), (512, 512)), ((1, 3, 480, 640), (224, 298)),
+                ((2, 1, 300, 224), (300, 224)), ((1, 2, 270, 480), (128, 128)), ((1, 1, 7, 3), (3, 7)), ((1, 1, 1, 9), (5, 1)),
+                ((1, 1, 33, 31), (32, 32)))
+
+
+@pytest.mark.parametrize("shape,size", RESIZE_CASES)
+def test_resize_oracle_is_the_uint8_kernel_of_the_reference_pipeline(shape, size):
+    """The frames' resize (nodes.py:184-196: v2.Resize(bicubic, antialias) on uint8 CPU tensors) dispatches to ATen's native uint8
+    kernel; torchvision is not in the image, so the pin is that kernel itself - F.interpolate on uint8.  The oracle's integer
+    restatement (and the tap tables the HIP pass consumes, host/encoders.py::aa_tables) must equal it bit for bit: up- and
+    down-scaling, identity axes, windows cut by the borders, one-sample axes."""
+    import numpy as np
+    from foley_amd.host import encoders as E
+    g = torch.Generator().manual_seed(sum(shape) + sum(size))
+    fr = torch.randint(0, 256, shape, generator=g, dtype=torch.uint8)
+    fr[..., : shape[-2] // 2, :] = fr[..., : shape[-2] // 2, :] // 64 * 85      # flat areas + hard edges: overshoot, saturation
+    ref = F.interpolate(fr, size=size, mode="bicubic", antialias=True).numpy()
+    got = O.resize_u8(fr.numpy(), size)
+    assert got.dtype == np.uint8 and got.shape == ref.shape and np.array_equal(got, ref)
+    for n_in, n_out in ((shape[-1], size[1]), (shape[-2], size[0])):
+        if n_in == n_out:
+            continue
+        xmin, xsize, w, prec = E.aa_tables(n_in, n_out)
+        x = fr.numpy().astype(np.int64)[0, 0, 0] if n_in == shape[-1] else fr.numpy().astype(np.int64)[0, 0, :, 0]
+        want = O.resize_u8_axis(x.astype(np.uint8), 0, n_out)
+        mine = np.array([np.clip(((1 << (prec - 1)) + int((x[xmin[i]:xmin[i] + xsize[i]] * w[i, :xsize[i]].astype(np.int64)).sum())) >> prec,
+                                 0, 255) for i in range(n_out)], dtype=np.uint8)
+        assert np.array_equal(mine, want), (n_in, n_out)
