@@ -145,7 +145,8 @@ __global__ __launch_bounds__(64) void attn_kernel(const AttnArgs a) {
   if (tok >= a.Sq) return;
   const float inv = 1.0f / l_run;
   OutT* dst;
-  if (tok < a.split) dst = (OutT*)a.outA + ((long)b * a.split + tok) * (a.H * HD);
+  if (a.out_rows) dst = (OutT*)a.outA + (long)a.out_rows[(long)b * a.Sq + tok] * (a.H * HD);
+  else if (tok < a.split) dst = (OutT*)a.outA + ((long)b * a.split + tok) * (a.H * HD);
   else dst = (OutT*)a.outB + ((long)b * (a.Sq - a.split) + (tok - a.split)) * (a.H * HD);
   dst += h * HD;
 #pragma unroll
@@ -720,7 +721,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   if (tok >= a.Sq) return;
   const float inv = 1.0f / l_run;
   OutT* dst;
-  if (tok < a.split) dst = (OutT*)a.outA + ((long)b * a.split + tok) * (a.H * HD);
+  if (a.out_rows) dst = (OutT*)a.outA + (long)a.out_rows[(long)b * a.Sq + tok] * (a.H * HD);
+  else if (tok < a.split) dst = (OutT*)a.outA + ((long)b * a.split + tok) * (a.H * HD);
   else dst = (OutT*)a.outB + ((long)b * (a.Sq - a.split) + (tok - a.split)) * (a.H * HD);
   dst += h * HD;
   // lane (j, kh) holds dims d*32 + 8*g4 + 4*kh + {0..3} of query j: 4 consecutive outputs per store
@@ -1074,6 +1076,7 @@ int launch_attention(const AttnArgs& a_in, int out_dtype, hipStream_t st) {
   if (a.Sq <= 0 || a.Skv <= 0) return foley_set_err("attention: empty sequence", __FILE__, __LINE__);
   const int hd = a.head_dim > 0 ? a.head_dim : 128;
   if (hd != 128 && hd != 64) return foley_set_err("attention: head_dim must be 128 or 64", __FILE__, __LINE__);
+  if (a.out_rows && hd != 64) return foley_set_err("attention: the output row table serves head_dim 64 (the conditioning encoders' kernels)", __FILE__, __LINE__);
   dim3 grid((a.Sq + 31) / 32, a.H, a.Bq), block(64);
   const dim3 grid1(grid.x * grid.y * grid.z);   // 16-bit kernels: 1-D grid, XCD-aware remap inside
   if (foley_is_half(a.in_dtype)) {

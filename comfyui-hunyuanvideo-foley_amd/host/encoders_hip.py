@@ -52,6 +52,13 @@ class _Engine:
             t = self.vecs[k] = (t - 1.0 if minus_one else t).contiguous()
         return t
 
+    def table(self, key: str, w: Tensor) -> Tensor:
+        """An embedding table staged once on the device in its OWN dtype (rows are widened after the lookup)."""
+        t = self.mats.get(key + "#tab")
+        if t is None:
+            t = self.mats[key + "#tab"] = w.detach().to(self.dev).contiguous()
+        return t
+
     def fused(self, sd: SD, key: str, wkeys, bkeys) -> SD:
         """Row-concatenation of several linear layers that read the same input (q / k / v projections kept as separate modules
         by the HF encoders) staged once as ONE matrix / bias under `key`: one GEMM launch and one read of the activations
@@ -107,11 +114,15 @@ class _Engine:
             t = self.tabs[key] = build().to(self.dev, torch.int32).contiguous()
         return t
 
-    def attention_regrouped(self, qkv: Tensor, heads: int, idx_q: Tensor, idx_kv: Tensor) -> Tensor:
+    def attention_regrouped(self, qkv: Tensor, heads: int, idx_q: Tensor, idx_kv: Tensor, out: Optional[Tensor] = None) -> Tensor:
         """Attention straight from a fused projection qkv [rows, 3*H*64]: ONE regroup launch (foley_op_qkv_regroup: head split,
-        token gather per group, transposed V for the 16-bit kernels) + the attention -> [G, Sq, H*64] token-major."""
+        token gather per group, transposed V for the 16-bit kernels) + the attention -> [G, Sq, H*64] token-major; with `out`
+        [rows, H*64] every query is written back to the row it was gathered from (foley_op_attention_scatter) and `out` returns."""
         q, k, v = rt.op_qkv_regroup(qkv, heads, idx_q, idx_kv)
         G, H, Sq, hd = q.shape
+        if out is not None:
+            rt.op_attention_scatter(q, k, v, idx_q, out)
+            return out
         out = torch.empty(G, Sq, H * hd, device=self.dev, dtype=self.dtype)
         rt.op_attention(q, k, v, out, out, 0)
         return out
@@ -143,7 +154,8 @@ def _divided_attention(E: _Engine, h: Tensor, sd: SD, key: str, B: int, frames: 
     base = lambda: (torch.arange(B) * N)[:, None]
     all_rows = E.index(("all", B, N), lambda: base() + torch.arange(N)[None])                   # [B, N]
     cls_rows = E.index(("cls", B, N), lambda: base().clone())                                   # [B, 1]
-    cls_out = E.attention_regrouped(qkv, HEADS, cls_rows, all_rows)                             # [B, 1, D]
+    out = torch.empty(B * N, HEADS * HD, device=E.dev, dtype=E.dtype)     # both attentions scatter into the token-major layer output
+    E.attention_regrouped(qkv, HEADS, cls_rows, all_rows, out=out)                              # rows b*N
     if over == "time":      # groups = (batch, location), sequence = frames
         def build():
             tok = 1 + torch.arange(frames)[None, :] * space + torch.arange(space)[:, None]     # [space, frames]
@@ -156,12 +168,7 @@ def _divided_attention(E: _Engine, h: Tensor, sd: SD, key: str, B: int, frames: 
     iq = E.index((over, "q", B, frames, space), build)
     ikv = E.index((over, "kv", B, frames, space),
                   lambda: torch.cat(((torch.arange(B) * N).repeat_interleave(G)[:, None], build()), dim=1))   # CLS key / value first
-    out = E.attention_regrouped(qkv, HEADS, iq, ikv)                                            # [B*G, s, D]
-    D = HEADS * HD
-    if over == "time":
-        out = out.view(B, space, frames, D).permute(0, 2, 1, 3)
-    out = out.reshape(B, frames * space, D)
-    return torch.cat((cls_out, out), dim=1).reshape(B * N, D)
+    return E.attention_regrouped(qkv, HEADS, iq, ikv, out=out)      # the inverse rearrange + torch.cat((cls_out, x), 1) of the reference = the scatter
 
 
 def synchformer_segments_hip(sd: SD, x: Tensor, dtype: torch.dtype = torch.float16, prefix: str = "vfeat_extractor.",
@@ -312,9 +319,9 @@ def clap_text_hidden_hip(sd: SD, input_ids: Tensor, attention_mask: Tensor, dtyp
         raise rt.FoleyRuntimeError("the engine's CLAP text encoder expects right-padded prompts")
     nz = input_ids.ne(pad_id).long()
     pos_ids = torch.cumsum(nz, dim=1) * nz + pad_id                      # create_position_ids_from_input_ids
-    f32 = lambda k: sd[p + k].to(E.dev, torch.float32)
-    emb = f32("embeddings.word_embeddings.weight")[input_ids] + f32("embeddings.token_type_embeddings.weight")[0] \
-        + f32("embeddings.position_embeddings.weight")[pos_ids]
+    tab = lambda k: E.table(p + k, sd[p + k])                            # rows are picked first, then widened (the word table is 154 MB in fp32)
+    emb = tab("embeddings.word_embeddings.weight")[input_ids].float() + tab("embeddings.token_type_embeddings.weight")[0].float() \
+        + tab("embeddings.position_embeddings.weight")[pos_ids].float()
     D = emb.shape[-1]
     hd = D // heads
     if hd != HD:
@@ -330,10 +337,10 @@ def clap_text_hidden_hip(sd: SD, input_ids: Tensor, attention_mask: Tensor, dtyp
         qkv = E.linear(xT, fq, a_ + "qkv#.w", a_ + "qkv#.b")                  # [B*T, 3*D]
         # per prompt: all T query rows against its first len_b keys - one regroup + one attention launch each (index tables per
         # (prompt slot, T, len); until round 5: slices, .contiguous() copies and a padded V^T per prompt, ~14 launches per layer)
-        att = torch.cat([E.attention_regrouped(
-            qkv, heads,
-            E.index(("clap-q", b, T), lambda b=b: (b * T + torch.arange(T))[None]),
-            E.index(("clap-kv", b, T, lens_h[b]), lambda b=b: (b * T + torch.arange(lens_h[b]))[None])) for b in range(B)])
+        att = torch.empty(B * T, D, device=E.dev, dtype=E.dtype)
+        for b in range(B):
+            E.attention_regrouped(qkv, heads, E.index(("clap-q", b, T), lambda b=b: (b * T + torch.arange(T))[None]),
+                                  E.index(("clap-kv", b, T, lens_h[b]), lambda b=b: (b * T + torch.arange(lens_h[b]))[None]), out=att)
         E.linear_residual(x, att.reshape(B * T, D), sd, l + ".attention.output.dense.weight", l + ".attention.output.dense.bias")
         y = E.ln(x, sd, l + ".attention.output.LayerNorm", eps, out_dtype=torch.float32)
         hid = E.linear(y.to(E.dtype), sd, l + ".intermediate.dense.weight", l + ".intermediate.dense.bias", act="gelu_erf")

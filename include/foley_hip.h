@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FOLEY_ABI_VERSION 11   /* 11: foley_op_resize_aa_u8 (the frames' antialiased uint8 resize, bit for bit); 10: foley_op_qkv_regroup (token regrouping of the conditioning encoders' attention); 9: foley_bcast_local (single-process grouped broadcast of the arenas); 8: foley_qkv_split_desc.attn_* (cross attention in the epilogue of its q projection), foley_abort / FOLEY_ERR_ABORTED; 7: FOLEY_DT_F16 as a compute dtype (foley_config.compute_dtype, op descriptors); 6: foley_rowbcast.Ls (mode 2: nearest-exact up-sampled operand); 5: reference-keyed loading (foley_weights_*, foley_load_tensor, foley_bcast_weights); 4: fp8 weight storage (dtype codes 3/4, foley_gemm_desc.ldw/.wfmt); 3: foley_profile_forward; 2: foley_gemm_desc gained partials / qkv / rstride; foley_op_ln_mod_pending, foley_dac_encode */
+#define FOLEY_ABI_VERSION 11   /* 11: foley_op_resize_aa_u8 (the frames' antialiased uint8 resize, bit for bit), foley_op_attention_scatter; 10: foley_op_qkv_regroup (token regrouping of the conditioning encoders' attention); 9: foley_bcast_local (single-process grouped broadcast of the arenas); 8: foley_qkv_split_desc.attn_* (cross attention in the epilogue of its q projection), foley_abort / FOLEY_ERR_ABORTED; 7: FOLEY_DT_F16 as a compute dtype (foley_config.compute_dtype, op descriptors); 6: foley_rowbcast.Ls (mode 2: nearest-exact up-sampled operand); 5: reference-keyed loading (foley_weights_*, foley_load_tensor, foley_bcast_weights); 4: fp8 weight storage (dtype codes 3/4, foley_gemm_desc.ldw/.wfmt); 3: foley_profile_forward; 2: foley_gemm_desc gained partials / qkv / rstride; foley_op_ln_mod_pending, foley_dac_encode */
 
 enum foley_dtype {
   FOLEY_DT_F32 = 0, FOLEY_DT_BF16 = 1, FOLEY_DT_I32 = 2,
@@ -261,6 +261,12 @@ int foley_op_attention(const void* q, const void* k, const void* v, int in_dtype
 int foley_op_attention_hd(const void* q, const void* k, const void* v, int in_dtype, int vt_pitch, int Bq, int H,
                           int Sq, int Skv, int kv_bdiv, void* outA, void* outB, int split, int out_dtype,
                           int head_dim, void* stream);
+/* foley_op_attention_hd at head_dim 64 with scattered output rows: query t of group g lands in row out_rows[g*Sq + t] of out
+ * [rows, H*64] - normally the table the queries were gathered by (foley_op_qkv_regroup's idx_q), so that the CLS attention and the
+ * time / space group attention of a DividedAttention layer (vit_helper.py:37-105: `torch.cat((cls_out, x), dim=1)` after the inverse
+ * rearrange) write ONE token-major buffer, ready for the output projection. */
+int foley_op_attention_scatter(const void* q, const void* k, const void* v, int in_dtype, int vt_pitch, int G, int H, int Sq,
+                               int Skv, const int32_t* out_rows, void* out, int out_dtype, void* stream);
 /* Token regrouping between a fused q/k/v projection and foley_op_attention_hd at head_dim 64 - the conditioning encoders
  * (reference models/synchformer/vit_helper.py:37-105 DividedAttention: patch tokens attend over the frames of their location or
  * the locations of their frame with the CLS key / value prepended; transformers' SiglipAttention / ClapTextSelfAttention head split):

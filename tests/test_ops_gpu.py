@@ -781,3 +781,27 @@ def test_qkv_regroup(dev, dtype, G, H, Sq, Skv, rows):
         pitch = (Skv + 31) // 32 * 32
         assert v.shape == (G, H, 64, pitch)
         assert torch.equal(v[..., :Skv], want_v.transpose(2, 3)) and not bool(v[..., Skv:].any())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("G,H,Sq,Skv", [(3, 12, 8, 9), (2, 12, 1, 197), (5, 4, 196, 197), (1, 12, 130, 77)])
+def test_attention_scatter(dev, dtype, G, H, Sq, Skv):
+    """foley_op_attention_scatter: the head_dim-64 attention whose query (g, t) is written to row out_rows[g, t] of a token-major
+    buffer (the conditioning encoders: the inverse rearrange + torch.cat of vit_helper.py:95-105) - EQUAL to the plain
+    foley_op_attention_hd output placed by the same permutation; rows no query maps to stay untouched."""
+    from foley_amd.host import runtime as rt
+    g = torch.Generator().manual_seed(G * 100 + Sq)
+    rows = G * Sq + 7
+    qkv = torch.randn(rows, 3 * H * 64, generator=g).to(dtype).to(dev)
+    iq = torch.randperm(rows, generator=g)[: G * Sq].view(G, Sq).to(torch.int32).to(dev)
+    ikv = torch.randint(0, rows, (G, Skv), generator=g, dtype=torch.int32).to(dev)
+    q, k, v = rt.op_qkv_regroup(qkv, H, iq, ikv)
+    plain = torch.empty(G, Sq, H * 64, device=dev, dtype=dtype)
+    rt.op_attention(q, k, v, plain, plain, 0)
+    out = torch.full((rows, H * 64), 7.0, device=dev, dtype=dtype)
+    rt.op_attention_scatter(q, k, v, iq, out)
+    want = torch.full((rows, H * 64), 7.0, device=dev, dtype=dtype)
+    want[iq.view(-1).long()] = plain.view(G * Sq, H * 64)
+    assert torch.equal(out, want)
+    with pytest.raises(rt.FoleyRuntimeError):
+        rt.op_attention_scatter(q, k, v, iq.long(), out)
