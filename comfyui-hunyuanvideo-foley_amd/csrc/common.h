@@ -170,6 +170,9 @@ struct RowBcast {
   float scale;          // mode 2: float(Ls) / float(L)
   int per;              // mode 2: 0, or a power of two: the Ls rows repeat with this period and only the first `per`
                         // rows per cfg are stored (empty sync features: sync_pos_emb makes 8 distinct rows per half)
+  int dense_from;       // mode 2: cfg halves [0, dense_from) are stored periodically (`per` rows each), the others with all their
+  int dense_base;       // Ls rows from operand row dense_base on (0 / 0: every half dense; INT_MAX: every half periodic).  A video
+                        // clip under CFG: the unconditional half carries the empty sync features (8 rows), the other one Ls rows
 };
 
 __host__ __device__ __forceinline__ int rb_nearest_exact(int l, float scale, int Ls) {
@@ -183,7 +186,7 @@ __device__ __forceinline__ const float* rb_row(const RowBcast& b, int r) {
   if (b.mode == 1) p += ((long)(r / b.rows_per_cfg) * b.L + (r % b.L)) * b.ld;
   else if (b.mode == 2) {
     const int s = rb_nearest_exact(r % b.L, b.scale, b.Ls), cfg = r / b.rows_per_cfg;
-    p += (b.per ? (long)cfg * b.per + (s & (b.per - 1)) : (long)cfg * b.Ls + s) * b.ld;
+    p += (cfg < b.dense_from ? (long)cfg * b.per + (s & (b.per - 1)) : (long)b.dense_base + (long)(cfg - b.dense_from) * b.Ls + s) * b.ld;
   }
   return p;
 }

@@ -6,6 +6,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -125,7 +126,9 @@ struct foley_ctx {
   void* txt_v = nullptr;            // [n_triple][ncfg, H, Lt, 128] or transposed [.., 128, ceil32(Lt)]
   float* v_cond0 = nullptr;         // [ncfg, Lv, D]
   float* sync_tok = nullptr;        // [ncfg, Ls, D] sync tokens after sync_in; audio frame l reads row nearest_exact(l) (RowBcast mode 2)
-  int sync_per = 0;                 // 8 when the token rows of EVERY cfg half repeat with period 8 (empty sync features), else 0
+  int sync_per = 0;                 // 8 when the token rows of the first sync_lead cfg halves repeat with period 8 (empty sync features), else 0
+  int sync_lead = 0;                // number of leading 8-periodic halves: ncfg = all of them (text-to-audio); 1 of 2 = a video clip under
+                                    // CFG (unconditional half first, utils.py:150-176); 0 = none
   int* flag = nullptr;              // device scratch word of the periodicity check
   int* ident_idx = nullptr;         // 0..max(Lv,La)-1
   // forward workspace
@@ -629,16 +632,24 @@ extern "C" int foley_prepare(foley_ctx* c, const foley_plan* pl, void* stream_v)
     // Empty sync features (text-to-audio; the unconditional half of a CFG pair) are one learned row plus
     // sync_pos_emb, which repeats every 8 tokens: the token rows are then 8-periodic and the per-token work of the
     // single-stream blocks only has 8 distinct rows per half.  Detected on the data (bit patterns), not assumed.
-    HIPTRY(hipMemsetAsync(c->flag, 0, 4, st));
+    // One flag per cfg half: under CFG a video clip's unconditional half carries the empty features (periodic) next to the dense
+    // conditional half - the modulation GEMM then runs on 8 + Ls rows instead of 2 Ls (round 5).
+    if (ncfg > 32) return FAIL(FOLEY_ERR_INVALID, "more than 32 cfg halves");
+    HIPTRY(hipMemsetAsync(c->flag, 0, 4 * 32, st));
     TRY(launch_rows_periodic_check(c->sync_tok, ncfg, Ls, 8, D, c->flag, st));
   }
   HIPTRY(hipStreamSynchronize(st));
   {
-    int differs = 1;
-    HIPTRY(hipMemcpy(&differs, c->flag, 4, hipMemcpyDeviceToHost));
-    const int per = (!differs && Ls > 8) ? 8 : 0;
-    if (c->graph_exec && per != c->sync_per) ctx_drop_graph(c);   // the captured modulation GEMM has another M
+    int differs[32];
+    HIPTRY(hipMemcpy(differs, c->flag, 4 * 32, hipMemcpyDeviceToHost));
+    static const bool mixed_on = []() { const char* e = getenv("FOLEY_SYNC_MIXED"); return !(e && e[0] == '0'); }();
+    int lead = 0;
+    while (Ls > 8 && lead < ncfg && !differs[lead]) ++lead;
+    if (!mixed_on && lead < ncfg) lead = 0;                      // A/B switch: all halves periodic or none (rounds 2-4)
+    const int per = lead > 0 ? 8 : 0;
+    if (c->graph_exec && (per != c->sync_per || lead != c->sync_lead)) ctx_drop_graph(c);   // the captured modulation GEMM has another M
     c->sync_per = per;
+    c->sync_lead = lead;
   }
   if (!c->fw.ok) TRY(resolve_forward_weights(c));
   {
@@ -649,7 +660,7 @@ extern "C" int foley_prepare(foley_ctx* c, const foley_plan* pl, void* stream_v)
     // FOLEY_SMOD_TABLE_GB (default 24; 1.06 GB for the 16 distinct rows of text-to-audio, 14.9 GB for the 224 rows of a 5 s
     // video clip); longer clips keep the per-iteration GEMM of run_forward.
     static const double cap_gb = []() { const char* e = getenv("FOLEY_SMOD_TABLE_GB"); return e ? atof(e) : 24.0; }();
-    const int P = c->sync_per ? c->sync_per : Ls;
+    const int P = (c->sync_per && c->sync_lead == ncfg) ? c->sync_per : Ls;   // hoisting serves the all-periodic case
     const size_t ncol = (size_t)f.depth_single * 6 * D;
     const size_t tab_bytes = (size_t)NI * ncfg * P * ncol * 4;
     // ... and only where the weight stream is what the per-iteration GEMM costs (a few distinct rows: the 8-periodic empty sync
@@ -709,8 +720,15 @@ static RowBcast rb_tok(const float* base, long ld, int rows_per_cfg, int L) {
   return RowBcast{base, ld, 1, rows_per_cfg, L, nullptr, 0, 0, 0.f, 0};
 }
 // operand with Ls rows per cfg, read by audio frame l at its nearest-exact source row (common.h RowBcast mode 2)
-static RowBcast rb_up(const float* base, long ld, int rows_per_cfg, int L, int Ls, int per = 0) {
-  return RowBcast{base, ld, 2, rows_per_cfg, L, nullptr, 0, Ls, (float)Ls / (float)L, per};
+// per > 0: the first `lead` cfg halves store `per` rows each (8-periodic token rows), the others all Ls rows behind them;
+// lead < 0: every half periodic
+static RowBcast rb_up(const float* base, long ld, int rows_per_cfg, int L, int Ls, int per = 0, int lead = -1) {
+  RowBcast r{base, ld, 2, rows_per_cfg, L, nullptr, 0, Ls, (float)Ls / (float)L, per, 0, 0};
+  if (per > 0) {
+    r.dense_from = lead < 0 ? INT_MAX : lead;
+    r.dense_base = lead < 0 ? 0 : lead * per;
+  }
+  return r;
 }
 
 // Per-kernel profile (foley_profile_forward): the op's kernel launch carries two events as its own
@@ -776,15 +794,20 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
       HIPTRY(hipEventRecord(c->ev_fork, st));
       HIPTRY(hipStreamWaitEvent(sd, c->ev_fork, 0));
     }
-    TRY(launch_rows_add_act(c->sync_tok, rb_vec(c->vec_table, D, sp), ncfg * Ls, D, 1, c->svec, T, sd));
+    // distinct rows only: 8 per 8-periodic half (the leading sync_lead halves), Ls per dense half - packed back to back, which
+    // is the row order of the modulation table (RowBcast::dense_from / dense_base)
+    const int lead = c->sync_per ? c->sync_lead : 0, R = lead * c->sync_per + (ncfg - lead) * Ls;
+    for (int h = 0; h < lead; ++h)
+      TRY(launch_rows_add_act(c->sync_tok + (size_t)h * Ls * D, rb_vec(c->vec_table, D, sp), c->sync_per, D, 1,
+                              (char*)c->svec + (size_t)h * c->sync_per * D * es, T, sd));
+    if (lead < ncfg)
+      TRY(launch_rows_add_act(c->sync_tok + (size_t)lead * Ls * D, rb_vec(c->vec_table, D, sp), (ncfg - lead) * Ls, D, 1,
+                              (char*)c->svec + (size_t)lead * c->sync_per * D * es, T, sd));
     if (f.depth_single > 0) {
-      // one GEMM for all blocks: [ncfg*P, D] x [n_single*6D, D]^T -> smod [ncfg*P, n_single*6D], P = Ls, or 8 when
-      // the token rows are 8-periodic (virtual rows: row r of the product is token r % P of half r / P)
+      // one GEMM for all blocks: [R, D] x [n_single*6D, D]^T -> smod [R, n_single*6D]
       const double n = (double)f.depth_single * 6 * D;
-      const int P = c->sync_per ? c->sync_per : Ls;
-      GemmArgs gm = gemm_plain(c->svec, ncfg * P, W.smod, c->smod, (long)f.depth_single * 6 * D);
-      gm.segV = P; gm.segS = Ls;
-      TRY(prof_begin(c, st, "single.modulation (all blocks, one GEMM)", gf(ncfg * P, n, D), gb(ncfg * P, n, D, 4)));
+      GemmArgs gm = gemm_plain(c->svec, R, W.smod, c->smod, (long)f.depth_single * 6 * D);
+      TRY(prof_begin(c, st, "single.modulation (all blocks, one GEMM)", gf(R, n, D), gb(R, n, D, 4)));
       TRY(launch_gemm(gm, T, EPI_STORE_F32, 0, sd));
       TRY(prof_end(c, st));
     }
@@ -921,11 +944,15 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
   for (int blk = 0; blk < f.depth_single; ++blk) {
     const SingleW& w = W.s[blk];
     const float* smod_b = (c->smod_hoisted ? (const float*)c->smod_tab.p : c->smod) + (size_t)blk * 6 * D;   // column block of the fused table
+    // table layout per iteration: every half periodic (8 rows each) | the leading halves periodic, the others dense (the
+    // per-iteration GEMM only - a hoisted table that is not all-periodic is dense) | every half dense
+    const bool allper = c->sync_per && c->sync_lead == ncfg;
+    const int per_eff = (allper || !c->smod_hoisted) ? c->sync_per : 0;
     auto sm = [&](int chunk) {
-      RowBcast r = rb_up(smod_b + (size_t)chunk * D, 6L * D * f.depth_single, clips * La, La, Ls, c->sync_per);
+      RowBcast r = rb_up(smod_b + (size_t)chunk * D, 6L * D * f.depth_single, clips * La, La, Ls, per_eff, allper ? -1 : c->sync_lead);
       if (c->smod_hoisted) {   // the table of every iteration: this iteration's rows start at step * ncfg*P*ld
         r.step_ptr = sp;
-        r.step_stride = (long)ncfg * (c->sync_per ? c->sync_per : Ls) * 6L * D * f.depth_single;
+        r.step_stride = (long)ncfg * (allper ? c->sync_per : Ls) * 6L * D * f.depth_single;
       }
       return r;
     };
@@ -1345,7 +1372,12 @@ static RowBcast to_rb(const foley_rowbcast* r) {
   if (!r || !r->p) return rb_none();
   const int L = r->L > 0 ? r->L : 1, Ls = r->mode == 2 ? (r->Ls > 0 ? r->Ls : 1) : 0;
   const int per = (r->mode == 2 && r->period > 0 && !(r->period & (r->period - 1))) ? r->period : 0;
-  return RowBcast{r->p, (long)r->ld, r->mode, r->rows_per_cfg > 0 ? r->rows_per_cfg : 1, L, nullptr, 0, Ls, Ls ? (float)Ls / (float)L : 0.f, per};
+  RowBcast b{r->p, (long)r->ld, r->mode, r->rows_per_cfg > 0 ? r->rows_per_cfg : 1, L, nullptr, 0, Ls, Ls ? (float)Ls / (float)L : 0.f, per, 0, 0};
+  if (per > 0) {
+    b.dense_from = r->periodic_cfgs > 0 ? r->periodic_cfgs : INT_MAX;
+    b.dense_base = r->periodic_cfgs > 0 ? r->periodic_cfgs * per : 0;
+  }
+  return b;
 }
 
 extern "C" int foley_op_gemm(const foley_gemm_desc* d, void* stream) {

@@ -133,12 +133,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[F
 struct RbCursor {   // rb_row() for rows that advance by a fixed stride, without per-row divisions
   const float* p;
   long ld;
-  int mode, rpc, L, cfg, rc, l, Ls, per;
+  int mode, rpc, L, cfg, rc, l, Ls, per, dense_from, dense_base;
   float scale;
   __device__ __forceinline__ void init(const RowBcast& b, int row) {
     p = b.p;
     if (p && b.step_ptr) p += (long)(*b.step_ptr) * b.step_stride;
-    ld = b.ld; mode = p ? b.mode : 0; rpc = b.rows_per_cfg; L = b.L; Ls = b.Ls; scale = b.scale; per = b.per;
+    ld = b.ld; mode = p ? b.mode : 0; rpc = b.rows_per_cfg; L = b.L; Ls = b.Ls; scale = b.scale; per = b.per; dense_from = b.dense_from; dense_base = b.dense_base;
     cfg = 0; rc = 0; l = 0;
     if (mode != 0) { cfg = row / rpc; rc = row - cfg * rpc; l = row % L; }
   }
@@ -146,7 +146,7 @@ struct RbCursor {   // rb_row() for rows that advance by a fixed stride, without
     if (mode == 1) return p + ((long)cfg * L + l) * ld;
     if (mode == 2) {   // common.h RowBcast mode 2
       const int s = rb_nearest_exact(l, scale, Ls);
-      return p + (per ? (long)cfg * per + (s & (per - 1)) : (long)cfg * Ls + s) * ld;
+      return p + (cfg < dense_from ? (long)cfg * per + (s & (per - 1)) : (long)dense_base + (long)(cfg - dense_from) * Ls + s) * ld;
     }
     return p;
   }

@@ -741,17 +741,19 @@ int launch_qkv_split(const QkvSplitArgs& a, hipStream_t st) {
 // flag |= 1 when some row s >= period of a group differs (bit pattern) from row s - period
 __global__ void rows_periodic_check_kernel(const unsigned* __restrict__ x, int groups, int rows, int period, int D, int* flag) {
   const long per_g = (long)(rows - period) * D, n = (long)groups * per_g;
-  bool diff = false;
+  unsigned diff = 0;   // bit g: group g (<= 32 groups) has a row that differs from the one `period` rows above it -> flag[g] = 1
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const long g = i / per_g, r = i - g * per_g;
     const long at = (g * rows + period) * D + r;
-    diff = diff || x[at] != x[at - (long)period * D];
+    if (x[at] != x[at - (long)period * D]) diff |= 1u << g;
   }
-  if (diff) atomicOr(flag, 1);
+  for (int g = 0; g < groups; ++g)
+    if (diff >> g & 1u) atomicOr(flag + g, 1);
 }
 
 int launch_rows_periodic_check(const float* x, int groups, int rows, int period, int D, int* flag, hipStream_t st) {
   if (rows <= period) return 0;
+  if (groups > 32) return foley_set_err("rows_periodic_check: at most 32 groups", __FILE__, __LINE__);
   const long n = (long)groups * (rows - period) * D;
   FOLEY_LAUNCH(rows_periodic_check_kernel, dim3(grid1d(n, 256)), dim3(256), 0, st, (const unsigned*)x, groups, rows, period, D, flag);
   FOLEY_LAUNCH_CHECK();

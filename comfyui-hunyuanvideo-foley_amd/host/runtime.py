@@ -46,7 +46,7 @@ class FoleyPlanC(C.Structure):
 
 class RowBcastC(C.Structure):
     _fields_ = [("p", C.c_void_p), ("ld", C.c_int64), ("mode", C.c_int32), ("rows_per_cfg", C.c_int32),
-                ("L", C.c_int32), ("Ls", C.c_int32), ("period", C.c_int32)]
+                ("L", C.c_int32), ("Ls", C.c_int32), ("period", C.c_int32), ("periodic_cfgs", C.c_int32)]
 
 
 class QkvSplitDescC(C.Structure):
@@ -413,10 +413,12 @@ def bcast_local(buffers_per_device: Sequence[Sequence[torch.Tensor]]) -> float:
 
 
 def rowbcast(t: Optional[torch.Tensor], mode: int = 0, rows_per_cfg: int = 1, L: int = 1,
-             ld: Optional[int] = None, Ls: int = 0, period: int = 0) -> RowBcastC:
-    """mode 2: `t` holds Ls rows per cfg; token l of a clip reads row nearest_exact(l) (tables.nearest_exact_index)."""
+             ld: Optional[int] = None, Ls: int = 0, period: int = 0, periodic_cfgs: int = 0) -> RowBcastC:
+    """mode 2: `t` holds Ls rows per cfg; token l of a clip reads row nearest_exact(l) (tables.nearest_exact_index).  period > 0:
+    only `period` rows per cfg are stored - for every cfg half, or (periodic_cfgs = k > 0) for the first k halves only, the
+    others following with all their Ls rows."""
     r = RowBcastC()
-    r.Ls, r.period = Ls, period
+    r.Ls, r.period, r.periodic_cfgs = Ls, period, periodic_cfgs
     if t is not None and not t.is_cuda:
         raise FoleyRuntimeError("row-broadcast operand must live on the GPU")
     r.p = t.data_ptr() if t is not None else None     # views allowed: rows are addressed through `ld`

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FOLEY_ABI_VERSION 11   /* 11: foley_op_resize_aa_u8 (the frames' antialiased uint8 resize, bit for bit), foley_op_attention_scatter; 10: foley_op_qkv_regroup (token regrouping of the conditioning encoders' attention); 9: foley_bcast_local (single-process grouped broadcast of the arenas); 8: foley_qkv_split_desc.attn_* (cross attention in the epilogue of its q projection), foley_abort / FOLEY_ERR_ABORTED; 7: FOLEY_DT_F16 as a compute dtype (foley_config.compute_dtype, op descriptors); 6: foley_rowbcast.Ls (mode 2: nearest-exact up-sampled operand); 5: reference-keyed loading (foley_weights_*, foley_load_tensor, foley_bcast_weights); 4: fp8 weight storage (dtype codes 3/4, foley_gemm_desc.ldw/.wfmt); 3: foley_profile_forward; 2: foley_gemm_desc gained partials / qkv / rstride; foley_op_ln_mod_pending, foley_dac_encode */
+#define FOLEY_ABI_VERSION 11   /* 11: foley_op_resize_aa_u8 (the frames' antialiased uint8 resize, bit for bit), foley_op_attention_scatter, foley_rowbcast.periodic_cfgs; 10: foley_op_qkv_regroup (token regrouping of the conditioning encoders' attention); 9: foley_bcast_local (single-process grouped broadcast of the arenas); 8: foley_qkv_split_desc.attn_* (cross attention in the epilogue of its q projection), foley_abort / FOLEY_ERR_ABORTED; 7: FOLEY_DT_F16 as a compute dtype (foley_config.compute_dtype, op descriptors); 6: foley_rowbcast.Ls (mode 2: nearest-exact up-sampled operand); 5: reference-keyed loading (foley_weights_*, foley_load_tensor, foley_bcast_weights); 4: fp8 weight storage (dtype codes 3/4, foley_gemm_desc.ldw/.wfmt); 3: foley_profile_forward; 2: foley_gemm_desc gained partials / qkv / rstride; foley_op_ln_mod_pending, foley_dac_encode */
 
 enum foley_dtype {
   FOLEY_DT_F32 = 0, FOLEY_DT_BF16 = 1, FOLEY_DT_I32 = 2,
@@ -192,6 +192,8 @@ typedef struct foley_rowbcast {  /* row-broadcast operand (AdaLN shift/scale/gat
   int32_t Ls;           /* mode 2 only */
   int32_t period;       /* mode 2 only: 0, or a power of two - the up-sampled sequence repeats with this period and the
                          * operand stores only `period` rows per cfg (row (nearest_exact(l) mod period)) */
+  int32_t periodic_cfgs; /* mode 2 with period > 0: 0 = every cfg half is stored periodically; k > 0 = only the first k halves
+                         * (`period` rows each), the others follow with all their Ls rows (ABI 11; fills the struct's padding) */
 } foley_rowbcast;
 
 /* Head split applied to a fused q/k/v (or cross-attention q) projection: per (row, head) RMSNorm

@@ -821,7 +821,8 @@ def test_profile_forward_brackets(tiny):
     y1 = model.ctx.dit_forward(lat, 1)
     y2 = model.ctx.dit_forward(lat, 1)
     assert torch.equal(y1, y2)
-    # 5 s of video: 2 x 112 dense sync rows - the modulation GEMM stays in the loop, on the sync tokens (not on the 250 audio frames)
+    # 5 s of video: the modulation GEMM stays in the loop, on the DISTINCT sync-token rows (not on the 250 audio frames): the 8
+    # periodic rows of the unconditional half (empty sync features) + the 112 dense rows of the conditional half
     La5, _lv5, Ls5 = C.lengths(5.0)
     lat5 = torch.randn(1, 128, La5, device=model.device)
     cond5 = synth.synth_conditioning(C.TINY, 5.0, t2a=False)
@@ -830,7 +831,7 @@ def test_profile_forward_brackets(tiny):
     model.ctx.prepare(plan5)
     prof5, _ = model.ctx.profile_forward(lat5, it=1, repeats=1)
     smod = {e["label"]: e for e in prof5}["single.modulation (all blocks, one GEMM)"]
-    assert abs(smod["flop_per_launch"] - 2 * (2 * Ls5) * D * ns * 6 * D) < 1
+    assert abs(smod["flop_per_launch"] - 2 * (8 + Ls5) * D * ns * 6 * D) < 1
     y5 = model.ctx.dit_forward(lat5, 1)
     # 5 s text-to-audio: both halves carry the empty sync feature, whose tokens repeat every 8 (sync_pos_emb) - foley_prepare finds
     # that on the data: 2 x 8 distinct rows, hoisted out of the loop

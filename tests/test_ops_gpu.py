@@ -566,6 +566,27 @@ def test_rowbcast_nearest_exact_mode(dev, dur):
                  rt.rowbcast(tab8[..., D:], 2, clips * La, La, ld=3 * D, Ls=Ls, period=8), a)
     rt.op_ln_mod(x, 1e-6, rt.rowbcast(up8[..., 0:], 1, clips * La, La, ld=3 * D), rt.rowbcast(up8[..., D:], 1, clips * La, La, ld=3 * D), b)
     assert torch.equal(a, b)
+    # a video clip under CFG (ABI 11, periodic_cfgs = 1): the unconditional half stores its 8 periodic rows, the conditional half
+    # all Ls rows right behind them - LayerNorm operands, the pending gate and both GEMM epilogue decoders
+    mixed = torch.cat((tab[0, :8], tab[1]), dim=0).contiguous()      # [8 + Ls, 3D]
+    upm = torch.stack((tab[0, :8][(idx % 8).to(dev)], tab[1][idx.to(dev)])).contiguous()
+    rbm = lambda c: rt.rowbcast(mixed[..., c * D:], 2, clips * La, La, ld=3 * D, Ls=Ls, period=8, periodic_cfgs=1)
+    rbu = lambda c: rt.rowbcast(upm[..., c * D:], 1, clips * La, La, ld=3 * D)
+    a, b = (torch.empty(M, D, device=dev, dtype=torch.bfloat16) for _ in range(2))
+    rt.op_ln_mod(x, 1e-6, rbm(0), rbm(1), a)
+    rt.op_ln_mod(x, 1e-6, rbu(0), rbu(1), b)
+    assert torch.equal(a, b)
+    slabs_m = (_rand((2, M, D), 65) * 0.1).to(dev)
+    xa, xb = x.clone(), x.clone()
+    rt.op_ln_mod_pending(xa, 1e-6, rbm(0), rbm(1), a, slabs_m, 2, None, rbm(2))
+    rt.op_ln_mod_pending(xb, 1e-6, rbu(0), rbu(1), b, slabs_m, 2, None, rbu(2))
+    assert torch.equal(a, b) and torch.equal(xa, xb)
+    Am, Wm = (_rand((M, 128), 66)).to(dev), (_rand((D, 128), 67) / 128 ** 0.5).to(dev)
+    for dt in (torch.float32, torch.bfloat16):
+        ga, gb = x.clone(), x.clone()
+        rt.op_gemm(Am.to(dt), Wm.to(dt), None, out0=ga, epilogue=rt.EPI_GATE_RES, rb=rbm(2), ksplit=1)
+        rt.op_gemm(Am.to(dt), Wm.to(dt), None, out0=gb, epilogue=rt.EPI_GATE_RES, rb=rbu(2), ksplit=1)
+        assert torch.equal(ga, gb)
     # pending split-K slabs + per-token gate (single blocks), then the same LayerNorm
     slabs = (_rand((2, M, D), 62) * 0.1).to(dev)
     xa, xb = x.clone(), x.clone()
