@@ -186,7 +186,8 @@ __device__ __forceinline__ const float* rb_row(const RowBcast& b, int r) {
   if (b.mode == 1) p += ((long)(r / b.rows_per_cfg) * b.L + (r % b.L)) * b.ld;
   else if (b.mode == 2) {
     const int s = rb_nearest_exact(r % b.L, b.scale, b.Ls), cfg = r / b.rows_per_cfg;
-    p += (cfg < b.dense_from ? (long)cfg * b.per + (s & (b.per - 1)) : (long)b.dense_base + (long)(cfg - b.dense_from) * b.Ls + s) * b.ld;
+    const int idx = cfg < b.dense_from ? cfg * b.per + (s & (b.per - 1)) : b.dense_base + (cfg - b.dense_from) * b.Ls + s;   // 32-bit: row counts are small
+    p += (long)idx * b.ld;
   }
   return p;
 }

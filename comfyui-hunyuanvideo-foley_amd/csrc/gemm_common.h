@@ -146,7 +146,8 @@ struct RbCursor {   // rb_row() for rows that advance by a fixed stride, without
     if (mode == 1) return p + ((long)cfg * L + l) * ld;
     if (mode == 2) {   // common.h RowBcast mode 2
       const int s = rb_nearest_exact(l, scale, Ls);
-      return p + (cfg < dense_from ? (long)cfg * per + (s & (per - 1)) : (long)dense_base + (long)(cfg - dense_from) * Ls + s) * ld;
+      const int idx = cfg < dense_from ? cfg * per + (s & (per - 1)) : dense_base + (cfg - dense_from) * Ls + s;
+      return p + (long)idx * ld;
     }
     return p;
   }
