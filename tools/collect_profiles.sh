@@ -24,6 +24,11 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_C
 python $R/tools/pmc_summary.py --mfma-json $OUT/${TAG}_pmc_mfma.json --workload c2/bs1/bf16/xxl $(find /tmp/pmc_sq -name "*.db") > $OUT/${TAG}_pmc_sq.md
 cp $OUT/${TAG}_pmc_mfma.json $R/profiles/${TAG}_pmc_mfma.json
 
+# kernel-trace stats of the bench command itself (1 timed pass + the event-timed loop / decode) - BEFORE the headline run, so that its line
+# carries roofline.frac_rocprof from this very collection (bench.py matches the kernel-source hash)
+rocprofv3 --kernel-trace --stats -d /tmp/kt1 -o kt -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > /tmp/kt1.log 2>&1
+python $R/tools/prof_summary.py $(find /tmp/kt1 -name "*.db" | head -1) --dominant-json $OUT/${TAG}_rocprof_dominant.json --workload c2/bs1/bf16/xxl > $OUT/${TAG}_bench_bs1_kernel_stats.md
+cp $OUT/${TAG}_rocprof_dominant.json $R/profiles/${TAG}_rocprof_dominant.json
 python $R/bench.py --steps 5 --warmup 2 > $OUT/${TAG}_bench_c2.json 2> $OUT/${TAG}_bench_c2.err
 tail -c 400 $OUT/${TAG}_bench_c2.json
 python $R/bench.py --config c3 --with-encoders --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $OUT/${TAG}_bench_c3.json 2> $OUT/${TAG}_bench_c3.err
@@ -31,10 +36,6 @@ python $R/bench.py --config c4 --steps 2 --warmup 1 --no-cpu-baseline --no-extra
 python $R/bench.py --config c5 --steps 2 --warmup 1 --no-extra > $OUT/${TAG}_bench_c5.json 2> $OUT/${TAG}_bench_c5.err
 python $R/bench.py --precision fp16 --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $OUT/${TAG}_bench_c2_fp16.json 2> $OUT/${TAG}_bench_fp16.err
 
-# kernel-trace stats of the bench command itself (1 timed pass + the event-timed loop / decode)
-rocprofv3 --kernel-trace --stats -d /tmp/kt1 -o kt -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > /tmp/kt1.log 2>&1
-python $R/tools/prof_summary.py $(find /tmp/kt1 -name "*.db" | head -1) --dominant-json $OUT/${TAG}_rocprof_dominant.json --workload c2/bs1/bf16/xxl > $OUT/${TAG}_bench_bs1_kernel_stats.md
-cp $OUT/${TAG}_rocprof_dominant.json $R/profiles/${TAG}_rocprof_dominant.json
 rocprofv3 --kernel-trace --stats -d /tmp/kt8 -o kt -- python $R/bench.py --steps 1 --warmup 0 --bs 8 --no-cpu-baseline --no-extra > /tmp/kt8.log 2>&1
 python $R/tools/prof_summary.py $(find /tmp/kt8 -name "*.db" | head -1) > $OUT/${TAG}_bench_bs8_kernel_stats.md
 rocprofv3 --kernel-trace --stats -d /tmp/kt3 -o kt -- python $R/bench.py --config c3 --with-encoders --steps 1 --warmup 0 --no-cpu-baseline --no-extra > /tmp/kt3.log 2>&1
