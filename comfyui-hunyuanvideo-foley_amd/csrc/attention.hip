@@ -588,7 +588,9 @@ __global__ __launch_bounds__(256) void attn_lds_kernel(const AttnArgs a, const i
 // the operands are read from L2 once per 128 queries instead of once per 32 (the narrow kernel above
 // re-reads them for each of its 32-query workgroups: ~10x at S = 290).  No cross-wave merge.
 // LDS rows are padded (K: 272 B, V^T: 80 B) so the 16-lane groups of ds_read_b128 hit distinct banks.
-template <typename T, typename OutT, int HD>
+// GRP (head dim 64): block-diagonal attention over packed small groups (AttnArgs::grp_q / grp_kv): a query only sees the keys of its own
+// group, a wave skips the key tiles none of its 32 queries can see, rows with no visible key in a tile contribute nothing.
+template <typename T, typename OutT, int HD, bool GRP = false>
 // Three waves per SIMD: left to itself the compiler takes 166 VGPRs + 80 AGPRs (two waves per SIMD); capped at 168 registers the
 // kernel needs no AGPRs and no scratch, and three resident workgroups per CU hide each other's LDS / MFMA / softmax latencies:
 // S = 290, 16 clips: 39.0 -> 29.3 us; S = 1740 (30 s clip): 99 -> 77 us (tools/attn_bench.py).  Four (128 registers) spills.
@@ -621,6 +623,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
+  int klo = 0, khi = 0, wlo = 0, whi = 0;   // GRP: this lane's visible keys [klo, khi), the union over the wave's queries [wlo, whi)
+  if constexpr (GRP) {
+    const int qi = min(q0 + j, a.Sq - 1);
+    klo = (qi / a.grp_q) * a.grp_kv;
+    khi = klo + a.grp_kv;
+    if (q0 < a.Sq) {
+      wlo = (q0 / a.grp_q) * a.grp_kv;
+      whi = (min(q0 + 31, a.Sq - 1) / a.grp_q + 1) * a.grp_kv;
+    }
+  }
 
   // staging: 4*HD + 4*HD pieces of 16 B per tile, NP + NP per thread
   const int k_row0 = tid / CK, k_col = tid % CK;       // K tile: 32 rows x CK chunks, 256 / CK rows per pass
@@ -655,6 +667,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (t + 1 < nt) gload(t + 1);                 // next tile's global loads fly during this tile's math
     const unsigned char* Ks = lds + (t & 1) * STG;
     const unsigned char* Vs = Ks + 32 * KP;
+    bool live = true;
+    if constexpr (GRP) live = kt < whi && kt + 32 > wlo;     // wave-uniform
+    if (live) {
     f32x16 s;
 #pragma unroll
     for (int e = 0; e < 16; ++e) s[e] = 0.f;
@@ -666,7 +681,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // raw scores: the scale (log2(e)/sqrt(128) > 0) commutes with the maximum and is folded into the exponent's FMA;
     // only a tile that sticks out of the sequence masks its elements (wave-uniform test)
     float mx = -INFINITY;
-    if (kt + 32 > a.Skv) {
+    if constexpr (GRP) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = kt + 16 * kh + e;
+        s[e] = (key >= klo && key < khi) ? s[e] : -INFINITY;
+      }
+    } else if (kt + 32 > a.Skv) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) s[e] = (kt + 16 * kh + e < a.Skv) ? s[e] : -INFINITY;
     }
@@ -674,18 +695,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[e]);
     mx = xhalf_max(mx);
     const float m_new = fmaxf(m_run, mx * scale2);
+    const float m_exp = (GRP && m_new == -INFINITY) ? 0.f : m_new;   // GRP: no visible key so far - exp2(-inf - 0) = 0, not exp2(-inf + inf)
     float ps = 0.f;
     bf16x8 pb[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], scale2, -m_new));
+      const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], scale2, -m_exp));
       ps += pv;
       pb[e >> 3][e & 7] = to_carrier<T>(pv);
     }
     ps = xhalf_sum(ps);
     // the 64 accumulator rescales only when some query's running maximum moved (rare after the first tiles)
     if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // exp2(-inf) = 0 on the first tile
+      const float alpha = (GRP && m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new);   // exp2(-inf) = 0 on the first tile
       l_run *= alpha;
 #pragma unroll
       for (int d = 0; d < ND; ++d)
@@ -699,6 +721,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
       for (int d = 0; d < ND; ++d)
         o[d] = mfma16<T>(*(const bf16x8*)(Vs + (d * 32 + j) * VP + (16 * kh + 8 * u) * 2), pb[u], o[d]);
+    }   // live
     const long long cb = acct ? (long long)__builtin_readcyclecounter() : 0;
     if (t + 1 < nt) {
       lstore((t + 1) & 1);        // stage (t+1)&1 was last read in iteration t-1: every wave passed the barrier below since
@@ -1076,6 +1099,11 @@ int launch_attention(const AttnArgs& a_in, int out_dtype, hipStream_t st) {
   if (a.Sq <= 0 || a.Skv <= 0) return foley_set_err("attention: empty sequence", __FILE__, __LINE__);
   const int hd = a.head_dim > 0 ? a.head_dim : 128;
   if (hd != 128 && hd != 64) return foley_set_err("attention: head_dim must be 128 or 64", __FILE__, __LINE__);
+  if (a.grp_q > 0 || a.grp_kv > 0) {
+    if (hd != 64 || !foley_is_half(a.in_dtype) || a.grp_q < 1 || a.grp_kv < 1 || a.kv_bdiv != 1 ||
+        (long)((a.Sq + a.grp_q - 1) / a.grp_q) * a.grp_kv > a.Skv)
+      return foley_set_err("attention: grouped (block-diagonal) form: head_dim 64, 16-bit operands, every query group's keys inside Skv", __FILE__, __LINE__);
+  }
   if (a.out_rows && hd != 64) return foley_set_err("attention: the output row table serves head_dim 64 (the conditioning encoders' kernels)", __FILE__, __LINE__);
   dim3 grid((a.Sq + 31) / 32, a.H, a.Bq), block(64);
   const dim3 grid1(grid.x * grid.y * grid.z);   // 16-bit kernels: 1-D grid, XCD-aware remap inside
@@ -1135,7 +1163,8 @@ int launch_attention(const AttnArgs& a_in, int out_dtype, hipStream_t st) {
         if (e_ != hipSuccess) return foley_set_err(hipGetErrorString(e_), __FILE__, __LINE__);       \
         FOLEY_LAUNCH((attn_bf16_long_kernel<T, O>), gw, dim3(256), 2 * 35840, st, a);                \
       } else                                                                                         \
-      if (wide && hd == 64) FOLEY_LAUNCH((attn_bf16_wide_kernel<T, O, 64>), gw, dim3(256), 0, st, a);  \
+      if (wide && hd == 64 && a.grp_q > 0) FOLEY_LAUNCH((attn_bf16_wide_kernel<T, O, 64, true>), gw, dim3(256), 0, st, a);  \
+      else if (wide && hd == 64) FOLEY_LAUNCH((attn_bf16_wide_kernel<T, O, 64>), gw, dim3(256), 0, st, a);  \
       else if (wide) FOLEY_LAUNCH((attn_bf16_wide_kernel<T, O, 128>), gw, dim3(256), 0, st, a);        \
       else FOLEY_LAUNCH((attn_bf16_kernel<T, O>), grid1, dim3(256), 0, st, a);                         \
     } while (0)

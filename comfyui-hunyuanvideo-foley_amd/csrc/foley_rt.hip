@@ -1427,9 +1427,10 @@ extern "C" int foley_op_attention_hd(const void* q, const void* k, const void* v
 }
 
 extern "C" int foley_op_attention_scatter(const void* q, const void* k, const void* v, int in_dtype, int vt_pitch, int G, int H, int Sq,
-                                          int Skv, const int32_t* out_rows, void* out, int out_dtype, void* stream) {
+                                          int Skv, int grp_q, int grp_kv, const int32_t* out_rows, void* out, int out_dtype, void* stream) {
   if (!out_rows || !out) return FAIL(FOLEY_ERR_INVALID, "null argument");
   AttnArgs a{q, k, v, G, H, Sq, Skv, 1, out, out, 0, in_dtype, vt_pitch, 64};
+  a.grp_q = grp_q; a.grp_kv = grp_kv;
   a.out_rows = out_rows;
   return launch_attention(a, out_dtype, (hipStream_t)stream);
 }

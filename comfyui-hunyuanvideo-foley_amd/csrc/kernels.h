@@ -141,6 +141,8 @@ struct AttnArgs {
   int head_dim;     // 0 / 128: the Foley DiT; 64: the conditioning encoders (fp32 kernel and the 16-bit wide kernel)
   int no_preload;   // set by the launcher (A/B switch FOLEY_ATTN_PRELOAD=0): small-grid kernel without the up-front operand requests
   long long* dbg;   // tools/attn_timeline.py: 5 wall-clock stamps per workgroup of the small-grid bf16 kernel; null in production
+  int grp_q, grp_kv;     // head_dim 64, 16-bit operands: > 0 = block-diagonal attention - query t attends keys [g*grp_kv, (g+1)*grp_kv), g = t / grp_q
+                         // (small groups packed into one sequence: the Synchformer's 8-frame time groups, 14 of them per 128-query workgroup)
   const int* out_rows;   // head_dim 64 only: row of outA that query (b, t) is written to - [Bq, Sq]; null: [Bq, Sq] order (split above).
                          // The conditioning encoders scatter every attention of a layer (CLS rows, time / space groups) into ONE
                          // token-major buffer with the table their queries were gathered by - no torch.cat / permute copies.

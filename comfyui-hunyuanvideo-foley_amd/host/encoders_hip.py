@@ -15,7 +15,7 @@ vit_helper.py:37-170}; SigLIP2 is `transformers`' SiglipVisionModel (google/sigl
 There is no fallback: these functions raise when the library is missing (runtime.load_library)."""
 from __future__ import annotations
 
-from typing import Dict, Optional
+from typing import Tuple, Dict, Optional
 
 import torch
 
@@ -114,14 +114,15 @@ class _Engine:
             t = self.tabs[key] = build().to(self.dev, torch.int32).contiguous()
         return t
 
-    def attention_regrouped(self, qkv: Tensor, heads: int, idx_q: Tensor, idx_kv: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    def attention_regrouped(self, qkv: Tensor, heads: int, idx_q: Tensor, idx_kv: Tensor, out: Optional[Tensor] = None,
+                            grp: Tuple[int, int] = (0, 0)) -> Tensor:
         """Attention straight from a fused projection qkv [rows, 3*H*64]: ONE regroup launch (foley_op_qkv_regroup: head split,
         token gather per group, transposed V for the 16-bit kernels) + the attention -> [G, Sq, H*64] token-major; with `out`
         [rows, H*64] every query is written back to the row it was gathered from (foley_op_attention_scatter) and `out` returns."""
         q, k, v = rt.op_qkv_regroup(qkv, heads, idx_q, idx_kv)
         G, H, Sq, hd = q.shape
-        if out is not None:
-            rt.op_attention_scatter(q, k, v, idx_q, out)
+        if out is not None:     # grp = (queries, keys) per packed group: block-diagonal attention inside each table row
+            rt.op_attention_scatter(q, k, v, idx_q, out, grp[0], grp[1])
             return out
         out = torch.empty(G, Sq, H * hd, device=self.dev, dtype=self.dtype)
         rt.op_attention(q, k, v, out, out, 0)
@@ -168,6 +169,17 @@ def _divided_attention(E: _Engine, h: Tensor, sd: SD, key: str, B: int, frames: 
     iq = E.index((over, "q", B, frames, space), build)
     ikv = E.index((over, "kv", B, frames, space),
                   lambda: torch.cat(((torch.arange(B) * N).repeat_interleave(G)[:, None], build()), dim=1))   # CLS key / value first
+    if over == "time" and E.half and frames <= 64:
+        # 8 queries x 9 keys per location: one 128-query workgroup per group ran 6 % full (133 us per layer).  The tables are free
+        # to PACK groups: p locations per table row (p | B*space, p*frames <= 128) and a block-diagonal mask in the kernel
+        # (foley_op_attention_scatter grp_q / grp_kv) - same arithmetic per query, 14x fewer workgroups
+        n = B * space
+        p = max(d for d in range(1, 128 // frames + 1) if n % d == 0)
+        if p > 1:
+            iq_p = E.index((over, "q-pack", B, frames, space, p), lambda: build().reshape(n // p, p * frames))
+            ikv_p = E.index((over, "kv-pack", B, frames, space, p),
+                            lambda: torch.cat(((torch.arange(B) * N).repeat_interleave(G)[:, None], build()), dim=1).reshape(n // p, p * (frames + 1)))
+            return E.attention_regrouped(qkv, HEADS, iq_p, ikv_p, out=out, grp=(frames, frames + 1))
     return E.attention_regrouped(qkv, HEADS, iq, ikv, out=out)      # the inverse rearrange + torch.cat((cls_out, x), 1) of the reference = the scatter
 
 

@@ -130,7 +130,7 @@ _SIGNATURES = {
     "foley_op_ln_mod": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.POINTER(RowBcastC),
                                   C.POINTER(RowBcastC), C.c_void_p, C.c_int, C.c_void_p]),
     "foley_op_attention_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                             C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+                                             C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "foley_op_qkv_regroup": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "foley_op_resize_aa_u8": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -508,9 +508,11 @@ def op_attention(q, k, v, outA, outB, split: int, kv_bdiv: int = 1):
                                           _ptr(outA), _ptr(outB), split, dt_of(outB), hd, _stream()), "foley_op_attention_hd")
 
 
-def op_attention_scatter(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_rows: torch.Tensor, out: torch.Tensor) -> None:
+def op_attention_scatter(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_rows: torch.Tensor, out: torch.Tensor,
+                         grp_q: int = 0, grp_kv: int = 0) -> None:
     """Attention at head_dim 64 (operands as op_qkv_regroup returns them) whose query (g, t) is written to row out_rows[g, t] of
-    out [rows, H*64] (foley_op_attention_scatter)."""
+    out [rows, H*64] (foley_op_attention_scatter).  grp_q / grp_kv > 0 (16-bit operands): block-diagonal - each sequence is a pack
+    of groups of grp_q queries that attend their own grp_kv keys only."""
     lib = load_library()
     G, H, Sq, hd = q.shape
     half = q.dtype in (torch.bfloat16, torch.float16)
@@ -519,7 +521,7 @@ def op_attention_scatter(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_
             not out.is_contiguous() or not out_rows.is_contiguous():
         raise FoleyRuntimeError("op_attention_scatter: head_dim 64, int32 out_rows [G, Sq], contiguous out [rows, H*64]")
     _check(lib, lib.foley_op_attention_scatter(_ptr(q), _ptr(k), _ptr(v), dt_of(q), v.shape[3] if half else 0, G, H, Sq, Skv,
-                                               _ptr(out_rows), _ptr(out), dt_of(out), _stream()), "foley_op_attention_scatter")
+                                               grp_q, grp_kv, _ptr(out_rows), _ptr(out), dt_of(out), _stream()), "foley_op_attention_scatter")
 
 
 def op_qkv_regroup(qkv: torch.Tensor, heads: int, idx_q: torch.Tensor, idx_kv: torch.Tensor):

@@ -266,9 +266,12 @@ int foley_op_attention_hd(const void* q, const void* k, const void* v, int in_dt
 /* foley_op_attention_hd at head_dim 64 with scattered output rows: query t of group g lands in row out_rows[g*Sq + t] of out
  * [rows, H*64] - normally the table the queries were gathered by (foley_op_qkv_regroup's idx_q), so that the CLS attention and the
  * time / space group attention of a DividedAttention layer (vit_helper.py:37-105: `torch.cat((cls_out, x), dim=1)` after the inverse
- * rearrange) write ONE token-major buffer, ready for the output projection. */
+ * rearrange) write ONE token-major buffer, ready for the output projection.
+ * grp_q / grp_kv > 0 (16-bit operands): block-diagonal attention - the sequence is a pack of small groups, query t attends keys
+ * [g*grp_kv, (g+1)*grp_kv) with g = t / grp_q only (DividedAttention over time: 8 frame queries x (CLS + 8 frame keys) per location;
+ * 14 locations share one 128-query workgroup instead of taking one each); 0 / 0: every query sees all Skv keys. */
 int foley_op_attention_scatter(const void* q, const void* k, const void* v, int in_dtype, int vt_pitch, int G, int H, int Sq,
-                               int Skv, const int32_t* out_rows, void* out, int out_dtype, void* stream);
+                               int Skv, int grp_q, int grp_kv, const int32_t* out_rows, void* out, int out_dtype, void* stream);
 /* Token regrouping between a fused q/k/v projection and foley_op_attention_hd at head_dim 64 - the conditioning encoders
  * (reference models/synchformer/vit_helper.py:37-105 DividedAttention: patch tokens attend over the frames of their location or
  * the locations of their frame with the CLS key / value prepended; transformers' SiglipAttention / ClapTextSelfAttention head split):

@@ -826,3 +826,29 @@ def test_attention_scatter(dev, dtype, G, H, Sq, Skv):
     assert torch.equal(out, want)
     with pytest.raises(rt.FoleyRuntimeError):
         rt.op_attention_scatter(q, k, v, iq.long(), out)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("G,H,p,gq,gkv", [(6, 12, 14, 8, 9), (3, 4, 16, 8, 9), (2, 12, 5, 8, 9), (4, 2, 3, 33, 40), (1, 12, 1, 8, 9)])
+def test_attention_scatter_grouped(dev, dtype, G, H, p, gq, gkv):
+    """The block-diagonal form of foley_op_attention_scatter (grp_q / grp_kv): p small groups packed into one sequence must give
+    what the same groups give one by one (the plain kernel, one group per sequence) - the Synchformer's time attention (8 frame
+    queries x (CLS + 8) keys, 14 locations per workgroup), packs that end inside a 32-key tile, groups that straddle tiles, a wave
+    whose queries see no key of a tile, idle waves, p = 1."""
+    from foley_amd.host import runtime as rt
+    g = torch.Generator().manual_seed(G * 100 + p)
+    n = G * p                      # small groups
+    rows = n * gkv + 5
+    qkv = torch.randn(rows, 3 * H * 64, generator=g).to(dtype).to(dev)
+    iq = torch.randperm(rows, generator=g)[: n * gq].view(n, gq).to(torch.int32).to(dev)
+    ikv = torch.randint(0, rows, (n, gkv), generator=g, dtype=torch.int32).to(dev)
+    q, k, v = rt.op_qkv_regroup(qkv, H, iq, ikv)                    # one group per sequence
+    want = torch.zeros(rows, H * 64, device=dev, dtype=dtype)
+    rt.op_attention_scatter(q, k, v, iq, want)
+    qp, kp, vp = rt.op_qkv_regroup(qkv, H, iq.view(G, p * gq), ikv.view(G, p * gkv))   # p groups per sequence
+    out = torch.zeros(rows, H * 64, device=dev, dtype=dtype)
+    rt.op_attention_scatter(qp, kp, vp, iq.view(G, p * gq), out, gq, gkv)
+    err = float((out.float() - want.float()).abs().max())
+    assert bool(torch.isfinite(out.float()).all()) and err <= (2e-2 if dtype == torch.bfloat16 else 3e-3), err
+    with pytest.raises(rt.FoleyRuntimeError):       # the last group's keys must lie inside Skv
+        rt.op_attention_scatter(qp, kp, vp, iq.view(G, p * gq), out, gq, gkv + 1)
