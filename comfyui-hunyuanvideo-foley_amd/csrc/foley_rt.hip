@@ -130,7 +130,6 @@ struct foley_ctx {
   int sync_lead = 0;                // number of leading 8-periodic halves: ncfg = all of them (text-to-audio); 1 of 2 = a video clip under
                                     // CFG (unconditional half first, utils.py:150-176); 0 = none
   int* flag = nullptr;              // device scratch word of the periodicity check
-  int* xk_ctr = nullptr;            // [XK_CTR_CAP] tickets of GemmArgs::xk (audio problem: first half, visual problem: second half)
   int* ident_idx = nullptr;         // 0..max(Lv,La)-1
   // forward workspace
   void* xin = nullptr;              // T [M, C]
@@ -277,7 +276,6 @@ static const void* zero_page() {
 }
 
 // --------------------------------------------------------------------------- launch helpers
-constexpr int XK_CTR_CAP = 4096;
 static RowBcast rb_none() { return RowBcast{nullptr, 0, 0, 1, 1, nullptr, 0}; }
 static RowBcast rb_vec(const float* base, long step_stride, const int* step_ptr);
 
@@ -483,8 +481,6 @@ extern "C" int foley_prepare(foley_ctx* c, const foley_plan* pl, void* stream_v)
     ALLOC(c->v_cond0, (size_t)ncfg * Lv * D * 4);
     ALLOC(c->sync_tok, (size_t)ncfg * Ls * D * 4);
     ALLOC(c->flag, 256);
-    ALLOC(c->xk_ctr, XK_CTR_CAP * 4);          // tickets of the in-launch K split (cross-attention q projection): zero between launches
-    HIPTRY(hipMemsetAsync(c->xk_ctr, 0, XK_CTR_CAP * 4, st));
     ALLOC(c->xin, (size_t)M * C * es);
     ALLOC(c->audio, (size_t)M * D * 4);
     ALLOC(c->vcond, (size_t)Mv * D * 4);
@@ -916,10 +912,6 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
       // 16-bit modes: the projection may run the attention against the <= 96 cached text keys in its epilogue (small grids:
       // gemm_impl.h decides and reports through attn_fused); the q tensor and the attention launch are then gone
       int fused = 0;
-      // the split-K slabs are idle between the LayerNorm above (it consumed them) and `cross proj` below: lent to the projection as the
-      // exchange area of its in-launch K split (gemm_impl.h decides)
-      g0.xk_scratch = c->part_a; g0.xk_scratch_bytes = (size_t)PART_CAP * M * D * 4; g0.xk_ctr = c->xk_ctr; g0.xk_ctr_cap = XK_CTR_CAP / 2;
-      g1.xk_scratch = c->part_v; g1.xk_scratch_bytes = (size_t)PART_CAP * Mv * D * 4; g1.xk_ctr = c->xk_ctr + XK_CTR_CAP / 2; g1.xk_ctr_cap = XK_CTR_CAP / 2;
       if (bf && Lt <= 96 && Ltp >= 96) {
         for (int s = 0; s < 2; ++s) {
           QkvSplitArgs& q = s ? g1.qs : g0.qs;

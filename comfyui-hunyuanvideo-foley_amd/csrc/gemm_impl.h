@@ -850,25 +850,7 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     const bool fuse = fuse_on && sizeof(T) == 2 && tile == 27 && fits(g) && (!g1 || fits(g1s));
     if (g.qs.attn_fused) *g.qs.attn_fused = fuse ? 1 : 0;
     if (g1 && g1s.qs.attn_fused) *g1s.qs.attn_fused = fuse ? 1 : 0;
-    if (fuse) {
-      epi = EPI_QKV_ATTN;
-      // In-launch K split (gemm_ws_impl.h xk_fixup): these grids are small by selection (<= ~130 tiles of 64x128), so every workgroup streams
-      // its whole weight panel while half of the CUs idle.  Two K ranges per tile when both fit one round of 256 CUs and the caller lent the
-      // scratch + ticket buffers (the sampler does; op-level callers without them keep one range).  FOLEY_CROSS_XK=0: never.
-      static const bool xk_on = []() { const char* e = getenv("FOLEY_CROSS_XK"); return !(e && e[0] == '0'); }();
-      auto tiles_of = [](const GemmArgs& q) { return ((q.M + 63) / 64) * ((q.N + 127) / 128); };
-      auto lent = [&](const GemmArgs& q) {
-        return q.xk_scratch && q.xk_ctr && tiles_of(q) <= q.xk_ctr_cap && (size_t)tiles_of(q) * 2 * 64 * 128 * 4 <= q.xk_scratch_bytes &&
-               !((uintptr_t)q.xk_scratch & 15);
-      };
-      const int t_all = tiles_of(g) + (g1 ? tiles_of(g1s) : 0);
-      const bool split = xk_on && lent(g) && (!g1 || lent(g1s)) && 2 * t_all <= 256 && g.K / 64 >= 8 && (!g1 || g1s.K == g.K);
-      g.xk = split ? 2 : 1;
-      if (g1) g1s.xk = g.xk;
-    } else {
-      g.xk = 1;
-      if (g1) g1s.xk = 1;
-    }
+    if (fuse) epi = EPI_QKV_ATTN;
   }
   if (tile == 15 || tile == 19 || tile == 21 || tile == 22 || tile == 23 || tile == 24 || tile == 25 || tile == 26 || tile == 27 || tile == 28 || tile == 29) {
     if constexpr (__is_same(T, bf16_t)) return launch_gemm_ws_bf16(g, g1, epi, tile, st);

@@ -124,63 +124,6 @@ __device__ __forceinline__ void cvt_fp8x16(const u32x4 w, bf16x8& lo, bf16x8& hi
 // a kernel-argument load at a CONSTANT offset (hoisted and batched into a few wide s_loads at entry).  With
 // a run-time index the compiler re-loaded fields one dword at a time at their points of use: 200 scalar
 // loads, 169 of them serialised through the epilogue (tools/kernel_resources.py, gemm_timeline.py --epilogue).
-// In-launch K split of a tile whose epilogue needs complete sums (GemmArgs::xk, the cross-attention q projection at bs=1: 120 workgroups
-// on 256 CUs, each streaming its whole 393 KB weight panel - with two K ranges per tile 240 workgroups stream half of it).  Every
-// workgroup publishes its accumulators (coalesced: lane-major float4 rows), fences, takes a ticket; all but the last arriver leave; the
-// last one resets the ticket for the next launch, acquires, adds the others' accumulators and goes on into the epilogue.  No waiting
-// anywhere - a workgroup never depends on one that may not be resident.  PER = accumulator floats per lane; CW = consumer waves;
-// `consumer` waves hold accumulators, helper (loader) waves only take part in the barriers.  Returns false when this workgroup is done.
-template <int PER, int CW>
-__device__ __forceinline__ bool xk_fixup(const GemmArgs& g, float* acc, int tile, int ks, bool consumer, int ctid, int* flag_lds) {
-  // Memory protocol (tools/ubench/splitk_seam.hip variant B - the cheapest correct one measured there): the accumulators leave with `sc1`
-  // (write-through) stores and are drained per wave, so NO release fence is needed (an agent-scope release is `buffer_wbl2`: a write-back of
-  // the whole L2 - with every wave of 240 workgroups issuing one, the first version of this split ran 62 us per launch SLOWER than no
-  // split); the ticket is a relaxed agent-scope atomic; the last arriver's thread 0 issues ONE acquire, the others' accumulators come in
-  // with `sc1` loads.
-  const int xk = g.xk;
-  constexpr int LANES = CW * 64;
-  f32x4* mine = (f32x4*)(g.xk_scratch + ((size_t)tile * xk + ks) * (size_t)(PER * LANES));
-  if (consumer) {
-#pragma unroll
-    for (int c = 0; c < PER / 4; ++c) {
-      const f32x4 v = *(const f32x4*)(acc + 4 * c);
-      f32x4* d = mine + c * LANES + ctid;
-      asm volatile("global_store_dwordx4 %0, %1, off sc1\n s_nop 1" ::"v"(d), "v"(v) : "memory");
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its stores are performed
-  __syncthreads();
-  if (threadIdx.x == 0) *flag_lds = (int)__hip_atomic_fetch_add((unsigned*)g.xk_ctr + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  const int old = *(volatile int*)flag_lds;
-  if (old != xk - 1) return false;
-  if (threadIdx.x == 0) {
-    __hip_atomic_store((unsigned*)g.xk_ctr + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch (stream order) starts from zero
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  __syncthreads();
-  if (consumer) {
-    for (int o = 0; o < xk; ++o) {
-      if (o == ks) continue;
-      const f32x4* src = (const f32x4*)(g.xk_scratch + ((size_t)tile * xk + o) * (size_t)(PER * LANES));
-      f32x4 part[PER / 4];
-#pragma unroll
-      for (int c = 0; c < PER / 4; ++c) {
-        const f32x4* sp = src + c * LANES + ctid;
-        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(part[c]) : "v"(sp) : "memory");
-      }
-#pragma unroll
-      for (int c = 0; c < PER / 4; ++c) asm volatile("s_waitcnt vmcnt(0)" : "+v"(part[c])::"memory");   // the compiler cannot see the loads' latency: tie every
-                                                                                                      // destination to the wait (the first one drains them all)
-#pragma unroll
-      for (int c = 0; c < PER / 4; ++c)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[4 * c + e] += part[c][e];
-    }
-  }
-  return true;
-}
-
 template <typename T, int BM, int BN, int WM, int WN, int NS, int LW, int EPI, int WF, int SEL>
 __device__ __forceinline__ void gemm_ws_body(const GemmPair& pr) {
   constexpr int sel = SEL;
@@ -205,16 +148,12 @@ __device__ __forceinline__ void gemm_ws_body(const GemmPair& pr) {
   const int tiles_n = (g.N + BN - 1) / BN;
   int bid = (int)blockIdx.x - (sel ? pr.tiles0 : 0);
   {  // bijective XCD remap: consecutive tile ids (same weight panel) share an XCD / L2
-    const int nwg = tiles_m * tiles_n * (EPI == EPI_GATE_RES ? g.ksplit : (EPI == EPI_QKV_ATTN ? g.xk : 1));
+    const int nwg = tiles_m * tiles_n * (EPI == EPI_GATE_RES ? g.ksplit : 1);
     const int xcd = bid & 7, slot = bid >> 3;
     const int q = nwg >> 3, r = nwg & 7;
     bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
   }
   int ks = 0;
-  if constexpr (EPI == EPI_QKV_ATTN) {   // in-launch split: the ranges of a tile are neighbours (one XCD: the exchange stays in its L2)
-    ks = bid % g.xk;
-    bid /= g.xk;
-  }
   if constexpr (EPI == EPI_GATE_RES) {
     // K-range-major order (round 5): the XCD remap above hands consecutive ids to one XCD, so all tiles of a K range sit on one or
     // two XCDs and only those L2s fetch the range's activation columns (range-fastest order: every XCD fetches ALL of A - 8 x 4 MB
@@ -241,14 +180,6 @@ __device__ __forceinline__ void gemm_ws_body(const GemmPair& pr) {
     kt_begin = (int)((long)tot * ks / g.ksplit);
     nk = (int)((long)tot * (ks + 1) / g.ksplit) - kt_begin;
   }
-  if constexpr (EPI == EPI_QKV_ATTN) {
-    const int tot = nk;
-    kt_begin = (int)((long)tot * ks / g.xk);
-    nk = (int)((long)tot * (ks + 1) / g.xk) - kt_begin;
-  }
-  // first byte past the ring / the epilogue images: the ticket word of the in-launch K split (launch_ws_one adds 64 bytes)
-  constexpr int XK_EPI = BM * BN * 4 + BM * 256 + 96 * 256 + 2 * 128 * 256;
-  constexpr int XK_FLAG = NS * STAGE > XK_EPI ? NS * STAGE : XK_EPI;
 
   if (wave >= NW) {
     // ------------------------------------------------------------------ loader wave
@@ -352,10 +283,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmPair& pr) {
     if constexpr (NW == 4) {
       f32x16 none[FM][FN];
       if constexpr (EPI == EPI_QKV_SPLIT) gemm_epilogue_qkv<T, BM, BN, WM, WN, LW>(g, none, lds, m0, n0);
-      else if constexpr (EPI == EPI_QKV_ATTN) {
-        if (g.xk > 1 && !xk_fixup<FM * FN * 16, NW>(g, nullptr, tm * tiles_n + tn, ks, false, 0, (int*)(lds + XK_FLAG))) return;
-        gemm_epilogue_qkv<T, BM, BN, WM, WN, LW, true, true>(g, none, lds, m0, n0);
-      }
+      else if constexpr (EPI == EPI_QKV_ATTN) gemm_epilogue_qkv<T, BM, BN, WM, WN, LW, true, true>(g, none, lds, m0, n0);
       else gemm_epilogue_lds<T, EPI, BM, BN, WM, WN, LW>(g, none, lds, m0, n0, ks);   // vector epilogue only (gemm_impl.h launcher)
     }
     return;
@@ -572,7 +500,6 @@ __device__ __forceinline__ void gemm_ws_body(const GemmPair& pr) {
     gemm_epilogue_qkv<T, BM, BN, WM, WN, XW, NW == 4 && BM <= 128>(g, acc, lds, m0, n0);
   } else if constexpr (EPI == EPI_QKV_ATTN) {
     static_assert(NW == 4 && BM <= 128, "fused cross attention: four-consumer small tiles");
-    if (g.xk > 1 && !xk_fixup<FM * FN * 16, NW>(g, (float*)&acc[0][0], tm * tiles_n + tn, ks, true, tid, (int*)(lds + XK_FLAG))) return;
     gemm_epilogue_qkv<T, BM, BN, WM, WN, XW, true, true>(g, acc, lds, m0, n0);
   } else if constexpr (NW == 4) {
     gemm_epilogue_lds<T, EPI, BM, BN, WM, WN, XW>(g, acc, lds, m0, n0, ks);   // the launcher sends scalar-epilogue problems to the eight-consumer twins
@@ -1196,19 +1123,17 @@ int launch_ws_conv3_fmt(const GemmArgs& g, int epi, hipStream_t st) {
 template <typename T, int BM, int BN, int WM, int WN, int NS, int LW, int EPI, int WF>
 int launch_ws_one(const GemmArgs& g, const GemmArgs* g1, hipStream_t st) {
   auto ntiles = [](const GemmArgs& q) {
-    return ((q.M + BM - 1) / BM) * ((q.N + BN - 1) / BN) * (EPI == EPI_GATE_RES ? q.ksplit : (EPI == EPI_QKV_ATTN ? (q.xk > 1 ? q.xk : 1) : 1));
+    return ((q.M + BM - 1) / BM) * ((q.N + BN - 1) / BN) * (EPI == EPI_GATE_RES ? q.ksplit : 1);
   };
   GemmPair pr;
   pr.g[0] = g;
   pr.g[1] = g1 ? *g1 : g;
-  if (pr.g[0].xk < 1) pr.g[0].xk = 1;
-  if (pr.g[1].xk < 1) pr.g[1].xk = 1;
   pr.tiles0 = ntiles(g);
   const int tiles = pr.tiles0 + (g1 ? ntiles(*g1) : 0);
   constexpr size_t lds_ring = (size_t)NS * (BM * 128 + BN * (WF ? 64 : 128));
   constexpr size_t lds_epi = (size_t)BM * BN * 4 +           // the epilogues transpose the accumulator tile through LDS
                              (EPI == EPI_QKV_ATTN ? (size_t)BM * 256 + 96 * 256 + 2 * 128 * 256 : 0);   // + Q / K / V^T images (two V^T: straddling tiles)
-  constexpr size_t lds = (lds_ring > lds_epi ? lds_ring : lds_epi) + (EPI == EPI_QKV_ATTN ? 64 : 0);   // + the ticket word of the in-launch K split
+  constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto k = gemm_ws_kernel<T, BM, BN, WM, WN, NS, LW, EPI, WF>;
   static std::atomic<unsigned long long> raised{0};

@@ -92,11 +92,6 @@ struct GemmArgs {
                       // groups (the workgroups that run together then cover a near-square block of tiles); 0 = [panel][M tile]
   int ks_major;       // set by the launcher: workgroup order of a split - 1: K range slowest (all tiles of a range are neighbours, i.e. on
                       // one or two XCDs: only those L2s fetch that range's activation columns), 0: K range fastest
-  int xk;             // EPI_QKV_ATTN only, set by the launcher: > 1 = the K extent is split over xk workgroups per tile INSIDE the launch -
-  float* xk_scratch;  // every workgroup publishes its fp32 accumulators (xk_scratch: [tile][xk][BM x BN]), takes a ticket (xk_ctr[tile]); the
-  size_t xk_scratch_bytes; int xk_ctr_cap;   // capacity of the two caller-owned buffers (bytes / counters)
-  int* xk_ctr;        // last one to arrive adds the others' and runs the epilogue (the head split needs complete sums, so the deferred slabs
-                      // of EPI_GATE_RES do not apply).  Caller-owned, zero-initialised counters (one per tile); null = no split.
   QkvSplitArgs qs;    // EPI_QKV_SPLIT: destination / norm / rotation description (qs.qkv, qs.M unused)
   int vec_out;        // set by the launcher: the problem qualifies for the LDS-transposed vector epilogue
   int wfmt;           // storage of W: 0 = the operand dtype, 1 = fp8 e4m3fn, 2 = fp8 e5m2 (bf16 activations; wave-specialised
