@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64) void attn_kernel(const AttnArgs a) {
   if (tok >= a.Sq) return;
   const float inv = 1.0f / l_run;
   OutT* dst;
-  if (a.out_rows) dst = (OutT*)a.outA + (long)a.out_rows[(long)b * a.Sq + tok] * (a.H * HD);
+  if (HD == 64 && a.out_rows) dst = (OutT*)a.outA + (long)a.out_rows[(long)b * a.Sq + tok] * (a.H * HD);   // HD is a template constant: the DiT's instances carry no trace of it
   else if (tok < a.split) dst = (OutT*)a.outA + ((long)b * a.split + tok) * (a.H * HD);
   else dst = (OutT*)a.outB + ((long)b * (a.Sq - a.split) + (tok - a.split)) * (a.H * HD);
   dst += h * HD;
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   if (tok >= a.Sq) return;
   const float inv = 1.0f / l_run;
   OutT* dst;
-  if (a.out_rows) dst = (OutT*)a.outA + (long)a.out_rows[(long)b * a.Sq + tok] * (a.H * HD);
+  if (HD == 64 && a.out_rows) dst = (OutT*)a.outA + (long)a.out_rows[(long)b * a.Sq + tok] * (a.H * HD);   // HD is a template constant: the DiT's instances carry no trace of it
   else if (tok < a.split) dst = (OutT*)a.outA + ((long)b * a.split + tok) * (a.H * HD);
   else dst = (OutT*)a.outB + ((long)b * (a.Sq - a.split) + (tok - a.split)) * (a.H * HD);
   dst += h * HD;
