@@ -93,6 +93,8 @@ def aa_tables(n_in: int, n_out: int):
     rounded half away from zero.  Returns (xmin int32 [n_out], xsize int32 [n_out], weights int16 [n_out, kmax], precision)
     as numpy arrays; cached per (n_in, n_out)."""
     import numpy as np
+    if n_in < 1 or n_out < 1:
+        raise ValueError(f"aa_tables: axis lengths must be positive (got {n_in} -> {n_out})")
     key = (int(n_in), int(n_out))
     hit = _AA_TABLES.get(key)
     if hit is not None:

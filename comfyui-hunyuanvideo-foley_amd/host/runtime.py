@@ -518,8 +518,11 @@ def op_attention_scatter(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_
     half = q.dtype in (torch.bfloat16, torch.float16)
     Skv = k.shape[2]
     if hd != 64 or out_rows.dtype != torch.int32 or out_rows.numel() != G * Sq or out.dim() != 2 or out.shape[1] != H * 64 or \
-            not out.is_contiguous() or not out_rows.is_contiguous():
-        raise FoleyRuntimeError("op_attention_scatter: head_dim 64, int32 out_rows [G, Sq], contiguous out [rows, H*64]")
+            not out.is_contiguous() or not out_rows.is_contiguous() or k.shape[:2] != q.shape[:2] or not (q.is_contiguous() and k.is_contiguous()
+                                                                                                       and v.is_contiguous()):
+        raise FoleyRuntimeError("op_attention_scatter: head_dim 64, contiguous q / k / v of one (G, H), int32 out_rows [G, Sq], contiguous out [rows, H*64]")
+    if (grp_q > 0) != (grp_kv > 0) or (grp_q > 0 and not half):
+        raise FoleyRuntimeError("op_attention_scatter: grp_q and grp_kv come together and need 16-bit operands")
     _check(lib, lib.foley_op_attention_scatter(_ptr(q), _ptr(k), _ptr(v), dt_of(q), v.shape[3] if half else 0, G, H, Sq, Skv,
                                                grp_q, grp_kv, _ptr(out_rows), _ptr(out), dt_of(out), _stream()), "foley_op_attention_scatter")
 
