@@ -87,6 +87,24 @@ def kernel_src_sha() -> str:
     return h.hexdigest()[:16]
 
 
+def kernel_key(name: str) -> str:
+    """A kernel symbol reduced to what identifies the instance: `void f<a, b>(Args)` -> `f<a,b>` (return type, argument list and
+    blanks dropped) - the demanglers of rocprofv3 and of libfoley_hip.so (abi::__cxa_demangle) differ only in those."""
+    n = name.strip().replace("(anonymous namespace)::", "").replace("unsigned short", "bf16")   # tools/prof_summary.py's spelling
+    if n.startswith("void "):
+        n = n[5:]
+    depth, end = 0, len(n)
+    for i, ch in enumerate(n):          # cut at the '(' that opens the argument list (outside any template bracket)
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            end = i
+            break
+    return n[:end].replace(" ", "")
+
+
 def physical_cores() -> int:
     """Physical cores this process may run on (distinct (package, core) pairs of /proc/cpuinfo within the affinity mask)."""
     try:
@@ -508,7 +526,7 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
         for e in prof:
             tf = e["flop_per_launch"] / (e["avg_us"] * 1e-6) / 1e12 if e["avg_us"] > 0 else 0.0
             gbs = e["bytes_per_launch"] / (e["avg_us"] * 1e-6) / 1e9 if e["avg_us"] > 0 else 0.0
-            kernels.append({"name": e["label"], "calls_per_iteration": e["calls_per_forward"],
+            kernels.append({"name": e["label"], "kernel": e["kernel"], "calls_per_iteration": e["calls_per_forward"],
                             "avg_us": round(e["avg_us"], 2), "us_per_iteration": round(e["avg_us"] * e["calls_per_forward"], 1),
                             "gflop_per_launch": round(e["flop_per_launch"] / 1e9, 3),
                             "mbytes_per_launch": round(e["bytes_per_launch"] / 1e6, 3),
@@ -601,13 +619,17 @@ def run_rank(a, world: int, rank: int, local: int, launched: bool) -> int:
             except Exception:
                 continue
             if rj.get("kernel_src_sha") == kernel_src_sha() and rj.get("workload") == f"{a.config}/bs{bs_main}/{a.precision}/{a.model}" and dom:
-                # the traced kernel with the dominant op's launch count whose average is closest to the live one
-                cand = [k for k in rj.get("kernels", []) if k["calls"] == dom["calls_per_iteration"] * rj.get("loop_iterations", 100)]
-                if cand:
-                    rk = min(cand, key=lambda k: abs(k["avg_us"] - dom["avg_us"]))
+                # the traced row is matched BY NAME: the symbol foley_profile_forward reports for the dominant op (the kernel its
+                # launch ran, demangled) against the rows of the trace, both normalised; no row or more than one -> null.  When other
+                # ops run the same kernel instance the traced average covers them too: `ops_sharing_kernel` lists them.
+                cand = [k for k in rj.get("kernels", []) if kernel_key(k["name"]) == kernel_key(dom.get("kernel", "")) and dom.get("kernel")]
+                if len(cand) == 1:
+                    rk = cand[0]
+                    sharing = [k["name"] for k in kernels if k is not dom and kernel_key(k.get("kernel", "")) == kernel_key(dom["kernel"])]
                     tfr = dom["gflop_per_launch"] * 1e9 / (rk["avg_us"] * 1e-6) / 1e12
                     rocprof = {"kernel": rk["name"], "avg_us": rk["avg_us"], "calls": rk["calls"], "achieved": round(tfr, 1),
-                               "frac": round(tfr / peak, 4), "file": os.path.relpath(rp_path, ROOT)}
+                               "frac": round(tfr / peak, 4), "file": os.path.relpath(rp_path, ROOT), "matched_by": "kernel symbol",
+                               "ops_sharing_kernel": sharing}
                 break
         roof = {"bound": "mfma", "peak": peak, "unit": "TFLOP/s",
                 "achieved": dom["tflops"] if dom else loop_tf, "frac": dom["frac"] if dom else loop_tf / peak,

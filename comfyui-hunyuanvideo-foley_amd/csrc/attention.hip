@@ -145,7 +145,11 @@ __global__ __launch_bounds__(64) void attn_kernel(const AttnArgs a) {
   if (tok >= a.Sq) return;
   const float inv = 1.0f / l_run;
   OutT* dst;
-  if (HD == 64 && a.out_rows) dst = (OutT*)a.outA + (long)a.out_rows[(long)b * a.Sq + tok] * (a.H * HD);   // HD is a template constant: the DiT's instances carry no trace of it
+  if (HD == 64 && a.out_rows) {   // HD is a template constant: the DiT's instances carry no trace of it
+    const int orow = a.out_rows[(long)b * a.Sq + tok];
+    if ((unsigned)orow >= (unsigned)a.out_nrows) return;   // a row outside out [out_nrows, H*64] is dropped, never written (caller-supplied table)
+    dst = (OutT*)a.outA + (long)orow * (a.H * HD);
+  }
   else if (tok < a.split) dst = (OutT*)a.outA + ((long)b * a.split + tok) * (a.H * HD);
   else dst = (OutT*)a.outB + ((long)b * (a.Sq - a.split) + (tok - a.split)) * (a.H * HD);
   dst += h * HD;
@@ -744,7 +748,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   if (tok >= a.Sq) return;
   const float inv = 1.0f / l_run;
   OutT* dst;
-  if (HD == 64 && a.out_rows) dst = (OutT*)a.outA + (long)a.out_rows[(long)b * a.Sq + tok] * (a.H * HD);   // HD is a template constant: the DiT's instances carry no trace of it
+  if (HD == 64 && a.out_rows) {   // HD is a template constant: the DiT's instances carry no trace of it
+    const int orow = a.out_rows[(long)b * a.Sq + tok];
+    if ((unsigned)orow >= (unsigned)a.out_nrows) return;   // a row outside out [out_nrows, H*64] is dropped, never written (caller-supplied table)
+    dst = (OutT*)a.outA + (long)orow * (a.H * HD);
+  }
   else if (tok < a.split) dst = (OutT*)a.outA + ((long)b * a.split + tok) * (a.H * HD);
   else dst = (OutT*)a.outB + ((long)b * (a.Sq - a.split) + (tok - a.split)) * (a.H * HD);
   dst += h * HD;

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cxxabi.h>
 #include <atomic>
 #include <mutex>
 #include <string>
@@ -93,6 +94,7 @@ struct ProfRec {
   const char* label;
   double flop, bytes;
   hipEvent_t e0, e1;
+  const void* fn;   // the kernel the op's launch ran (null: the op launched nothing)
 };
 struct Profiler {
   bool on = false;
@@ -735,9 +737,9 @@ static RowBcast rb_up(const float* base, long ld, int rows_per_cfg, int L, int L
 // start / stop timestamps (common.h FOLEY_LAUNCH), tagged with the op's algorithmic FLOPs / bytes.
 static int prof_begin(foley_ctx* c, hipStream_t st, const char* label, double flop, double bytes) {
   if (!c->prof.on) return 0;
-  ProfRec r{label, flop, bytes, c->prof.get(), c->prof.get()};
+  ProfRec r{label, flop, bytes, c->prof.get(), c->prof.get(), nullptr};
   c->prof.recs.push_back(r);
-  g_foley_prof = FoleyProfHook{r.e0, r.e1};   // consumed by the op's (first) kernel launch
+  g_foley_prof = FoleyProfHook{r.e0, r.e1, nullptr};   // consumed by the op's (first) kernel launch
   return 0;
 }
 static int prof_end(foley_ctx* c, hipStream_t st) {
@@ -746,6 +748,8 @@ static int prof_end(foley_ctx* c, hipStream_t st) {
     g_foley_prof.e0 = nullptr;
     HIPTRY(hipEventRecord(c->prof.recs.back().e0, st));
     HIPTRY(hipEventRecord(c->prof.recs.back().e1, st));
+  } else {
+    c->prof.recs.back().fn = g_foley_prof.fn;
   }
   return 0;
 }
@@ -1047,7 +1051,7 @@ extern "C" int foley_profile_forward(foley_ctx* c, const float* latents, int ite
   int rc = 0;
   for (int r = 0; r < repeats && rc == 0; ++r) rc = run_forward(c, st);
   c->prof.on = false;
-  g_foley_prof = FoleyProfHook{nullptr, nullptr};   // an op that failed between prof_begin and its launch leaves the hook armed
+  g_foley_prof = FoleyProfHook{nullptr, nullptr, nullptr};   // an op that failed between prof_begin and its launch leaves the hook armed
   if (rc) return rc;
   // empty brackets for the calibration
   constexpr int NCAL = 32;
@@ -1076,6 +1080,15 @@ extern "C" int foley_profile_forward(foley_ctx* c, const float* latents, int ite
       if (n == cap) return FAIL(FOLEY_ERR_INVALID, "profile: entry buffer too small");
       memset(&out[n], 0, sizeof(out[n]));
       strncpy(out[n].label, r.label, sizeof(out[n].label) - 1);
+      if (r.fn) {   // the kernel's symbol, demangled - the name rocprofv3's kernel trace lists it under
+        const char* mangled = hipKernelNameRefByPtr(r.fn, st);
+        if (mangled) {
+          int status = 0;
+          char* dm = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
+          strncpy(out[n].kernel, status == 0 && dm ? dm : mangled, sizeof(out[n].kernel) - 1);
+          free(dm);
+        }
+      }
       ++n;
     }
     out[j].calls += 1;
@@ -1427,11 +1440,13 @@ extern "C" int foley_op_attention_hd(const void* q, const void* k, const void* v
 }
 
 extern "C" int foley_op_attention_scatter(const void* q, const void* k, const void* v, int in_dtype, int vt_pitch, int G, int H, int Sq,
-                                          int Skv, int grp_q, int grp_kv, const int32_t* out_rows, void* out, int out_dtype, void* stream) {
+                                          int Skv, int grp_q, int grp_kv, const int32_t* out_rows, void* out, int out_nrows, int out_dtype, void* stream) {
   if (!out_rows || !out) return FAIL(FOLEY_ERR_INVALID, "null argument");
+  if (out_nrows < 1) return FAIL(FOLEY_ERR_INVALID, "attention_scatter: out has no rows");
   AttnArgs a{q, k, v, G, H, Sq, Skv, 1, out, out, 0, in_dtype, vt_pitch, 64};
   a.grp_q = grp_q; a.grp_kv = grp_kv;
   a.out_rows = out_rows;
+  a.out_nrows = out_nrows;
   return launch_attention(a, out_dtype, (hipStream_t)stream);
 }
 
@@ -1441,10 +1456,10 @@ extern "C" int foley_op_attention(const void* q, const void* k, const void* v, i
   return foley_op_attention_hd(q, k, v, in_dtype, vt_pitch, Bq, H, Sq, Skv, kv_bdiv, outA, outB, split, out_dtype, 128, stream);
 }
 
-extern "C" int foley_op_qkv_regroup(const void* qkv, int dtype, int H, const int32_t* idx_q, int G, int Sq, const int32_t* idx_kv, int Skv,
+extern "C" int foley_op_qkv_regroup(const void* qkv, int n_rows, int dtype, int H, const int32_t* idx_q, int G, int Sq, const int32_t* idx_kv, int Skv,
                                     void* q, void* k, void* v, int vt_pitch, void* stream) {
   if (!qkv || !idx_q || !idx_kv || !q || !k || !v) return FAIL(FOLEY_ERR_INVALID, "null argument");
-  return launch_qkv_regroup(qkv, dtype, H, idx_q, G, Sq, idx_kv, Skv, q, k, v, vt_pitch, (hipStream_t)stream);
+  return launch_qkv_regroup(qkv, n_rows, dtype, H, idx_q, G, Sq, idx_kv, Skv, q, k, v, vt_pitch, (hipStream_t)stream);
 }
 
 extern "C" int foley_op_resize_aa_u8(const uint8_t* in, long outer, int len_in, long inner, int len_out, const int32_t* xmin,

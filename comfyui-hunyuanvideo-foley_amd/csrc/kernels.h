@@ -143,6 +143,7 @@ struct AttnArgs {
   long long* dbg;   // tools/attn_timeline.py: 5 wall-clock stamps per workgroup of the small-grid bf16 kernel; null in production
   int grp_q, grp_kv;     // head_dim 64, 16-bit operands: > 0 = block-diagonal attention - query t attends keys [g*grp_kv, (g+1)*grp_kv), g = t / grp_q
                          // (small groups packed into one sequence: the Synchformer's 8-frame time groups, 14 of them per 128-query workgroup)
+  int out_nrows;         // rows of outA when out_rows is set: table entries outside [0, out_nrows) are dropped by the kernels
   const int* out_rows;   // head_dim 64 only: row of outA that query (b, t) is written to - [Bq, Sq]; null: [Bq, Sq] order (split above).
                          // The conditioning encoders scatter every attention of a layer (CLS rows, time / space groups) into ONE
                          // token-major buffer with the table their queries were gathered by - no torch.cat / permute copies.
@@ -218,7 +219,7 @@ int launch_solver_step(const StepArgs& a, hipStream_t st);
 int launch_dac_in(const float* x, const float* w, const float* bias, const float* alpha, int B, int T, int C,
                   float* out0, float* out1, hipStream_t st);
 int launch_rows_to_planes(const float* rows, int B, int T, int C, float* out, hipStream_t st);
-int launch_qkv_regroup(const void* qkv, int dtype, int H, const int* idx_q, int G, int Sq, const int* idx_kv, int Skv, void* q, void* k,
+int launch_qkv_regroup(const void* qkv, int n_rows, int dtype, int H, const int* idx_q, int G, int Sq, const int* idx_kv, int Skv, void* q, void* k,
                        void* v, int vt_pitch, hipStream_t st);
 int launch_resize_aa_u8(const uint8_t* in, long outer, int len_in, long inner, int len_out, const int* xmin, const int* xsize,
                         const short* w, int kmax, int prec, uint8_t* out, hipStream_t st);

@@ -857,7 +857,7 @@ int launch_dac_in(const float* x, const float* w, const float* bias, const float
 template <typename E>   // E = the element's storage type (uint16_t: bf16 / fp16, uint32_t: fp32)
 __global__ __launch_bounds__(256) void qkv_regroup_kernel(const E* __restrict__ qkv, int H, const int* __restrict__ idx_q, int Sq,
                                                           const int* __restrict__ idx_kv, int Skv, E* __restrict__ q, E* __restrict__ k,
-                                                          E* __restrict__ v, int vt_pitch) {
+                                                          E* __restrict__ v, int vt_pitch, int n_rows) {
   constexpr int HD = 64, CPR = HD * sizeof(E) / 16;   // 16-byte chunks per head row
   __shared__ __attribute__((aligned(16))) E tile[64][HD + 16 / sizeof(E)];
   const int t0 = blockIdx.x * 64, h = blockIdx.y, g = blockIdx.z;
@@ -866,11 +866,11 @@ __global__ __launch_bounds__(256) void qkv_regroup_kernel(const E* __restrict__ 
   for (int c = tid; c < 64 * CPR; c += 256) {
     const int t = t0 + c / CPR, ch = c % CPR;
     if (t < Sq) {
-      const long r = idx_q[(long)g * Sq + t];
+      const long r = min(max(idx_q[(long)g * Sq + t], 0), n_rows - 1);   // caller-supplied table: never read outside qkv [n_rows, 3*H*64]
       *(u32x4*)(q + (((long)g * H + h) * Sq + t) * HD + ch * (16 / sizeof(E))) = *(const u32x4*)(qkv + r * ld + (long)h * HD + ch * (16 / sizeof(E)));
     }
     if (t < Skv) {
-      const long r = idx_kv[(long)g * Skv + t];
+      const long r = min(max(idx_kv[(long)g * Skv + t], 0), n_rows - 1);
       const E* src = qkv + r * ld + (long)(H + h) * HD + ch * (16 / sizeof(E));
       *(u32x4*)(k + (((long)g * H + h) * Skv + t) * HD + ch * (16 / sizeof(E))) = *(const u32x4*)src;
       const u32x4 vv = *(const u32x4*)(src + (long)H * HD);
@@ -894,9 +894,9 @@ __global__ __launch_bounds__(256) void qkv_regroup_kernel(const E* __restrict__ 
   }
 }
 
-int launch_qkv_regroup(const void* qkv, int dtype, int H, const int* idx_q, int G, int Sq, const int* idx_kv, int Skv, void* q, void* k,
+int launch_qkv_regroup(const void* qkv, int n_rows, int dtype, int H, const int* idx_q, int G, int Sq, const int* idx_kv, int Skv, void* q, void* k,
                        void* v, int vt_pitch, hipStream_t st) {
-  if (G < 1 || H < 1 || Sq < 1 || Skv < 1) return foley_set_err("qkv_regroup: empty problem", __FILE__, __LINE__);
+  if (G < 1 || H < 1 || Sq < 1 || Skv < 1 || n_rows < 1) return foley_set_err("qkv_regroup: empty problem", __FILE__, __LINE__);
   if (vt_pitch && (vt_pitch % 8 || vt_pitch < Skv || vt_pitch > (Skv + 63) / 64 * 64))
     return foley_set_err("qkv_regroup: the transposed-V pitch must be a multiple of 8 in [Skv, ceil64(Skv)]", __FILE__, __LINE__);
   if (((uintptr_t)qkv | (uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) return foley_set_err("qkv_regroup: operands must be 16-byte aligned", __FILE__, __LINE__);
@@ -904,9 +904,9 @@ int launch_qkv_regroup(const void* qkv, int dtype, int H, const int* idx_q, int 
   const dim3 grid((S + 63) / 64, H, G);
   if (dtype == FOLEY_F32) {
     if (vt_pitch) return foley_set_err("qkv_regroup: fp32 operands keep V untransposed", __FILE__, __LINE__);
-    FOLEY_LAUNCH(qkv_regroup_kernel<uint32_t>, grid, dim3(256), 0, st, (const uint32_t*)qkv, H, idx_q, Sq, idx_kv, Skv, (uint32_t*)q, (uint32_t*)k, (uint32_t*)v, 0);
+    FOLEY_LAUNCH(qkv_regroup_kernel<uint32_t>, grid, dim3(256), 0, st, (const uint32_t*)qkv, H, idx_q, Sq, idx_kv, Skv, (uint32_t*)q, (uint32_t*)k, (uint32_t*)v, 0, n_rows);
   } else if (foley_is_half(dtype)) {
-    FOLEY_LAUNCH(qkv_regroup_kernel<uint16_t>, grid, dim3(256), 0, st, (const uint16_t*)qkv, H, idx_q, Sq, idx_kv, Skv, (uint16_t*)q, (uint16_t*)k, (uint16_t*)v, vt_pitch);
+    FOLEY_LAUNCH(qkv_regroup_kernel<uint16_t>, grid, dim3(256), 0, st, (const uint16_t*)qkv, H, idx_q, Sq, idx_kv, Skv, (uint16_t*)q, (uint16_t*)k, (uint16_t*)v, vt_pitch, n_rows);
   } else {
     return foley_set_err("qkv_regroup: fp32, bf16 or fp16 operands", __FILE__, __LINE__);
   }

@@ -87,11 +87,11 @@ class GemmDescC(C.Structure):
 
 class ProfEntryC(C.Structure):
     _fields_ = [("label", C.c_char * 80), ("calls", C.c_int32), ("total_ms", C.c_float), ("flop", C.c_double),
-                ("bytes", C.c_double)]
+                ("bytes", C.c_double), ("kernel", C.c_char * 200)]
 
 
 PROGRESS_CB = C.CFUNCTYPE(None, C.c_int32, C.c_int32, C.c_void_p)
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _SIGNATURES = {
     "foley_abi_version": (C.c_uint32, []),
@@ -130,8 +130,8 @@ _SIGNATURES = {
     "foley_op_ln_mod": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.POINTER(RowBcastC),
                                   C.POINTER(RowBcastC), C.c_void_p, C.c_int, C.c_void_p]),
     "foley_op_attention_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                             C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
-    "foley_op_qkv_regroup": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                             C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "foley_op_qkv_regroup": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "foley_op_resize_aa_u8": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_int, C.c_void_p, C.c_void_p]),
@@ -374,7 +374,7 @@ class FoleyContext:
         out = []
         for e in arr[:n.value]:
             calls = max(e.calls, 1)
-            out.append({"label": e.label.decode(), "calls_per_forward": e.calls / repeats,
+            out.append({"label": e.label.decode(), "kernel": e.kernel.decode(errors="replace"), "calls_per_forward": e.calls / repeats,
                         "avg_us": 1e3 * e.total_ms / calls,
                         "flop_per_launch": e.flop / calls, "bytes_per_launch": e.bytes / calls})
         return out, 1e3 * br.value
@@ -518,13 +518,14 @@ def op_attention_scatter(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out_
     half = q.dtype in (torch.bfloat16, torch.float16)
     Skv = k.shape[2]
     if hd != 64 or out_rows.dtype != torch.int32 or out_rows.numel() != G * Sq or out.dim() != 2 or out.shape[1] != H * 64 or \
-            not out.is_contiguous() or not out_rows.is_contiguous() or k.shape[:2] != q.shape[:2] or not (q.is_contiguous() and k.is_contiguous()
+            not out.is_contiguous() or not out_rows.is_contiguous() or out_rows.device != q.device or out.device != q.device or \
+            k.shape[:2] != q.shape[:2] or not (q.is_contiguous() and k.is_contiguous()
                                                                                                        and v.is_contiguous()):
         raise FoleyRuntimeError("op_attention_scatter: head_dim 64, contiguous q / k / v of one (G, H), int32 out_rows [G, Sq], contiguous out [rows, H*64]")
     if (grp_q > 0) != (grp_kv > 0) or (grp_q > 0 and not half):
         raise FoleyRuntimeError("op_attention_scatter: grp_q and grp_kv come together and need 16-bit operands")
     _check(lib, lib.foley_op_attention_scatter(_ptr(q), _ptr(k), _ptr(v), dt_of(q), v.shape[3] if half else 0, G, H, Sq, Skv,
-                                               grp_q, grp_kv, _ptr(out_rows), _ptr(out), dt_of(out), _stream()), "foley_op_attention_scatter")
+                                               grp_q, grp_kv, _ptr(out_rows), _ptr(out), out.shape[0], dt_of(out), _stream()), "foley_op_attention_scatter")
 
 
 def op_qkv_regroup(qkv: torch.Tensor, heads: int, idx_q: torch.Tensor, idx_kv: torch.Tensor):
@@ -534,14 +535,16 @@ def op_qkv_regroup(qkv: torch.Tensor, heads: int, idx_q: torch.Tensor, idx_kv: t
     lib = load_library()
     G, Sq = idx_q.shape
     Skv = idx_kv.shape[1]
-    if qkv.shape[1] != 3 * heads * 64 or idx_kv.shape[0] != G or idx_q.dtype != torch.int32 or idx_kv.dtype != torch.int32:
+    if qkv.dim() != 2 or qkv.shape[1] != 3 * heads * 64 or idx_kv.shape[0] != G or idx_q.dtype != torch.int32 or idx_kv.dtype != torch.int32:
         raise FoleyRuntimeError("op_qkv_regroup: qkv [rows, 3*H*64], int32 index tables with one row per group")
+    if not (qkv.is_contiguous() and idx_q.is_contiguous() and idx_kv.is_contiguous()) or idx_q.device != qkv.device or idx_kv.device != qkv.device:
+        raise FoleyRuntimeError("op_qkv_regroup: contiguous qkv (the kernel's row pitch is 3*H*64) and contiguous index tables on qkv's device")
     half = qkv.dtype in (torch.bfloat16, torch.float16)
     pitch = (Skv + 31) // 32 * 32 if half else 0
     q = torch.empty(G, heads, Sq, 64, device=qkv.device, dtype=qkv.dtype)
     k = torch.empty(G, heads, Skv, 64, device=qkv.device, dtype=qkv.dtype)
     v = torch.empty((G, heads, 64, pitch) if half else (G, heads, Skv, 64), device=qkv.device, dtype=qkv.dtype)
-    _check(lib, lib.foley_op_qkv_regroup(_ptr(qkv), dt_of(qkv), heads, _ptr(idx_q), G, Sq, _ptr(idx_kv), Skv, _ptr(q), _ptr(k), _ptr(v),
+    _check(lib, lib.foley_op_qkv_regroup(_ptr(qkv), qkv.shape[0], dt_of(qkv), heads, _ptr(idx_q), G, Sq, _ptr(idx_kv), Skv, _ptr(q), _ptr(k), _ptr(v),
                                          pitch, _stream()), "foley_op_qkv_regroup")
     return q, k, v
 

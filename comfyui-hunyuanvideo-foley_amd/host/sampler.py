@@ -252,12 +252,14 @@ def replicate(model: FoleyModel, dac: Optional[FoleyDAC], devices: Sequence) -> 
             if d != model.device and d not in first:
                 first[d] = key
         model.last_broadcast_s = 0.0
+        model.last_broadcast_path = None           # 'rccl' | 'peer-copy' | None (nothing crossed a device boundary)
         if first:
             per_dev = [[model.arena.buffer.view(torch.uint8).reshape(-1)] + ([dac.arena.buffer.view(torch.uint8).reshape(-1)] if dac is not None else [])]
             for d, key in first.items():
                 per_dev.append([bufs[key][0].view(torch.uint8).reshape(-1)] + ([bufs[key][1].view(torch.uint8).reshape(-1)] if dac is not None else []))
             try:
                 model.last_broadcast_s = _rt.bcast_local(per_dev)
+                model.last_broadcast_path = "rccl"
             except FoleyRuntimeError as e:          # no librccl in the process / ncclCommInitAll refused the device list
                 import logging
                 import time as _time
@@ -269,6 +271,7 @@ def replicate(model: FoleyModel, dac: Optional[FoleyDAC], devices: Sequence) -> 
                 for d in first:
                     torch.cuda.synchronize(d)
                 model.last_broadcast_s = _time.perf_counter() - t0
+                model.last_broadcast_path = "peer-copy"    # so no record attributes this time to RCCL
         for key, d in pending:                      # further contexts on a device: device-local copies of what is there already
             if first.get(d) == key:
                 continue
@@ -325,6 +328,7 @@ def denoise_process_multi(visual_feats, text_feats, audio_len_in_s, replicas: Se
 
     failed = threading.Event()              # set by the first failing worker; the others do not start (or stop at their next iteration)
     running = [False] * len(replicas)
+    fail_lock = threading.Lock()
 
     def work(r):
         lo, hi = shards[r]
@@ -345,19 +349,23 @@ def denoise_process_multi(visual_feats, text_feats, audio_len_in_s, replicas: Se
                     progress=progress if r == 0 else None, _abort_event=failed)
                 torch.cuda.current_stream().synchronize()
         except Exception as e:          # surfaced on the calling thread
-            errors.append(e)
-            failed.set()                # replicas still in prepare / warm-up see it before their loop starts (foley_sample
-            import time as _time        # clears a stale abort request at entry); the ones inside the loop stop at the next iteration:
-            while True:                 # keep asking until every other worker has left (closes the check-then-clear window)
-                busy = [i for i in range(len(replicas)) if i != r and running[i]]
-                for i in busy:
-                    try:
-                        replicas[i][0].ctx.abort()
-                    except Exception:   # noqa: BLE001 - best effort; the first error is the one reported
-                        pass
-                if not busy:
-                    break
-                _time.sleep(0.005)
+            running[r] = False          # FIRST: a second failing (or aborted) worker must not keep the first one waiting on it
+            with fail_lock:
+                first_failure = not failed.is_set()
+                errors.append(e)
+                failed.set()            # replicas still in prepare / warm-up see it before their loop starts (foley_sample
+            if first_failure:           # clears a stale abort request at entry); the ones inside the loop stop at the next iteration.
+                import time as _time    # Only the FIRST failing worker asks, and keeps asking until every other worker has left
+                while True:             # (closes the check-then-clear window); workers that fail because of the abort just leave.
+                    busy = [i for i in range(len(replicas)) if i != r and running[i]]
+                    for i in busy:
+                        try:
+                            replicas[i][0].ctx.abort()
+                        except Exception:   # noqa: BLE001 - best effort; the first error is the one reported
+                            pass
+                    if not busy:
+                        break
+                    _time.sleep(0.005)
         finally:
             running[r] = False
 

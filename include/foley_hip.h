@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define FOLEY_ABI_VERSION 11   /* 11: foley_op_resize_aa_u8 (the frames' antialiased uint8 resize, bit for bit), foley_op_attention_scatter, foley_rowbcast.periodic_cfgs; 10: foley_op_qkv_regroup (token regrouping of the conditioning encoders' attention); 9: foley_bcast_local (single-process grouped broadcast of the arenas); 8: foley_qkv_split_desc.attn_* (cross attention in the epilogue of its q projection), foley_abort / FOLEY_ERR_ABORTED; 7: FOLEY_DT_F16 as a compute dtype (foley_config.compute_dtype, op descriptors); 6: foley_rowbcast.Ls (mode 2: nearest-exact up-sampled operand); 5: reference-keyed loading (foley_weights_*, foley_load_tensor, foley_bcast_weights); 4: fp8 weight storage (dtype codes 3/4, foley_gemm_desc.ldw/.wfmt); 3: foley_profile_forward; 2: foley_gemm_desc gained partials / qkv / rstride; foley_op_ln_mod_pending, foley_dac_encode */
+#define FOLEY_ABI_VERSION 12   /* 12: foley_op_qkv_regroup.n_rows / foley_op_attention_scatter.out_nrows (the caller-supplied row tables are range-checked on the device: source rows clamped, output rows outside the buffer dropped); 11: foley_op_resize_aa_u8 (the frames' antialiased uint8 resize, bit for bit), foley_op_attention_scatter, foley_rowbcast.periodic_cfgs; 10: foley_op_qkv_regroup (token regrouping of the conditioning encoders' attention); 9: foley_bcast_local (single-process grouped broadcast of the arenas); 8: foley_qkv_split_desc.attn_* (cross attention in the epilogue of its q projection), foley_abort / FOLEY_ERR_ABORTED; 7: FOLEY_DT_F16 as a compute dtype (foley_config.compute_dtype, op descriptors); 6: foley_rowbcast.Ls (mode 2: nearest-exact up-sampled operand); 5: reference-keyed loading (foley_weights_*, foley_load_tensor, foley_bcast_weights); 4: fp8 weight storage (dtype codes 3/4, foley_gemm_desc.ldw/.wfmt); 3: foley_profile_forward; 2: foley_gemm_desc gained partials / qkv / rstride; foley_op_ln_mod_pending, foley_dac_encode */
 
 enum foley_dtype {
   FOLEY_DT_F32 = 0, FOLEY_DT_BF16 = 1, FOLEY_DT_I32 = 2,
@@ -174,6 +174,7 @@ typedef struct foley_prof_entry {
   int32_t calls;
   float total_ms;
   double flop, bytes;
+  char kernel[200];   /* ABI 12: demangled symbol of the kernel the op launched - the row name in a rocprofv3 kernel trace ("" if none) */
 } foley_prof_entry;
 int foley_profile_forward(foley_ctx* ctx, const float* latents, int iter, int repeats, foley_prof_entry* out,
                           int cap, int* n_out, float* bracket_ms, void* stream);
@@ -269,16 +270,18 @@ int foley_op_attention_hd(const void* q, const void* k, const void* v, int in_dt
  * rearrange) write ONE token-major buffer, ready for the output projection.
  * grp_q / grp_kv > 0 (16-bit operands): block-diagonal attention - the sequence is a pack of small groups, query t attends keys
  * [g*grp_kv, (g+1)*grp_kv) with g = t / grp_q only (DividedAttention over time: 8 frame queries x (CLS + 8 frame keys) per location;
- * 14 locations share one 128-query workgroup instead of taking one each); 0 / 0: every query sees all Skv keys. */
+ * 14 locations share one 128-query workgroup instead of taking one each); 0 / 0: every query sees all Skv keys.
+ * out has out_nrows rows: a table entry outside [0, out_nrows) drops that query's output instead of writing out of bounds. */
 int foley_op_attention_scatter(const void* q, const void* k, const void* v, int in_dtype, int vt_pitch, int G, int H, int Sq,
-                               int Skv, int grp_q, int grp_kv, const int32_t* out_rows, void* out, int out_dtype, void* stream);
+                               int Skv, int grp_q, int grp_kv, const int32_t* out_rows, void* out, int out_nrows, int out_dtype, void* stream);
 /* Token regrouping between a fused q/k/v projection and foley_op_attention_hd at head_dim 64 - the conditioning encoders
  * (reference models/synchformer/vit_helper.py:37-105 DividedAttention: patch tokens attend over the frames of their location or
  * the locations of their frame with the CLS key / value prepended; transformers' SiglipAttention / ClapTextSelfAttention head split):
  * qkv [rows, 3*H*64] in nn.Linear(dim, 3*dim)'s (K H D) packing; group g reads source rows idx_q[g*Sq + t] as its queries and
  * idx_kv[g*Skv + t] as its keys / values and writes q [G,H,Sq,64], k [G,H,Skv,64] and v [G,H,Skv,64] (vt_pitch 0) or - 16-bit
- * operands - v TRANSPOSED [G,H,64,vt_pitch] with zeros beyond Skv (vt_pitch a multiple of 8 in [Skv, ceil64(Skv)]). */
-int foley_op_qkv_regroup(const void* qkv, int dtype, int H, const int32_t* idx_q, int G, int Sq, const int32_t* idx_kv, int Skv,
+ * operands - v TRANSPOSED [G,H,64,vt_pitch] with zeros beyond Skv (vt_pitch a multiple of 8 in [Skv, ceil64(Skv)]).
+ * qkv has n_rows rows: table entries are clamped to [0, n_rows) on the device, so a bad table cannot read out of bounds. */
+int foley_op_qkv_regroup(const void* qkv, int n_rows, int dtype, int H, const int32_t* idx_q, int G, int Sq, const int32_t* idx_kv, int Skv,
                          void* q, void* k, void* v, int vt_pitch, void* stream);
 /* One pass of the frames' antialiased bicubic uint8 resize - replaces torchvision's v2.Resize(interpolation=BICUBIC, antialias=True)
  * on uint8 tensors in the nodes' pre-processing (reference nodes.py:184-196, utils.py:262-283; on the CPU that dispatches to ATen's

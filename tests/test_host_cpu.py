@@ -210,7 +210,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(rt.EXPORTED_SYMBOLS), declared ^ set(rt.EXPORTED_SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.foley_abi_version() == rt.ABI_VERSION == 11
+    assert lib.foley_abi_version() == rt.ABI_VERSION == 12
 
 
 def test_no_cpu_fallback():
@@ -325,6 +325,95 @@ def test_text_padding_and_noise_draw():
     g = golden("g6_c1_xxl")
     n = sampler.draw_noise(1, 128, 50, torch.float32, torch.Generator("cpu").manual_seed(1234))
     assert torch.equal(n, g["noise"])
+
+
+def _mock_replicas(monkeypatch, n, behaviour):
+    """N mocked replicas for `denoise_process_multi` on a box without a GPU: the stream / device context managers of
+    torch.cuda are replaced by no-ops and `denoise_process_with_generator` by `behaviour(r, model, abort_event)`."""
+    import contextlib
+    import types
+
+    class _Stream:
+        def __init__(self, *_a, **_k): pass
+        def wait_event(self, _ev): pass
+        def synchronize(self): pass
+
+    monkeypatch.setattr(torch.cuda, "Stream", _Stream)
+    monkeypatch.setattr(torch.cuda, "device", lambda _d: contextlib.nullcontext())
+    monkeypatch.setattr(torch.cuda, "stream", lambda _s: contextlib.nullcontext())
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *_a: _Stream())
+    cfg = types.SimpleNamespace(frame_rate=50, text_len=128, latent_dim=128)
+    reps = []
+    for r in range(n):
+        ctx = types.SimpleNamespace(aborted=False)
+        ctx.abort = (lambda c: (lambda: setattr(c, "aborted", True)))(ctx)
+        reps.append((types.SimpleNamespace(cfg=cfg, dtype=torch.float32, device=torch.device("cpu"), _text_len_fixed=None, ctx=ctx, rank=r), None))
+
+    def fake(visual, text, secs, model, dac, cfg_scale, steps, bs, solver, **kw):
+        return behaviour(model.rank, model, kw["_abort_event"], kw.get("progress"), bs)
+    monkeypatch.setattr(sampler, "denoise_process_with_generator", fake)
+    return reps
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_failing_replica_does_not_deadlock_the_others(monkeypatch, n):
+    """a ComfyUI cancel - the progress callback of replica 0 raises - with other replicas inside their
+    loops.  Every aborted replica raises too (foley_sample returns ABORTED -> FoleyRuntimeError); the first failing worker
+    used to wait for `running[i]` of workers that were themselves spinning in their own `except` block: both waited forever.
+    The call must return the FIRST error, promptly, and have asked every running replica to stop."""
+    import threading
+    import time
+
+    class Cancel(Exception):
+        pass
+
+    inside = threading.Barrier(n)
+
+    def behaviour(r, model, abort_event, progress, bs):
+        inside.wait(timeout=5)                       # every replica is inside its loop before the cancel arrives
+        if r == 0:
+            progress(1, 10)                          # raises Cancel on the worker thread
+        t0 = time.time()
+        while not model.ctx.aborted:                 # the loop of the other replicas: stops when foley_abort() was called
+            assert time.time() - t0 < 5, "replica was never asked to stop"
+            time.sleep(0.001)
+        raise rt.FoleyRuntimeError("foley_sample: aborted")
+
+    reps = _mock_replicas(monkeypatch, n, behaviour)
+
+    def cancel(_i, _n):
+        raise Cancel()
+
+    out = {}
+
+    def call():
+        try:
+            sampler.denoise_process_multi({}, {"text_feat": torch.zeros(1, 12, 8)}, 1.0, reps, 4.5, 10, n, "euler",
+                                          generator=torch.Generator("cpu").manual_seed(1), progress=cancel)
+        except BaseException as e:                   # noqa: BLE001
+            out["err"] = e
+
+    t = threading.Thread(target=call, daemon=True)
+    t.start()
+    t.join(10)
+    assert not t.is_alive(), "denoise_process_multi is stuck: failing workers wait on each other"
+    assert isinstance(out.get("err"), Cancel), out                      # the first error is the one reported
+    assert all(m.ctx.aborted for m, _ in reps[1:])
+
+
+def test_replica_still_in_setup_does_not_start_after_a_failure(monkeypatch):
+    """A replica that fails before the others have entered their loop: they see the shared event and never start."""
+    started = []
+
+    def behaviour(r, model, abort_event, progress, bs):
+        started.append(r)
+        raise rt.FoleyRuntimeError("boom")
+
+    reps = _mock_replicas(monkeypatch, 3, behaviour)
+    with pytest.raises(rt.FoleyRuntimeError, match="boom"):
+        sampler.denoise_process_multi({}, {"text_feat": torch.zeros(1, 12, 8)}, 1.0, reps, 4.5, 10, 3, "euler",
+                                      generator=torch.Generator("cpu").manual_seed(1))
+    assert 1 <= len(started) <= 3
 
 
 def test_checkpoint_file_formats(tmp_path):

@@ -466,6 +466,33 @@ def test_gemm_exact_gelu_epilogue(dev, dtype, tile):
     assert rel_err(out.float(), F.gelu(y, approximate="tanh")) > rel_err(out.float(), F.gelu(y)) or dtype == torch.bfloat16
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_exact_gelu_fast_form_error_bound(dev, dtype):
+    """common.h::gelu_erf_fast (16-bit outputs) over x in [-8, 8]: the Abramowitz-Stegun 7.1.26 erfc form has an ABSOLUTE error
+    bound of 1.5e-7 on erfc, i.e. <= 0.5 |x| 1.5e-7 <= 6e-7 on GELU(x) - far below a 16-bit ulp for |GELU| > 2e-3 (bf16) / 2e-2 (fp16), but a LARGE
+    relative error in the negative tail (x <= -5, |GELU| ~ 1e-6: tens of percent).  The bound that holds everywhere is absolute:
+    |out - GELU(x)| <= half a 16-bit ulp of the result + 8e-7.  x is fed through a GEMM with a one-hot weight (y = x exactly)."""
+    M, N, K = 4096, 64, 64
+    x = torch.linspace(-8.0, 8.0, M).to(dtype)                      # representable inputs
+    A = torch.zeros(M, K, dtype=dtype)
+    A[:, 0] = x
+    W = torch.zeros(N, K, dtype=dtype)
+    W[:, 0] = 1.0
+    out = torch.empty(M, N, device=dev, dtype=dtype)
+    rt.op_gemm(A.to(dev), W.to(dev), torch.zeros(N, device=dev), out0=out, epilogue=rt.EPI_GELU_T, gelu_erf=True)
+    xd = x.double()
+    ref = 0.5 * xd * (1.0 + torch.erf(xd / math.sqrt(2.0)))
+    got = out[:, 0].double().cpu()
+    assert torch.equal(out.cpu(), out[:, :1].expand(M, N).cpu())    # every column saw the same y
+    mant = 8 if dtype == torch.bfloat16 else 11
+    ulp = torch.maximum(torch.ldexp(torch.ones_like(ref), torch.floor(torch.log2(ref.abs().clamp_min(1e-30))) - (mant - 1)),
+                        torch.full_like(ref, 2.0 ** -24 if dtype == torch.float16 else 0.0))   # fp16 subnormal spacing
+    err = (got - ref).abs()
+    assert bool((err <= 0.5 * ulp + 8e-7).all()), float((err - 0.5 * ulp).max())
+    main = ulp >= 1.2e-5      # |GELU| > ~2e-3 (bf16) / ~1.6e-2 (fp16): 6e-7 is < 5 % of an ulp there - the form IS exact to 16-bit rounding
+    assert bool(main.sum() > M // 2) and bool((err[main] <= 0.56 * ulp[main]).all()), float((err[main] / ulp[main]).max())
+
+
 def test_attention_bf16_spiky(dev):
     q, k, v = _rand((1, 1, 64, 128), 33), _rand((1, 1, 200, 128), 34), _rand((1, 1, 200, 128), 35)
     k[0, 0, 150] = q[0, 0, 7] * 5.0
