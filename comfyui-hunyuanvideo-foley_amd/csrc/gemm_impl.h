@@ -709,7 +709,7 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
       if (al & 15) return foley_set_err("fused head split: operands must be 16-byte aligned", __FILE__, __LINE__);
     }
     const bool listed = tile == 1 || tile == 2 || tile == 5 || tile == 7 || tile == 8 || tile == 9 || tile == 15 || tile == 19 || tile == 25 ||
-                        tile == 26 || tile == 27 || tile == 28 || tile == 29;
+                        tile == 26 || tile == 27 || tile == 28 || tile == 29 || tile == 32;
     if (tile_auto && tile == 29 && !g.wfmt) {
       // Large grids: workgroups run in ceil(n / 256) rounds of (BM + 128) * 128 bytes per K-slice each - 192-row tiles
       // win when they save bytes without adding a round (M = 4000 q/k/v: 3 rounds either way, 320 instead of 384 rows
@@ -736,6 +736,29 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
       long b96 = (long)((g.M + 95) / 96) * (g.N / 128);
       if (g1) b96 += (long)((g1s.M + 95) / 96) * (g1s.N / 128);
       if (tile == 25 && ws96 && b96 <= 256 && b128 > 100 && (g.M % 128 == 0 ? false : (g.M + 95) / 96 * 96 - g.M < 96)) tile = 26;
+    }
+  }
+  // Short-K plain layers of the large grids whose epilogue rules out a K split (fc1's GELU, the q/k/v head split; K = 1536 / 1408;
+  // one problem or the audio + visual pair of a two-stream block): such a launch is whole ROUNDS of 256 workgroups, and per round a
+  // 256x256 BK = 32 tile costs ~1.64x a 256x128 tile's round at K = 1536 for twice the area (tools/wide_bench.py, M = 4000 / 3000, bf16
+  // and fp8 storage: 45 / 43 us against 27.5 / 26 us; a 192x128 round 23.7 us = 0.86).  The 256x256 tile is taken where that count
+  // says it wins by more than 5 %: fc1 of the two-stream blocks at bs = 8 (M = 4000 + 640: 2 rounds against 4), q/k/v of the 30 s
+  // clip (M = 3000: 216 / 252 tiles = ONE round against two of 256x128).  FOLEY_WIDE_SHORTK=0 keeps the 256x128 / 192x128 tiles.
+  if (tile_auto && sizeof(T) == 2 && (epi == EPI_GELU_T || epi == EPI_QKV_SPLIT) && (tile == 19 || tile == 29 || tile == 28)) {
+    static const bool on = []() { const char* e = getenv("FOLEY_WIDE_SHORTK"); return !(e && e[0] == '0'); }();
+    auto plain = [&](const GemmArgs& q) {
+      return q.taps == 1 && q.segV >= q.M && q.rstride <= 1 && q.tap0 == 0 && q.tapC % 32 == 0 && q.K >= 1024 && q.K < 2048 &&
+             (epi == EPI_QKV_SPLIT || gemm_vec_out_ok<T>(q, epi));
+    };
+    auto tiles = [&](int bm, int bn) {
+      long n = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
+      if (g1) n += (long)((g1s.M + bm - 1) / bm) * ((g1s.N + bn - 1) / bn);
+      return n;
+    };
+    if (on && plain(g) && (!g1 || plain(g1s))) {
+      const double cur = (double)((tiles(tile == 28 ? 192 : 256, 128) + 255) / 256) * (tile == 28 ? 0.86 : 1.0);
+      const double wide = (double)((tiles(256, 256) + 255) / 256) * 1.64;
+      if (wide < 0.95 * cur) tile = 32;
     }
   }
   if (epi != EPI_GATE_RES || g.ksplit == 1 || (g.ksplit == 0 && sizeof(T) == 4)) {
@@ -826,9 +849,12 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
   if ((g.ldw != g.K || (g1 && g1s.ldw != g1s.K)) && tile != 31 && tile != 32 && !(tile == 15 || tile == 19 || tile == 21 || tile == 22 || tile == 23 || tile == 24 || tile == 25 || tile == 26 || tile == 27 || tile == 28 || tile == 29))
     return foley_set_err("GEMM: padded weight rows (ldw != K) need a wave-specialised tile", __FILE__, __LINE__);
   if (tile == 31 || tile == 32) {   // 256x256 tiles on the BK = 32 mainloop (gemm_wide_impl.h)
-    if (g1) return foley_set_err("GEMM: the 256x256 tiles have no two-problem form", __FILE__, __LINE__);
-    if constexpr (__is_same(T, bf16_t)) return launch_gemm_wide_bf16(g, epi, tile, st);
-    else if constexpr (__is_same(T, f16_t)) return launch_gemm_wide_f16(g, epi, tile, st);
+    if (epi == EPI_QKV_SPLIT) {   // the fused cross attention exists on the 64-row tile only: the caller launches the attention
+      if (g.qs.attn_fused) *g.qs.attn_fused = 0;
+      if (g1 && g1s.qs.attn_fused) *g1s.qs.attn_fused = 0;
+    }
+    if constexpr (__is_same(T, bf16_t)) return launch_gemm_wide_bf16(g, g1, epi, tile, st);
+    else if constexpr (__is_same(T, f16_t)) return launch_gemm_wide_f16(g, g1, epi, tile, st);
     else return foley_set_err("GEMM: the 256x256 tiles serve 16-bit operands", __FILE__, __LINE__);
   }
   if (tile == 11 || tile == 13) {

@@ -47,9 +47,11 @@ constexpr int wide_inflight(int nsb, int taps, int tap, int ai, int bi) {
 
 template <int N> __device__ __forceinline__ void wide_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int NW, int TAPS, int NSB, int NAB, int EPI, int WF>
-__global__ __launch_bounds__(NW * 64) void gemm_wide_kernel(const GemmPair pr) {
-  const GemmArgs& g = pr.g[0];
+// SEL: which problem of a two-problem launch (the audio and the visual stream of a two-stream block: hifi_foley.py:218-226,
+// 324-334) this workgroup runs - a template parameter for the reason given at gemm_ws_body (constant kernel-argument offsets).
+template <typename T, int NW, int TAPS, int NSB, int NAB, int EPI, int WF, int SEL>
+__device__ __forceinline__ void gemm_wide_body(const GemmPair& pr) {
+  const GemmArgs& g = pr.g[SEL];
   constexpr int BM = 256, BN = 256, BK = 32, ESZ = 2, OOB = 0x7ffffff0;
   constexpr int WM = 2, WN = NW / 2, TM = BM / WM, TN = BN / WN, FM = TM / 32, FN = TN / 32;
   constexpr int WSZ = WF ? 1 : 2, BROW = BK * WSZ;       // 64-byte (bf16 / fp16) or 32-byte (fp8) weight rows
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_wide_kernel(const GemmPair pr) {
 
   const int tiles_m = (g.M + BM - 1) / BM;
   const int tiles_n = (g.N + BN - 1) / BN;
-  int bid = (int)blockIdx.x;
+  int bid = (int)blockIdx.x - (SEL ? pr.tiles0 : 0);
   {  // bijective XCD remap: consecutive tile ids (same weight panel) share an XCD / L2 (gemm_ws_kernel)
     const int nwg = tiles_m * tiles_n * (EPI == EPI_GATE_RES ? g.ksplit : 1);
     const int xcd = bid & 7, slot = bid >> 3;
@@ -317,8 +319,20 @@ __global__ __launch_bounds__(NW * 64) void gemm_wide_kernel(const GemmPair pr) {
   tl_stamp(g, 3);
 }
 
+// PAIR: the launch may carry two problems (workgroups from pr.tiles0 on run the second one) - instantiated for the epilogues of
+// the two-stream blocks' K = 1536 layers only (fc1's GELU, the q/k/v head split): two bodies double the code of a kernel.
+template <typename T, int NW, int TAPS, int NSB, int NAB, int EPI, int WF, bool PAIR>
+__global__ __launch_bounds__(NW * 64) void gemm_wide_kernel(const GemmPair pr) {
+  if constexpr (PAIR) {
+    if ((int)blockIdx.x >= pr.tiles0) gemm_wide_body<T, NW, TAPS, NSB, NAB, EPI, WF, 1>(pr);   // workgroup-uniform
+    else gemm_wide_body<T, NW, TAPS, NSB, NAB, EPI, WF, 0>(pr);
+  } else {
+    gemm_wide_body<T, NW, TAPS, NSB, NAB, EPI, WF, 0>(pr);
+  }
+}
+
 template <typename T, int NW, int TAPS, int EPI, int WF>
-int launch_wide_one(const GemmArgs& g, hipStream_t st) {
+int launch_wide_one(const GemmArgs& g, const GemmArgs* g1, hipStream_t st) {
   // conv k=3: 3 (fp8: 4) activation chunks + 6 (8) weight slices; plain: one activation chunk per weight slice, 5 (6) deep
   constexpr int NSB = TAPS == 3 ? (WF ? 8 : 6) : (WF ? 6 : 5);
   constexpr int NAB = TAPS == 3 ? (NSB + 2 + 2) / 3 : NSB;
@@ -326,32 +340,37 @@ int launch_wide_one(const GemmArgs& g, hipStream_t st) {
   constexpr size_t lds_epi = (size_t)256 * 128 * 4;
   constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
   static_assert(lds <= 160 * 1024, "LDS budget");
+  constexpr bool PAIR = TAPS == 1 && (EPI == EPI_GELU_T || EPI == EPI_QKV_SPLIT);
+  if (g1 && !PAIR) return foley_set_err("256x256 GEMM: two-problem launches exist for the GELU and head-split epilogues of plain layers", __FILE__, __LINE__);
+  auto ntiles = [](const GemmArgs& q) { return ((q.M + 255) / 256) * ((q.N + 255) / 256) * (EPI == EPI_GATE_RES ? q.ksplit : 1); };
   GemmPair pr;
   pr.g[0] = g;
-  pr.g[1] = g;
-  pr.tiles0 = ((g.M + 255) / 256) * ((g.N + 255) / 256) * (EPI == EPI_GATE_RES ? g.ksplit : 1);
-  auto k = gemm_wide_kernel<T, NW, TAPS, NSB, NAB, EPI, WF>;
+  pr.g[1] = g1 ? *g1 : g;
+  pr.tiles0 = ntiles(g);
+  const int tiles = pr.tiles0 + (g1 ? ntiles(*g1) : 0);
+  auto k = gemm_wide_kernel<T, NW, TAPS, NSB, NAB, EPI, WF, PAIR>;
   static std::atomic<unsigned long long> raised{0};
   {
     hipError_t e = foley_raise_lds((const void*)k, (int)lds, raised);
     if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);
   }
-  FOLEY_LAUNCH(k, dim3(pr.tiles0), dim3(NW * 64), lds, st, pr);
+  FOLEY_LAUNCH(k, dim3(tiles), dim3(NW * 64), lds, st, pr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return foley_set_err(hipGetErrorString(e), __FILE__, __LINE__);
   return 0;
 }
 
 template <typename T, int NW, int TAPS, int WF>
-int launch_wide_fmt(const GemmArgs& g, int epi, hipStream_t st) {
+int launch_wide_fmt(const GemmArgs& g, const GemmArgs* g1, int epi, hipStream_t st) {
   switch (epi) {
-    case EPI_STORE_F32: return launch_wide_one<T, NW, TAPS, EPI_STORE_F32, WF>(g, st);
-    case EPI_GATE_RES: return launch_wide_one<T, NW, TAPS, EPI_GATE_RES, WF>(g, st);
-    case EPI_SILUGATE_T: return launch_wide_one<T, NW, TAPS, EPI_SILUGATE_T, WF>(g, st);
+    case EPI_STORE_F32: return launch_wide_one<T, NW, TAPS, EPI_STORE_F32, WF>(g, g1, st);
+    case EPI_GATE_RES: return launch_wide_one<T, NW, TAPS, EPI_GATE_RES, WF>(g, g1, st);
+    case EPI_SILUGATE_T: return launch_wide_one<T, NW, TAPS, EPI_SILUGATE_T, WF>(g, g1, st);
   }
   if constexpr (TAPS == 1) {
     switch (epi) {
-      case EPI_GELU_T: return launch_wide_one<T, NW, TAPS, EPI_GELU_T, WF>(g, st);
+      case EPI_GELU_T: return launch_wide_one<T, NW, TAPS, EPI_GELU_T, WF>(g, g1, st);
+      case EPI_QKV_SPLIT: return launch_wide_one<T, NW, TAPS, EPI_QKV_SPLIT, WF>(g, g1, st);   // each 128-column half of the tile is one head (two epilogue passes)
     }
   }
   return foley_set_err("256x256 GEMM: unsupported epilogue", __FILE__, __LINE__);
@@ -360,19 +379,22 @@ int launch_wide_fmt(const GemmArgs& g, int epi, hipStream_t st) {
 // tile: 31 = tap-fused conv k=3, 32 = plain linear layer (eight waves of 128x64 each).  g resolved (ksplit, vec_out, operand
 // extents) by gemm_impl.h's launcher.
 template <typename T>
-int launch_gemm_wide_t(const GemmArgs& g, int epi, int tile, hipStream_t st) {
-  if (g.wfmt < 0 || g.wfmt > 2) return foley_set_err("256x256 GEMM: bad weight format", __FILE__, __LINE__);
-  if (!g.vec_out && epi != EPI_QKV_SPLIT) return foley_set_err("256x256 GEMM: the problem must qualify for the vector epilogue", __FILE__, __LINE__);
+int launch_gemm_wide_t(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hipStream_t st) {
   const bool conv = tile == 31;
-  if (conv ? !(g.taps == 3 && g.dil == 1 && g.tap0 == -1 && g.rstride <= 1 && g.segV == g.segS)
-           : !(g.taps == 1 && g.segV >= g.M && g.rstride <= 1 && g.tap0 == 0))
-    return foley_set_err("256x256 GEMM: operand addressing not supported by this tile", __FILE__, __LINE__);
-  if (g.tapC % 32) return foley_set_err("256x256 GEMM: channels must be a multiple of 32", __FILE__, __LINE__);
+  for (const GemmArgs* q : {&g, g1}) {
+    if (!q) continue;
+    if (q->wfmt < 0 || q->wfmt > 2 || q->wfmt != g.wfmt) return foley_set_err("256x256 GEMM: bad weight format", __FILE__, __LINE__);
+    if (!q->vec_out && epi != EPI_QKV_SPLIT) return foley_set_err("256x256 GEMM: the problem must qualify for the vector epilogue", __FILE__, __LINE__);
+    if (conv ? !(q->taps == 3 && q->dil == 1 && q->tap0 == -1 && q->rstride <= 1 && q->segV == q->segS)
+             : !(q->taps == 1 && q->segV >= q->M && q->rstride <= 1 && q->tap0 == 0))
+      return foley_set_err("256x256 GEMM: operand addressing not supported by this tile", __FILE__, __LINE__);
+    if (q->tapC % 32) return foley_set_err("256x256 GEMM: channels must be a multiple of 32", __FILE__, __LINE__);
+  }
 #define FOLEY_WIDE_CASE(NWV, TAPSV)                                                       \
   do {                                                                                    \
-    if (g.wfmt == 0) return launch_wide_fmt<T, NWV, TAPSV, 0>(g, epi, st);               \
-    if (g.wfmt == 1) return launch_wide_fmt<T, NWV, TAPSV, 1>(g, epi, st);               \
-    return launch_wide_fmt<T, NWV, TAPSV, 2>(g, epi, st);                                 \
+    if (g.wfmt == 0) return launch_wide_fmt<T, NWV, TAPSV, 0>(g, g1, epi, st);           \
+    if (g.wfmt == 1) return launch_wide_fmt<T, NWV, TAPSV, 1>(g, g1, epi, st);           \
+    return launch_wide_fmt<T, NWV, TAPSV, 2>(g, g1, epi, st);                             \
   } while (0)
   switch (tile) {
     case 31: FOLEY_WIDE_CASE(8, 3);

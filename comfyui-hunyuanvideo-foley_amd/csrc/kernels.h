@@ -117,8 +117,8 @@ int launch_gemm_ws_bf16(const GemmArgs& g, const GemmArgs* g1, int epi, int tile
 int launch_gemm_ws_f16(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hipStream_t st);
 // 256x256 tiles on the BK = 32 mainloop (gemm_wide_impl.h): tile 31 = tap-fused conv k=3, 32 = plain linear layer (eight waves of
 // 128x64); single problem, vector epilogue, any weight storage
-int launch_gemm_wide_bf16(const GemmArgs& g, int epi, int tile, hipStream_t st);
-int launch_gemm_wide_f16(const GemmArgs& g, int epi, int tile, hipStream_t st);
+int launch_gemm_wide_bf16(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hipStream_t st);
+int launch_gemm_wide_f16(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // Attention: O = softmax(Q K^T / sqrt(hd)) V, no mask, hd = 128 (or 64: AttnArgs::head_dim).  Q [Bq, H, Sq, hd], K/V [Bkv, H, Skv, hd]

@@ -2,6 +2,8 @@
 reference (tests/golden/*.npz) and against the CPU oracle: DiT forward, blocks at full width,
 sampler loop with all solvers, DAC decoder, and the config-C1 gate at real xxl dimensions.
 """
+import os
+
 import pytest
 import torch
 
@@ -601,6 +603,13 @@ def test_large_grid_tiles_against_the_oracle(dev, name, hidden, heads, dtype, fm
         txt = {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]}
         model.ctx.prepare(sampler.build_plan(model, vis, txt, La, 4.5, steps, clips, "euler"))
         rows = model.ctx.dit_forward(x.to(dev).contiguous(), it).float().cpu()          # [(cfg, clip, l), 128]
+        if os.environ.get("FOLEY_WIDE_SHORTK", "1") != "0" and os.environ.get("FOLEY_WIDE", "1") != "0":
+            # round 6: the short-K layers whose epilogue rules out a K split take the 256x256 tile where it saves whole rounds of
+            # workgroups - fc1 of the two-stream pair at M = 4000 + 640 (two-problem launch), q/k/v at M = 3000 (one round)
+            kern = {e["label"]: e["kernel"] for e in model.ctx.profile_forward(x.to(dev).contiguous(), it=it, repeats=1)[0]}
+            want = ["triple.mlp fc1 GEMM + GELU"] if clips == 8 else ["single.qkv GEMM + RMSNorm/RoPE head split", "triple.qkv GEMM + RMSNorm/RoPE head split"]
+            for lab in want:
+                assert "gemm_wide_kernel" in kern[lab], (dur, lab, kern[lab])
         t_it = tables.model_timesteps(tables.sigma_grid(steps))[it]
         text77, unc77 = O.pad_or_trim_text(cond["text"]), O.pad_or_trim_text(cond["uncond_text"])
         e_clip = sd["empty_clip_feat"].view(1, 1, -1).expand(1, Lv, -1)

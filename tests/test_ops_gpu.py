@@ -686,11 +686,12 @@ def test_qkv_split_bf16_transposed_v(dev):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,L,H,Lv,tile", [(2, 11, 3, 4, 0), (2, 250, 2, 40, 0), (3, 70, 2, 3, 5), (2, 250, 1, 40, 9),
                                            (2, 250, 2, 40, 15), (3, 70, 1, 3, 19), (2, 250, 2, 40, 25), (3, 70, 1, 3, 29),
-                                           (4, 37, 2, 8, 2), (2, 250, 2, 40, 27), (3, 70, 1, 3, 27), (2, 250, 2, 40, 26), (3, 70, 1, 3, 26), (2, 250, 2, 40, 28), (3, 70, 1, 3, 28)])
+                                           (4, 37, 2, 8, 2), (2, 250, 2, 40, 27), (3, 70, 1, 3, 27), (2, 250, 2, 40, 26), (3, 70, 1, 3, 26), (2, 250, 2, 40, 28), (3, 70, 1, 3, 28),
+                                           (2, 250, 2, 40, 32), (3, 70, 1, 3, 32), (5, 250, 3, 40, 32)])   # 32: the 256x256 BK = 32 tile, one head per 128-column epilogue pass (N = 384: a half-dead last tile)
 def test_gemm_fused_head_split(dev, dtype, B, L, H, Lv, tile):
     """q/k/v projection with the head split fused into the GEMM epilogue (RMSNorm + RoPE into
     [B, H, S, 128]; bf16: V transposed [B, H, 128, pitch]) vs the unfused oracle math."""
-    if tile in (9, 15, 19, 25, 26, 27, 28, 29) and dtype == torch.float32:
+    if tile in (9, 15, 19, 25, 26, 27, 28, 29, 32) and dtype == torch.float32:
         pytest.skip("bf16-only tile")
     K = 256
     S = L + Lv
