@@ -642,7 +642,16 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
   // (bf16 convs on tile 22, the 256x64 tap-fused form); measured down to M = 2000 (w2 89 -> 70 us, fc2 65 -> 46 with five K ranges)
   const bool mid_split = (tile == 21 || tile == 22 || tile == 15 || tile == 25 || tile == 5 || tile == 3) && g.M >= 1536 && g.N >= 256 &&
                          epi == EPI_GATE_RES && deferred;
-  if (tile_auto && sizeof(T) == 2 && !g1 && (tile == 23 || tile == 19 || tile == 29 || mid_split)) {
+  // (round 6) two-problem launches - the audio + visual pair of a two-stream block's gated-residual layers (proj, fc2) - take the same
+  // route at mid-size grids: at M = 3000 + 480 they sat on 128x128 tiles (fc2 113 us where the single-problem form of the same shape
+  // takes 57 - 59 on 72 tiles x three K ranges)
+  static const bool wide_pair_on = []() { const char* e = getenv("FOLEY_WIDE_PAIR"); return !(e && e[0] == '0'); }();   // A/B switch
+  // ... where their 128x128 tiles do not fit ONE round of 256 workgroups (M = 3000 + 480: 336).  Where they do (bs = 4, M = 2000 + 320:
+  // 228 tiles, no K split, no slabs for the next LayerNorm to read) the 256x256 route with four K ranges LOSES 1.1 % of the loop.
+  const long pair_b128 = !g1 ? 0 : (long)((g.M + 127) / 128) * ((g.N + 127) / 128) + (long)((g1s.M + 127) / 128) * ((g1s.N + 127) / 128);
+  const bool pair_ok = !g1 || (wide_pair_on && mid_split && pair_b128 > 256 && !ws_conv3_ok && g1s.taps == 1 && g1s.segV >= g1s.M && g1s.rstride <= 1 && g1s.tap0 == 0 &&
+                               g1s.tapC % 32 == 0 && g1s.M >= 1 && g1s.N >= 256);
+  if (tile_auto && sizeof(T) == 2 && pair_ok && (tile == 23 || tile == 19 || tile == 29 || mid_split)) {
     static const bool wide_on = []() { const char* e = getenv("FOLEY_WIDE"); return !(e && e[0] == '0'); }();
     const bool conv = tile == 23 || tile == 21 || (mid_split && ws_conv3_ok);
     const bool epi_ok = epi == EPI_STORE_F32 || epi == EPI_GATE_RES || epi == EPI_SILUGATE_T || (!conv && epi == EPI_GELU_T);
@@ -653,7 +662,12 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
                                   // N = 331 776 columns - a 256-column tile re-reads the activations half as often: 60.6 -> 51.9 us per eighth)
                                   (g.K >= 2048 || mid_split || (epi == EPI_STORE_F32 && g.N >= 16384 && g.M >= 128)));
     if (wide_on && epi_ok && addr_ok && g.tapC % 32 == 0) {
-      const long mt = (g.M + 255) / 256, tw = mt * ((g.N + 255) / 256), tb = mt * ((g.N + 127) / 128);
+      long mt = (g.M + 255) / 256, tw = mt * ((g.N + 255) / 256), tb = mt * ((g.N + 127) / 128);
+      if (g1) {
+        const long mt1 = (g1s.M + 255) / 256;
+        tw += mt1 * ((g1s.N + 255) / 256);
+        tb += mt1 * ((g1s.N + 127) / 128);
+      }
       const int nk64 = (conv ? g.tapC : g.K) / 64;
       auto ksp = [&](long blocks) -> long {   // the K split the deferred rule below will choose for `blocks` tiles
         if (epi != EPI_GATE_RES) return 1;
@@ -673,7 +687,13 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
       // - w2 143 -> 97 us, fc2 99 -> 59 us with three K ranges); at M = 4000 the two slabs cost the next LayerNorm 12 us per launch
       // (pending form 21.6 vs 9.6 us) for 7 us won in the GEMM
       const bool split_ok = kw == 1 || eb < 0.6 || mid_split;
-      if (ew >= 0.74 && ew >= eb - 0.13 && split_ok && gemm_vec_out_ok<T>(gt, epi)) tile = conv ? 31 : 32;
+      bool vec1 = true;
+      if (g1) {
+        GemmArgs gt1 = g1s;
+        gt1.ksplit = (int)kw;
+        vec1 = gemm_vec_out_ok<T>(gt1, epi);
+      }
+      if (ew >= 0.74 && ew >= eb - 0.13 && split_ok && gemm_vec_out_ok<T>(gt, epi) && vec1) tile = conv ? 31 : 32;
     }
   }
   // A large conv grid whose 256-row tiles cover clearly less than one round of 256 CUs while 192-row tiles still fit it (w2 / linear1 at

@@ -320,7 +320,8 @@ __device__ __forceinline__ void gemm_wide_body(const GemmPair& pr) {
 }
 
 // PAIR: the launch may carry two problems (workgroups from pr.tiles0 on run the second one) - instantiated for the epilogues of
-// the two-stream blocks' K = 1536 layers only (fc1's GELU, the q/k/v head split): two bodies double the code of a kernel.
+// the two-stream blocks' plain layers only (fc1's GELU, the q/k/v head split, the gated-residual proj / fc2): two bodies double the
+// code of a kernel.
 template <typename T, int NW, int TAPS, int NSB, int NAB, int EPI, int WF, bool PAIR>
 __global__ __launch_bounds__(NW * 64) void gemm_wide_kernel(const GemmPair pr) {
   if constexpr (PAIR) {
@@ -340,8 +341,8 @@ int launch_wide_one(const GemmArgs& g, const GemmArgs* g1, hipStream_t st) {
   constexpr size_t lds_epi = (size_t)256 * 128 * 4;
   constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  constexpr bool PAIR = TAPS == 1 && (EPI == EPI_GELU_T || EPI == EPI_QKV_SPLIT);
-  if (g1 && !PAIR) return foley_set_err("256x256 GEMM: two-problem launches exist for the GELU and head-split epilogues of plain layers", __FILE__, __LINE__);
+  constexpr bool PAIR = TAPS == 1 && (EPI == EPI_GELU_T || EPI == EPI_QKV_SPLIT || EPI == EPI_GATE_RES);
+  if (g1 && !PAIR) return foley_set_err("256x256 GEMM: two-problem launches exist for the GELU, head-split and gated-residual epilogues of plain layers", __FILE__, __LINE__);
   auto ntiles = [](const GemmArgs& q) { return ((q.M + 255) / 256) * ((q.N + 255) / 256) * (EPI == EPI_GATE_RES ? q.ksplit : 1); };
   GemmPair pr;
   pr.g[0] = g;
