@@ -593,7 +593,11 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
     auto nblk = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn); };
     const long b128 = nblk(128, 128);
     const long rem = b128 % 256;
-    if (sizeof(T) == 2 && g.N > 64 && g.M > 128 && nblk(256, 128) >= 160) tile = 9;   // big grids: 64x64 per wave (one M tile: 128 rows
+    // (head-split pairs count both problems: the cross-attention q projection of the 30 s clip - 144 + 24 tiles of 256x128 in ONE round -
+    // sat on 336 tiles of 128x128 in two ragged ones: 39.8 us per launch)
+    static const bool pair_count = []() { const char* e = getenv("FOLEY_QKV_PAIR_COUNT"); return !(e && e[0] == '0'); }();   // A/B switch
+    const long pair256 = (pair_count && epi == EPI_QKV_SPLIT && g1) ? (long)((g1s.M + 255) / 256) * ((g1s.N + 127) / 128) : 0;
+    if (sizeof(T) == 2 && g.N > 64 && g.M > 128 && nblk(256, 128) + pair256 >= 160) tile = 9;   // big grids: 64x64 per wave (one M tile: 128 rows
                                                                                          // halve the activation DMA, modulation GEMM at M = 16: 258 -> 227 us)
     else if (deferred && g.N > 64 && b128 <= 256) tile = 5;   // 128x128 tiles, K ranges fill the chip (tools/gemm_timeline.py)
     else if (g.N <= 64 && epi != EPI_SILUGATE_T) tile = nblk(128, 64) >= 192 ? 4 : 3;
