@@ -2,9 +2,9 @@
 # Runs on the GPU box (via gpurun): bench lines, rocprofv3 kernel-trace stats of the bench command and
 # the PMC passes (separate runs, kernel filter - rocprofv3 segfaults in PyTorch's own kernels
 # otherwise), summarised into gpurun_out/ (the raw databases stay in /tmp: too large to ship back).
-#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r05 [tag-suffix]'
+#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r06 [tag-suffix]'
 set -u
-TAG=${1:-r05}${2:+_$2}
+TAG=${1:-r06}${2:+_$2}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out
 mkdir -p $OUT
