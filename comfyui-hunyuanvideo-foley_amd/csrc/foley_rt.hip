@@ -774,6 +774,13 @@ static int run_forward(foley_ctx* c, hipStream_t st) {
   const foley_plan& pl = c->plan;
   const ForwardW& W = c->fw;
   if (!W.ok) return FAIL(FOLEY_ERR_STATE, "forward weights are not resolved (foley_prepare)");
+  // one clip per CFG half: the small-grid GEMMs may rotate their K origin per M tile (gemm.hip: g_gemm_krot_ok) - with several clips
+  // in the batch, clips with equal noise must stay bit-identical, so their rows keep one summation order
+  struct KRotScope {
+    int prev;
+    explicit KRotScope(int v) : prev(g_gemm_krot_ok) { g_gemm_krot_ok = v; }
+    ~KRotScope() { g_gemm_krot_ok = prev; }
+  } krot_scope(pl.clips == 1 ? 1 : 0);
   const int D = f.hidden, H = f.heads, C = f.latent_dim, T = f.compute_dtype;
   const int ncfg = pl.ncfg, clips = pl.clips, La = pl.La, Lv = pl.Lv, Ls = pl.Ls, Lt = pl.Lt, NI = pl.n_iter;
   const int Bc = ncfg * clips, M = Bc * La, Mv = Bc * Lv, S = La + Lv;

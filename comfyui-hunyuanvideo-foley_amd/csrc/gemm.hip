@@ -4,6 +4,11 @@
 
 long long* g_gemm_dbg = nullptr;
 int g_gemm_dbg_mode = 0;
+// K-origin rotation (GemmArgs::k_rot) is an option of the CALLER: a row's summation order then depends on the M tile it falls into, so
+// rows with equal inputs no longer come out bit-identical.  The DiT forward of a single clip per CFG half opts in (foley_rt.hip::
+// run_forward); foley_prepare (its row-periodicity check compares bit patterns), batches (clips of a batch with equal noise stay
+// bit-identical) and the op-level entries do not.
+thread_local int g_gemm_krot_ok = 0;
 int g_gemm_pf_dist = 0;   // L2 prefetch distance of the wave-specialised mainloop (K-slices beyond the ring)
 
 int launch_gemm_typed_f32(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hipStream_t st, int* ksplit_used);

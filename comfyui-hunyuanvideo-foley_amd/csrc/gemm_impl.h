@@ -17,6 +17,7 @@
 extern long long* g_gemm_dbg;
 extern int g_gemm_dbg_mode;
 extern int g_gemm_pf_dist;
+extern thread_local int g_gemm_krot_ok;
 
 namespace {
 
@@ -861,6 +862,23 @@ int launch_typed(const GemmArgs& g_in, const GemmArgs* g1_in, int epi, int tile,
         }
       }
     }
+  }
+  {
+    // Small grids (one round of workgroups), plain layers on the wave-specialised tiles: K-origin rotation per M tile (GemmArgs::k_rot,
+    // gemm_ws_impl.h).  All M tiles of a weight panel start together and walk K in step, so every one of them waits for the SAME cold
+    // line (one HBM fill, the others queued behind it in the L2) - each holds a slot of its CU's memory queue for the full HBM latency.
+    // Started 1 / tiles_m of the range apart they take turns at the miss and find the other lines in the L2.  Only where the caller
+    // opted in (g_gemm_krot_ok, gemm.hip: the summation order of a row then depends on its tile).  FOLEY_K_ROTATE=0: off.
+    static const bool krot = []() { const char* e = getenv("FOLEY_K_ROTATE"); return !(e && e[0] == '0'); }();
+    const int rbm = tile == 27 ? 64 : tile == 26 ? 96 : (tile == 15 || tile == 25) ? 128 : tile == 28 ? 192 : (tile == 19 || tile == 29) ? 256 : 0;
+    g.k_rot = 0;
+    if (krot && g_gemm_krot_ok && rbm && sizeof(T) == 2 && g.taps == 1 && (!g1 || g1s.taps == 1)) {
+      const long ks_ = epi == EPI_GATE_RES ? g.ksplit : 1;
+      long n = (long)((g.M + rbm - 1) / rbm) * ((g.N + 127) / 128) * ks_;
+      if (g1) n += (long)((g1s.M + rbm - 1) / rbm) * ((g1s.N + 127) / 128) * ks_;
+      if (n <= 256 && (g.M + rbm - 1) / rbm >= 2) g.k_rot = 1;
+    }
+    if (g1) g1s.k_rot = g.k_rot;
   }
   g.vec_out = gemm_vec_out_ok<T>(g, epi) ? 1 : 0;
   if (g1) g1s.vec_out = gemm_vec_out_ok<T>(g1s, epi) ? 1 : 0;

@@ -217,9 +217,12 @@ __device__ __forceinline__ void gemm_ws_body(const GemmPair& pr) {
         vA[i] = in ? a_base[i] + toff * (int)(g.lda * ESZ) : OOB;
       }
     };
-    int ld_k0 = kt_begin * BK;
+    // K-origin rotation (GemmArgs::k_rot; plain layers): the walk starts at slice `rot` of the range and wraps at its end
+    const int k_lo = kt_begin * BK, k_hi = (kt_begin + nk) * BK;
+    const bool rotate = g.k_rot && g.taps == 1 && tiles_m > 1;
+    int ld_k0 = k_lo + (rotate ? (int)((long)tm * nk / tiles_m) * BK : 0);
     int ld_c0 = ld_k0, ld_toff = g.tap0;
-    if (kt_begin > 0) {
+    if (kt_begin > 0 && !rotate) {
       const int tap = ld_k0 / g.tapC;
       ld_c0 = ld_k0 - tap * g.tapC;
       ld_toff = g.tap0 + tap * g.dil;
@@ -235,7 +238,9 @@ __device__ __forceinline__ void gemm_ws_body(const GemmPair& pr) {
       for (int i = 0; i < BI; ++i) buf_lds16(g.W, g.w_bytes, Bs + (lw * BI + i) * 1024, vW[i], sW);
       ld_k0 += BK;
       ld_c0 += BK;
-      if (ld_c0 >= g.tapC) {
+      if (rotate) {            // one tap: channel offset == K offset
+        if (ld_k0 >= k_hi) ld_k0 = ld_c0 = k_lo;
+      } else if (ld_c0 >= g.tapC) {
         ld_c0 = 0;
         ld_toff += g.dil;
         set_tap(ld_toff);

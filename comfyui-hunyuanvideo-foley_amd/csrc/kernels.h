@@ -92,6 +92,9 @@ struct GemmArgs {
                       // groups (the workgroups that run together then cover a near-square block of tiles); 0 = [panel][M tile]
   int ks_major;       // set by the launcher: workgroup order of a split - 1: K range slowest (all tiles of a range are neighbours, i.e. on
                       // one or two XCDs: only those L2s fetch that range's activation columns), 0: K range fastest
+  int k_rot;          // set by the launcher (small grids, plain layers): M tile tm of a weight panel starts its K walk at slice tm * nk / tiles_m
+                      // and wraps - the M tiles of a panel (neighbours on one XCD) then reach every weight line at different times: ONE of
+                      // them takes the HBM miss, the others find the line in their L2 instead of all waiting for the same fill in lockstep
   QkvSplitArgs qs;    // EPI_QKV_SPLIT: destination / norm / rotation description (qs.qkv, qs.M unused)
   int vec_out;        // set by the launcher: the problem qualifies for the LDS-transposed vector epilogue
   int wfmt;           // storage of W: 0 = the operand dtype, 1 = fp8 e4m3fn, 2 = fp8 e5m2 (bf16 activations; wave-specialised
@@ -117,6 +120,7 @@ int launch_gemm_ws_bf16(const GemmArgs& g, const GemmArgs* g1, int epi, int tile
 int launch_gemm_ws_f16(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hipStream_t st);
 // 256x256 tiles on the BK = 32 mainloop (gemm_wide_impl.h): tile 31 = tap-fused conv k=3, 32 = plain linear layer (eight waves of
 // 128x64); single problem, vector epilogue, any weight storage
+extern thread_local int g_gemm_krot_ok;   // gemm.hip
 int launch_gemm_wide_bf16(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hipStream_t st);
 int launch_gemm_wide_f16(const GemmArgs& g, const GemmArgs* g1, int epi, int tile, hipStream_t st);
 
