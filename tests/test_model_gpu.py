@@ -625,6 +625,40 @@ def test_large_grid_tiles_against_the_oracle(dev, name, hidden, heads, dtype, fm
                 assert e < tol, (name, prec, fmt, dur, b, e)
 
 
+@pytest.mark.parametrize("dur,clips,fmt", [(8.0, 2, "none"), (12.0, 3, "none"), (3.7, 5, "none"), (20.0, 1, "none"), (1.0, 16, "none"),
+                                           (12.0, 3, "fp8_e4m3fn"), (20.0, 1, "fp8_e4m3fn")])
+def test_tile_rules_across_shapes(dev, dur, clips, fmt):
+    """The launcher's tile rules change with the grid (one- vs multi-round launches, two-problem launches on the 256x256 tiles, the
+    pair-counting head-split rule, K-origin rotation for single clips): one depth-1+1 full-width forward per shape BETWEEN the benchmarked
+    ones (M = 800 ... 3600 audio rows, ragged durations), bf16 and fp8 storage, against the fp32 oracle on the same rounded weights."""
+    from foley_amd import nodes
+    c = C.DiTConfig(name="xxl-1-1", depth_triple=1, depth_single=1, hidden=1536, heads=12)
+    sd = synth.synth_dit_state_dict(c)
+    model = nodes.HunyuanModelLoader.pack_state_dict(sd, "bf16", fmt, device=dev, cfg=c)
+    sdq = nodes.fp8_round_state_dict(nodes.round_params(sd, torch.bfloat16), fmt, autocast=True, param_dtype=torch.bfloat16) if fmt != "none" else nodes.round_params(sd, torch.bfloat16)
+    sdq = {k: v.float() for k, v in sdq.items()}
+    La, Lv, Ls = C.lengths(dur, c)
+    cond = synth.synth_conditioning(c, dur, t2a=False, sd=sd)
+    x = torch.randn(clips, 128, La, generator=torch.Generator().manual_seed(43)).to(torch.bfloat16).float()
+    steps, it = 10, 6
+    vis = {"siglip2_feat": cond["clip"], "syncformer_feat": cond["sync"]}
+    txt = {"text_feat": cond["text"], "uncond_text_feat": cond["uncond_text"]}
+    model.ctx.prepare(sampler.build_plan(model, vis, txt, La, 4.5, steps, clips, "euler"))
+    rows = model.ctx.dit_forward(x.to(dev).contiguous(), it).float().cpu()
+    t_it = tables.model_timesteps(tables.sigma_grid(steps))[it]
+    text77, unc77 = O.pad_or_trim_text(cond["text"]), O.pad_or_trim_text(cond["uncond_text"])
+    e_clip = sd["empty_clip_feat"].view(1, 1, -1).expand(1, Lv, -1)
+    e_sync = sd["empty_sync_feat"].view(1, 1, -1).expand(1, Ls, -1)
+    b = clips - 1
+    with torch.inference_mode():
+        ref = O.dit_forward(sdq, c.heads, torch.cat([x[b:b + 1], x[b:b + 1]]), t_it.expand(2), torch.cat([unc77, text77]),
+                            torch.cat([e_clip, cond["clip"]]), torch.cat([e_sync, cond["sync"]]))
+    got = torch.stack([rows.view(2, clips, La, 128)[0, b], rows.view(2, clips, La, 128)[1, b]]).transpose(1, 2)
+    e = rel_err(got, ref)
+    print("%gs x %d clips %s: %.2e" % (dur, clips, fmt, e))
+    assert e < (5e-3 if fmt == "none" else 8e-3), (dur, clips, fmt, e)
+
+
 def test_xl_dimensions_forward(dev):
     """The xl model family (D=1408, 11 heads: N/K not multiples of 128/256) at depth 1+1 against the
     oracle - exercises the N-edge masking of every GEMM tile and the 11-head split."""
